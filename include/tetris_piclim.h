@@ -1,0 +1,132 @@
+/*
+ * tetris_piclim.h -- C ABI of the MI355X-native batched Tetris-piclim environment.
+ *
+ * Drop-in boundary for the reference's hot path.  The reference has no FFI today: callers use the Python
+ * object `Tetris` (game/tetris.py:140-214 of the upstream repo).  Each entry point below names the
+ * reference interface it replaces; INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative tpl_status; tpl_last_error() gives the message of the
+ *     calling thread's last failure.  No C++ exception crosses this boundary.
+ *   - all data pointers are DEVICE pointers on the handle's GPU unless a parameter says "host".
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls only enqueue work: no
+ *     host synchronisation happens inside tpl_step / tpl_move / tpl_reset / tpl_get_state / tpl_expand_obs,
+ *     so they can be captured into a hipGraph.
+ *   - one handle per GPU; a handle is not re-entrant.
+ *
+ * Interchange layout (what callers see; the resident HBM layout is private)
+ *   board   uint16_t rows[20]  row 0 = top, bit x = column x        <- Tetris.board, 20x10 bool (:186)
+ *   pieces  uint8_t  [M+1]     I0 L1 J2 T3 S4 Z5 O6, [0] falls first <- Tetris.pieces (:187), ids (:8-16)
+ *   state   0 running / 1 won / 2 lost                              <- Tetris.state None/True/False (:151)
+ *   action  rot*10 + loc, rot 0..3, loc 0..9                         <- move(rotations, location) (:354)
+ */
+#ifndef TETRIS_PICLIM_H
+#define TETRIS_PICLIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TPL_ROWS 20
+#define TPL_COLS 10
+#define TPL_OBS_DIM 217            /* Model(217, 14), model/train.py:26 */
+#define TPL_NUM_ACTIONS 40
+
+typedef struct tpl_env tpl_env;    /* opaque handle */
+
+typedef enum {
+    TPL_OK = 0,
+    TPL_ERR_ARG = -1,              /* bad argument (null pointer, out-of-range L/M/n, ...) */
+    TPL_ERR_HIP = -2,              /* a HIP runtime call failed; message carries hipGetErrorString */
+    TPL_ERR_STATE = -3,            /* call order violated (e.g. reset before any configs were loaded) */
+    TPL_ERR_NOMEM = -4
+} tpl_status;
+
+typedef enum { TPL_U8 = 0, TPL_I32 = 1, TPL_I64 = 2 } tpl_int_dtype;      /* dtype of action / rot / loc arrays */
+typedef enum { TPL_F32 = 0, TPL_BF16 = 1 } tpl_obs_dtype;
+typedef enum { TPL_ASSIGN_HASH = 0, TPL_ASSIGN_SEQUENTIAL = 1 } tpl_assign_mode;
+
+/* Message of the last failure on this thread ("" if none). */
+const char* tpl_last_error(void);
+
+/* Library version string and the offload architecture it was built for ("gfx950"). */
+const char* tpl_version(void);
+
+/* Bytes of device memory a handle needs for `num_envs` boards with move limit M. */
+size_t tpl_workspace_bytes(int64_t num_envs, int32_t M);
+/* Bytes of device memory a pool of `n_cfg` prescribed configurations needs. */
+size_t tpl_pool_bytes(int64_t n_cfg, int32_t M);
+
+/* Replaces Tetris.__init__(L, M, ...) (game/tetris.py:141-214) for `num_envs` boards on GPU `device_id`.
+ * `global_offset` is the global index of this handle's board 0 (batch-index sharding over GPUs); `seed`
+ * keys the configuration assignment.  `workspace` is caller-owned device memory of at least
+ * tpl_workspace_bytes() (256-byte aligned), or NULL to let the library hipMalloc its own.
+ * Limits: 1 <= L <= 255, 1 <= M <= 254. */
+int tpl_create(tpl_env** out, int64_t num_envs, int32_t L, int32_t M, int32_t device_id,
+               int64_t global_offset, uint64_t seed, void* workspace, size_t workspace_bytes);
+
+/* Replaces Tetris.terminate() (game/tetris.py:451-470).  Frees only what the library allocated. */
+int tpl_destroy(tpl_env* env);
+
+/* auto_reset: a board that finishes during a step is re-initialised from the pool in that same step
+ * (done is still reported 1 for that step).  Off: finished boards are frozen (reward 0, done 1).
+ * reward = per_line * rows_cleared (+ win when the move wins) (+ lose when the move loses). */
+int tpl_set_options(tpl_env* env, int32_t auto_reset, int32_t assign_mode,
+                    float reward_per_line, float reward_win, float reward_lose);
+
+/* Replaces the warm-reset supply (queue of (board, pieces), game/tetris.py:195,445-449): uploads a pool of
+ * prescribed configurations that resets draw from.  rows: [n_cfg][20] uint16, pieces: [n_cfg][M+1] uint8,
+ * both device pointers.  `pool_mem` is caller-owned device memory of tpl_pool_bytes() or NULL. */
+int tpl_load_configs(tpl_env* env, const uint16_t* rows, const uint8_t* pieces, int64_t n_cfg,
+                     void* pool_mem, size_t pool_bytes, void* stream);
+
+/* Replaces Tetris.reset() (game/tetris.py:438-443).  mask == NULL: every board starts episode 0 and the
+ * statistics are zeroed; otherwise boards with mask[i] != 0 start their next episode.  Unlike the reference,
+ * lines_cleared / moves_used / state ARE zeroed. */
+int tpl_reset(tpl_env* env, const uint8_t* mask, void* stream);
+
+/* Replaces Tetris.move(rotations, location) (game/tetris.py:354-422), one move on every board.
+ * rot/loc: arrays of `dtype`; rot is taken modulo the piece's rotation count, loc is right-clamped to
+ * 10 - width (:364); values must be >= 0.  Outputs (each may be NULL): reward f32[n], done u8[n],
+ * cleared u8[n] (rows cleared by this move). */
+int tpl_move(tpl_env* env, const void* rot, const void* loc, int32_t dtype,
+             float* reward, uint8_t* done, uint8_t* cleared, void* stream);
+
+/* step(action): move(action / 10, action % 10).  The surface BASELINE.json's north_star names. */
+int tpl_step(tpl_env* env, const void* action, int32_t dtype, float* reward, uint8_t* done, void* stream);
+
+/* Replaces Tetris.get_state() (game/tetris.py:435-436) and the public attributes, batched and in the
+ * interchange layout.  Any output may be NULL.  rows [n][20] u16; cur/nxt u8[n] (7 = no such piece);
+ * lines/moves u8[n] (lines_cleared, moves_used -- L_rem = L - lines, M_rem = M - moves); state u8[n];
+ * pieces_left u8[n] = len(Tetris.pieces). */
+int tpl_get_state(tpl_env* env, uint16_t* rows, uint8_t* cur, uint8_t* nxt, uint8_t* lines,
+                  uint8_t* moves, uint8_t* state, uint8_t* pieces_left, void* stream);
+
+/* Observation for Model(217, 14) (model/train.py:26): out [n][217] of `dtype`:
+ * 200 cells row-major (y*10+x), one-hot current piece (7), one-hot next piece (7), L_rem, M_rem, terminal. */
+int tpl_expand_obs(tpl_env* env, void* out, int32_t dtype, void* stream);
+
+/* Statistics over episodes finished since the last full reset, reduced on the device into
+ * out[4] (device pointer, uint64): {episodes, sum of lines_cleared at finish, wins, top-outs}. */
+int tpl_get_stats(tpl_env* env, uint64_t* out, void* stream);
+
+/* Host-side decode of the device shape table: get_tetromino(piece, rotations) (game/tetris.py:60-61).
+ * masks[4]: row masks top->bottom (bit x = mask column x), revtopo[4]: reverse topography.  No GPU needed. */
+int tpl_shape_info(int32_t piece, int32_t rotations, int32_t* h, int32_t* w, uint8_t* masks, uint8_t* revtopo);
+
+/* Raw device pointers of the resident packed state (for zero-copy inspection; layout in DESIGN.md). */
+int tpl_state_ptrs(tpl_env* env, void** plane_a, void** plane_b, void** queue, int32_t* queue_words);
+
+/* Synthetic workload of SURVEY 8(d), generated on the device, identical to the oracle's generator. */
+int tpl_synth_configs(tpl_env* env, uint64_t seed, int64_t first, int64_t count,
+                      uint16_t* rows, uint8_t* pieces, void* stream);
+int tpl_synth_actions(tpl_env* env, uint64_t seed, int64_t first, int64_t count, uint64_t step,
+                      uint8_t* action, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,375 @@
+/*
+ * tetris_oracle.c -- CPU ORACLE for the Tetris-piclim board step.  TEST INFRASTRUCTURE ONLY
+ * (see tetris_oracle.h for who may use it).  Every function cites the reference lines it restates;
+ * citations are relative to the upstream repo root (game/tetris.py unless another file is named).
+ *
+ * Pinned by the tests/golden/ fixtures, which were generated from the imported reference.
+ */
+#include "tetris_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * Shape table: `tetrominos` (game/tetris.py:23-57).  Each entry is (mask rows top->bottom,
+ * reverse_topography).  Row masks use bit x = mask column x, so the reference's
+ * ((False, False, True), (True, True, True)) for L rot 0 is {0b100, 0b111} = {4, 7}.
+ * Piece ids follow piece_translations (game/tetris.py:8-16): I0 L1 J2 T3 S4 Z5 O6.
+ * ---------------------------------------------------------------------------------------------- */
+static const int N_ROT[7] = {2, 4, 4, 4, 2, 2, 1};
+
+static const to_shape SHAPES[7][4] = {
+    /* I  :24-27 */ {{1, 4, {15, 0, 0, 0}, {0, 0, 0, 0}}, {4, 1, {1, 1, 1, 1}, {3, 0, 0, 0}}, {0}, {0}},
+    /* L  :28-33 */ {{2, 3, {4, 7, 0, 0}, {1, 1, 1, 0}}, {3, 2, {3, 2, 2, 0}, {0, 2, 0, 0}},
+                     {2, 3, {7, 1, 0, 0}, {1, 0, 0, 0}}, {3, 2, {1, 1, 3, 0}, {2, 2, 0, 0}}},
+    /* J  :34-39 */ {{2, 3, {1, 7, 0, 0}, {1, 1, 1, 0}}, {3, 2, {2, 2, 3, 0}, {2, 2, 0, 0}},
+                     {2, 3, {7, 4, 0, 0}, {0, 0, 1, 0}}, {3, 2, {3, 1, 1, 0}, {2, 0, 0, 0}}},
+    /* T  :40-45 */ {{2, 3, {2, 7, 0, 0}, {1, 1, 1, 0}}, {3, 2, {2, 3, 2, 0}, {1, 2, 0, 0}},
+                     {2, 3, {7, 2, 0, 0}, {0, 1, 0, 0}}, {3, 2, {1, 3, 1, 0}, {2, 1, 0, 0}}},
+    /* S  :46-49 */ {{2, 3, {6, 3, 0, 0}, {1, 1, 0, 0}}, {3, 2, {1, 3, 2, 0}, {1, 2, 0, 0}}, {0}, {0}},
+    /* Z  :50-53 */ {{2, 3, {3, 6, 0, 0}, {0, 1, 1, 0}}, {3, 2, {2, 3, 1, 0}, {2, 1, 0, 0}}, {0}, {0}},
+    /* O  :54-56 */ {{2, 2, {3, 3, 0, 0}, {1, 1, 0, 0}}, {0}, {0}, {0}},
+};
+
+int to_num_rotations(int piece) { return N_ROT[piece]; }
+
+/* get_tetromino (game/tetris.py:60-61): tetrominos[piece][rotations % len(tetrominos[piece])] */
+void to_get_tetromino(int piece, int rotations, to_shape* out) {
+    *out = SHAPES[piece][rotations % N_ROT[piece]];
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Tetris.move (game/tetris.py:354-422) with calculate_drop_deltas (:427-433) and calculate_drop
+ * (:424-425).  Same operation order as the reference.
+ * ---------------------------------------------------------------------------------------------- */
+int to_move(to_game* g, const uint8_t* pieces, int L, int M, int rotations, int location) {
+    /* :356  piece = self.pieces.pop(0) -- consumed before anything can fail */
+    int piece = pieces[g->cursor];
+    g->cursor += 1;
+
+    /* :359-360 */
+    to_shape s;
+    to_get_tetromino(piece, rotations, &s);
+
+    /* :363-364  right clamp only */
+    if (location > TO_COLS - s.w) location = TO_COLS - s.w;
+
+    /* :427-433  board topography under the piece's columns, minus the piece's reverse topography */
+    int min_delta = 1 << 20;
+    for (int c = 0; c < s.w; ++c) {
+        int top = TO_ROWS; /* :431  20 when the column is empty */
+        for (int r = 0; r < TO_ROWS; ++r) {
+            if ((g->rows[r] >> (location + c)) & 1u) { top = r; break; }
+        }
+        int delta = top - (int)s.revtopo[c];
+        if (delta < min_delta) min_delta = delta;
+    }
+    /* :424-425 */
+    int drop = min_delta - 1;
+
+    /* :372-374  top-out: state False, nothing else changes (moves_used is NOT incremented) */
+    if (drop < 0) {
+        g->state = TO_LOST;
+        return -1;
+    }
+
+    /* :377-379  lock */
+    for (int i = 0; i < s.h; ++i) g->rows[drop + i] |= (uint16_t)((uint16_t)s.mask[i] << location);
+    g->moves_used += 1;
+
+    /* :382-386  only the piece's rows are tested */
+    int full[4] = {0, 0, 0, 0};
+    int rows_cleared = 0;
+    for (int i = 0; i < s.h; ++i) {
+        full[i] = (g->rows[drop + i] == TO_FULL_ROW);
+        rows_cleared += full[i];
+    }
+
+    /* :389-394 */
+    if (rows_cleared == 0) {
+        if (g->moves_used >= M) g->state = TO_LOST;
+        return 0;
+    }
+
+    /* :397-407  keep the rows that are not cleared, in order, under `rows_cleared` empty rows */
+    uint16_t kept[TO_ROWS];
+    int nk = 0;
+    for (int r = 0; r < TO_ROWS; ++r) {
+        int cleared = (r >= drop && r < drop + s.h && full[r - drop]);
+        if (!cleared) kept[nk++] = g->rows[r];
+    }
+    for (int r = 0; r < rows_cleared; ++r) g->rows[r] = 0;
+    for (int r = 0; r < nk; ++r) g->rows[rows_cleared + r] = kept[r];
+
+    /* :409 */
+    g->lines_cleared += rows_cleared;
+
+    /* :415-417  win is tested before the move limit */
+    if (g->lines_cleared >= L) {
+        g->state = TO_WON;
+        return rows_cleared;
+    }
+    /* :420-422 */
+    if (g->moves_used >= M) g->state = TO_LOST;
+    return rows_cleared;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Counter-based generator for the synthetic workload.  splitmix64 finaliser chained
+ * over (seed, stream, index, counter).  The HIP library implements the same function.
+ * ---------------------------------------------------------------------------------------------- */
+static inline uint64_t sm64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+uint64_t to_rng(uint64_t seed, uint64_t stream, uint64_t index, uint64_t counter) {
+    uint64_t h = sm64(seed ^ (stream * 0xD1B54A32D192ED03ULL));
+    h = sm64(h ^ index);
+    return sm64(h ^ counter);
+}
+
+enum { STREAM_BOARD = 0, STREAM_PIECES = 1, STREAM_ACTION = 2, STREAM_ASSIGN = 3 };
+
+/* rows 20-L..19: ten Bernoulli(1/2) cells; a row that comes out full has one hashed cell cleared */
+void to_synth_boards(uint64_t seed, int64_t first, int64_t count, int L, uint16_t* rows) {
+    int filled = L < TO_ROWS ? L : TO_ROWS;
+    for (int64_t b = 0; b < count; ++b) {
+        uint16_t* out = rows + b * TO_ROWS;
+        for (int r = 0; r < TO_ROWS; ++r) {
+            uint16_t v = 0;
+            if (r >= TO_ROWS - filled) {
+                uint64_t h = to_rng(seed, STREAM_BOARD, (uint64_t)(first + b), (uint64_t)r);
+                v = (uint16_t)(h & TO_FULL_ROW);
+                if (v == TO_FULL_ROW) v &= (uint16_t)~(1u << ((h >> 10) % 10u));
+            }
+            out[r] = v;
+        }
+    }
+}
+
+/* ceil((M+1)/7) Fisher-Yates-shuffled 7-bags truncated to M+1 -- the statistical form of
+ * RandomPieceGenerator.get_random_sequence (game/tetris.py:91-102). */
+void to_synth_pieces(uint64_t seed, int64_t first, int64_t count, int M, uint8_t* pieces) {
+    int len = M + 1;
+    for (int64_t b = 0; b < count; ++b) {
+        uint8_t* out = pieces + b * len;
+        int produced = 0;
+        for (int bag = 0; produced < len; ++bag) {
+            uint64_t h = to_rng(seed, STREAM_PIECES, (uint64_t)(first + b), (uint64_t)bag);
+            uint8_t a[7] = {0, 1, 2, 3, 4, 5, 6};
+            for (int j = 6; j >= 1; --j) {
+                unsigned k = (unsigned)((h >> (8 * (6 - j))) & 0xFFu) % (unsigned)(j + 1);
+                uint8_t t = a[j]; a[j] = a[k]; a[k] = t;
+            }
+            for (int j = 0; j < 7 && produced < len; ++j) out[produced++] = a[j];
+        }
+    }
+}
+
+/* uniform rot 0..3, loc 0..9, keyed by (board, step); action = rot*10 + loc */
+void to_synth_actions(uint64_t seed, int64_t first, int64_t count, uint64_t step, uint8_t* action) {
+    for (int64_t b = 0; b < count; ++b) {
+        uint64_t h = to_rng(seed, STREAM_ACTION, (uint64_t)(first + b), step);
+        unsigned rot = (unsigned)(h & 3u);
+        unsigned loc = (unsigned)((h >> 8) & 0xFFFFu) % 10u;
+        action[b] = (uint8_t)(rot * 10u + loc);
+    }
+}
+
+uint64_t to_board_hash(const uint16_t* rows) {
+    uint64_t h = 0xcbf29ce484222325ULL;
+    for (int r = 0; r < TO_ROWS; ++r) h = (h ^ (uint64_t)rows[r]) * 0x100000001b3ULL;
+    return h;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched environment (build-defined rules; the HIP library follows the same ones).
+ * ---------------------------------------------------------------------------------------------- */
+to_env* to_env_create(int64_t n, int L, int M, int64_t global_offset, uint64_t seed) {
+    to_env* e = (to_env*)calloc(1, sizeof(to_env));
+    e->n = n; e->L = L; e->M = M; e->global_offset = global_offset; e->seed = seed;
+    e->auto_reset = 0; e->assign_mode = 0;
+    e->reward_per_line = 1.0f; e->reward_win = 0.0f; e->reward_lose = 0.0f;
+    e->games = (to_game*)calloc((size_t)n, sizeof(to_game));
+    e->pieces = (uint8_t*)calloc((size_t)n * (size_t)(M + 1), 1);
+    e->episode = (uint32_t*)calloc((size_t)n, sizeof(uint32_t));
+    return e;
+}
+
+void to_env_destroy(to_env* e) {
+    if (!e) return;
+    free(e->games); free(e->pieces); free(e->episode); free(e);
+}
+
+void to_env_set_pool(to_env* e, const uint16_t* rows, const uint8_t* pieces, int64_t n_cfg) {
+    e->pool_rows = rows; e->pool_pieces = pieces; e->n_cfg = n_cfg;
+}
+
+void to_env_set_options(to_env* e, int auto_reset, int assign_mode, float per_line, float win, float lose) {
+    e->auto_reset = auto_reset; e->assign_mode = assign_mode;
+    e->reward_per_line = per_line; e->reward_win = win; e->reward_lose = lose;
+}
+
+/* Which pool entry a board's episode starts from.  32-bit mixing (murmur3 finaliser) so the device
+ * pays a handful of integer ops per reset; the range reduction is a multiply-high, not a modulo. */
+static inline uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+int64_t to_env_assign(const to_env* e, int64_t board, uint32_t episode) {
+    uint64_t g = (uint64_t)(e->global_offset + board);
+    if (e->assign_mode == 1) return (int64_t)((g + (uint64_t)episode) % (uint64_t)e->n_cfg);
+    uint32_t h = fmix32((uint32_t)g ^ ((uint32_t)(g >> 32) * 0x9E3779B9u) ^ (uint32_t)e->seed);
+    h = fmix32(h + episode * 0x9E3779B1u + (uint32_t)(e->seed >> 32));
+    return (int64_t)(((uint64_t)h * (uint64_t)(uint32_t)e->n_cfg) >> 32);
+}
+
+/* reset()/load_warm_reset() (game/tetris.py:438-449): clear, then take the next (board, pieces).
+ * Unlike the reference (which leaves lines_cleared/moves_used/state untouched -- SURVEY 3.3) the
+ * counters and the state are zeroed. */
+static void load_config(to_env* e, int64_t b) {
+    int64_t cfg = to_env_assign(e, b, e->episode[b]);
+    to_game* g = &e->games[b];
+    memcpy(g->rows, e->pool_rows + cfg * TO_ROWS, sizeof(g->rows));
+    memcpy(e->pieces + b * (e->M + 1), e->pool_pieces + cfg * (e->M + 1), (size_t)(e->M + 1));
+    g->lines_cleared = 0; g->moves_used = 0; g->state = TO_RUNNING; g->cursor = 0;
+}
+
+void to_env_reset(to_env* e, const uint8_t* mask) {
+    for (int64_t b = 0; b < e->n; ++b) {
+        if (mask && !mask[b]) continue;
+        /* a full reset() starts episode numbering over; a masked reset starts the board's next episode */
+        e->episode[b] = mask ? ((e->episode[b] + 1u) & 0xFFFFu) : 0u;
+        load_config(e, b);
+    }
+    if (!mask) { e->stat_episodes = e->stat_lines = e->stat_wins = e->stat_topouts = 0; }
+}
+
+static void env_move_one(to_env* e, int64_t b, int rot, int loc, float* reward, uint8_t* done, uint8_t* cleared) {
+    to_game* g = &e->games[b];
+    float r = 0.0f; int n = 0;
+    if (g->state == TO_RUNNING) {
+        int res = to_move(g, e->pieces + b * (e->M + 1), e->L, e->M, rot, loc);
+        n = res < 0 ? 0 : res;
+        r = e->reward_per_line * (float)n;
+        if (g->state == TO_WON) r = r + e->reward_win;
+        if (g->state == TO_LOST) r = r + e->reward_lose;
+        if (g->state != TO_RUNNING) {
+            e->stat_episodes += 1;
+            e->stat_lines += (uint64_t)g->lines_cleared;
+            e->stat_wins += (g->state == TO_WON);
+            e->stat_topouts += (res < 0);
+            if (done) done[b] = 1;
+            if (e->auto_reset) {
+                e->episode[b] = (e->episode[b] + 1u) & 0xFFFFu;
+                load_config(e, b);
+            }
+        } else if (done) {
+            done[b] = 0;
+        }
+    } else if (done) {
+        done[b] = 1;   /* frozen */
+    }
+    if (reward) reward[b] = r;
+    if (cleared) cleared[b] = (uint8_t)n;
+}
+
+void to_env_move(to_env* e, const uint8_t* rot, const uint8_t* loc, float* reward, uint8_t* done, uint8_t* cleared) {
+    for (int64_t b = 0; b < e->n; ++b) env_move_one(e, b, rot[b], loc[b], reward, done, cleared);
+}
+
+/* action = rot*10 + loc (4 rotation x 10 location choices) */
+void to_env_step(to_env* e, const uint8_t* action, float* reward, uint8_t* done) {
+    for (int64_t b = 0; b < e->n; ++b) env_move_one(e, b, action[b] / 10, action[b] % 10, reward, done, NULL);
+}
+
+/* get_state (game/tetris.py:435-436), batched; a missing piece (list exhausted) reads as 7 */
+void to_env_get_state(const to_env* e, uint16_t* rows, uint8_t* cur, uint8_t* nxt,
+                      uint8_t* lines, uint8_t* moves, uint8_t* state, uint8_t* pieces_left) {
+    int len = e->M + 1;
+    for (int64_t b = 0; b < e->n; ++b) {
+        const to_game* g = &e->games[b];
+        const uint8_t* p = e->pieces + b * len;
+        if (rows) memcpy(rows + b * TO_ROWS, g->rows, sizeof(g->rows));
+        if (cur) cur[b] = g->cursor < len ? p[g->cursor] : 7;
+        if (nxt) nxt[b] = g->cursor + 1 < len ? p[g->cursor + 1] : 7;
+        if (lines) lines[b] = (uint8_t)g->lines_cleared;
+        if (moves) moves[b] = (uint8_t)g->moves_used;
+        if (state) state[b] = (uint8_t)g->state;
+        if (pieces_left) pieces_left[b] = (uint8_t)(len - g->cursor);
+    }
+}
+
+void to_env_expand_obs(const to_env* e, float* out) {
+    int len = e->M + 1;
+    for (int64_t b = 0; b < e->n; ++b) {
+        const to_game* g = &e->games[b];
+        const uint8_t* p = e->pieces + b * len;
+        float* o = out + b * 217;
+        for (int y = 0; y < TO_ROWS; ++y)
+            for (int x = 0; x < TO_COLS; ++x) o[y * 10 + x] = (float)((g->rows[y] >> x) & 1u);
+        int cur = g->cursor < len ? p[g->cursor] : 7;
+        int nxt = g->cursor + 1 < len ? p[g->cursor + 1] : 7;
+        for (int k = 0; k < 7; ++k) { o[200 + k] = (cur == k) ? 1.0f : 0.0f; o[207 + k] = (nxt == k) ? 1.0f : 0.0f; }
+        o[214] = (float)(e->L - g->lines_cleared);
+        o[215] = (float)(e->M - g->moves_used);
+        o[216] = g->state != TO_RUNNING ? 1.0f : 0.0f;
+    }
+}
+
+void to_env_get_stats(const to_env* e, uint64_t out[4]) {
+    out[0] = e->stat_episodes; out[1] = e->stat_lines; out[2] = e->stat_wins; out[3] = e->stat_topouts;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * cpu_baseline: the loop shape of game/performance_test.py:13-17 (move; reset when finished) over
+ * `count` synthetic boards in lockstep, one contiguous slice per thread.
+ * ---------------------------------------------------------------------------------------------- */
+static double now_s(void) {
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int64_t to_bench_run(uint64_t seed, int64_t count, int L, int M, int64_t steps, int threads, double* seconds) {
+    uint16_t* rows = (uint16_t*)malloc((size_t)count * TO_ROWS * sizeof(uint16_t));
+    uint8_t* pcs = (uint8_t*)malloc((size_t)count * (size_t)(M + 1));
+    uint8_t* act = (uint8_t*)malloc((size_t)count * (size_t)steps);
+    to_synth_boards(seed, 0, count, L, rows);
+    to_synth_pieces(seed, 0, count, M, pcs);
+    for (int64_t s = 0; s < steps; ++s) to_synth_actions(seed, 0, count, (uint64_t)s, act + s * count);
+    if (threads < 1) threads = 1;
+    to_env** envs = (to_env**)calloc((size_t)threads, sizeof(to_env*));
+    int64_t per = (count + threads - 1) / threads;
+    for (int t = 0; t < threads; ++t) {
+        int64_t lo = t * per, hi = lo + per > count ? count : lo + per;
+        if (hi <= lo) continue;
+        envs[t] = to_env_create(hi - lo, L, M, lo, seed);
+        to_env_set_pool(envs[t], rows, pcs, count);
+        to_env_set_options(envs[t], 1, 1, 1.0f, 0.0f, 0.0f);
+        to_env_reset(envs[t], NULL);
+    }
+    float* reward = (float*)malloc((size_t)count * sizeof(float));
+    uint8_t* done = (uint8_t*)malloc((size_t)count);
+    double t0 = now_s();
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(static, 1)
+#endif
+    for (int t = 0; t < threads; ++t) {
+        if (!envs[t]) continue;
+        int64_t lo = t * per;
+        for (int64_t s = 0; s < steps; ++s) to_env_step(envs[t], act + s * count + lo, reward + lo, done + lo);
+    }
+    double t1 = now_s();
+    if (seconds) *seconds = t1 - t0;
+    for (int t = 0; t < threads; ++t) to_env_destroy(envs[t]);
+    free(envs); free(rows); free(pcs); free(act); free(reward); free(done);
+    return count * steps;
+}

@@ -1,0 +1,112 @@
+/*
+ * tetris_oracle.h -- CPU ORACLE for the Tetris-piclim board step.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a scalar C restatement of the reference's hot path (game/tetris.py:23-61, 354-449 of the
+ * upstream repo).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it;
+ * the product (the HIP library behind include/tetris_piclim.h) never links, loads or calls it.
+ *
+ * Parity pin: tests/golden/ fixtures were produced by importing the reference's own Python module
+ * (tests/golden/make_golden.py, run where /root/reference exists) and tests/test_oracle_golden.py checks
+ * every function here against them.
+ *
+ * Interchange layout (shared with include/tetris_piclim.h):
+ *   board   uint16_t rows[20]   row 0 = top, bit x = column x (bit 0 = leftmost column)
+ *   pieces  uint8_t  [M+1]      ids I0 L1 J2 T3 S4 Z5 O6 (game/tetris.py:8-16); index 0 = first to fall
+ *   state   0 running (None), 1 won (True), 2 lost (False)      (game/tetris.py:151,373,391,416,421)
+ */
+#ifndef TETRIS_ORACLE_H
+#define TETRIS_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TO_ROWS 20
+#define TO_COLS 10
+#define TO_FULL_ROW 0x3FFu
+
+enum { TO_RUNNING = 0, TO_WON = 1, TO_LOST = 2 };
+
+/* One game, mirroring the attributes of the reference's `Tetris` object (game/tetris.py:143-151,186-187). */
+typedef struct {
+    uint16_t rows[TO_ROWS];
+    int32_t  lines_cleared;
+    int32_t  moves_used;
+    int32_t  state;      /* TO_RUNNING / TO_WON / TO_LOST */
+    int32_t  cursor;     /* number of pieces popped so far == index of pieces[0] in the original list */
+} to_game;
+
+/* Shape table entry: get_tetromino(piece, rotations) (game/tetris.py:60-61). */
+typedef struct {
+    int32_t h, w;
+    uint8_t mask[4];      /* row masks top->bottom, bit x = mask column x */
+    uint8_t revtopo[4];   /* reverse_tetromino_topography */
+} to_shape;
+
+int  to_num_rotations(int piece);
+void to_get_tetromino(int piece, int rotations, to_shape* out);
+
+/* Tetris.move(rotations, location) (game/tetris.py:354-422) on one game.
+ * `pieces` is the game's full piece list; the piece consumed is pieces[g->cursor].
+ * Returns rows cleared by this move (0..4), or -1 when the move topped out (drop < 0).
+ * Like the reference it does NOT look at g->state first (a finished game still mutates). */
+int to_move(to_game* g, const uint8_t* pieces, int L, int M, int rotations, int location);
+
+/* ---- build-defined batched environment semantics (same rules as the HIP library) -------------------
+ * Finished boards are frozen (step is a no-op, reward 0, done 1) unless auto_reset is on, in which case
+ * a board that finishes during a step is re-initialised from the config pool in that same step.       */
+typedef struct {
+    int64_t n;            /* boards */
+    int32_t L, M;
+    int64_t global_offset;/* global index of board 0 (multi-GPU sharding) */
+    uint64_t seed;
+    int32_t auto_reset;
+    int32_t assign_mode;  /* 0 = hashed, 1 = sequential */
+    float   reward_per_line, reward_win, reward_lose;
+    /* pool */
+    int64_t n_cfg;
+    const uint16_t* pool_rows;    /* [n_cfg][20] */
+    const uint8_t*  pool_pieces;  /* [n_cfg][M+1] */
+    /* per-board state */
+    to_game* games;       /* [n] */
+    uint8_t* pieces;      /* [n][M+1]  current episode's list */
+    uint32_t* episode;    /* [n] episodes started so far minus one (0 for the first) */
+    /* statistics over finished episodes */
+    uint64_t stat_episodes, stat_lines, stat_wins, stat_topouts;
+} to_env;
+
+to_env* to_env_create(int64_t n, int L, int M, int64_t global_offset, uint64_t seed);
+void    to_env_destroy(to_env* e);
+void    to_env_set_pool(to_env* e, const uint16_t* rows, const uint8_t* pieces, int64_t n_cfg); /* borrowed */
+void    to_env_set_options(to_env* e, int auto_reset, int assign_mode, float per_line, float win, float lose);
+int64_t to_env_assign(const to_env* e, int64_t board, uint32_t episode);
+void    to_env_reset(to_env* e, const uint8_t* mask /* NULL = all */);
+/* rot/loc are uint8 arrays of length n.  reward/done/cleared may be NULL. */
+void    to_env_move(to_env* e, const uint8_t* rot, const uint8_t* loc, float* reward, uint8_t* done, uint8_t* cleared);
+void    to_env_step(to_env* e, const uint8_t* action, float* reward, uint8_t* done);
+void    to_env_get_state(const to_env* e, uint16_t* rows, uint8_t* cur, uint8_t* nxt,
+                         uint8_t* lines, uint8_t* moves, uint8_t* state, uint8_t* pieces_left);
+/* float observation [n][217]: 200 cells row-major, one-hot cur (7), one-hot next (7), L_rem, M_rem, terminal */
+void    to_env_expand_obs(const to_env* e, float* out);
+/* out = {episodes finished, sum of lines_cleared at finish, wins, top-outs} */
+void    to_env_get_stats(const to_env* e, uint64_t out[4]);
+
+/* ---- synthetic inputs: counter-based, identical on CPU and GPU ------------------------- */
+uint64_t to_rng(uint64_t seed, uint64_t stream, uint64_t index, uint64_t counter);
+void to_synth_boards(uint64_t seed, int64_t first, int64_t count, int L, uint16_t* rows /*[count][20]*/);
+void to_synth_pieces(uint64_t seed, int64_t first, int64_t count, int M, uint8_t* pieces /*[count][M+1]*/);
+void to_synth_actions(uint64_t seed, int64_t first, int64_t count, uint64_t step, uint8_t* action /*[count]*/);
+
+/* FNV-1a over the 20 rows (u16 units) -- per-step fingerprint used by the golden fixtures. */
+uint64_t to_board_hash(const uint16_t* rows);
+
+/* cpu_baseline helper: steps boards [first, first+count) of the synthetic workload for `steps` lockstep
+ * steps with auto-reset from a synthetic pool of the same size; returns board-steps executed. */
+int64_t to_bench_run(uint64_t seed, int64_t count, int L, int M, int64_t steps, int threads, double* seconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

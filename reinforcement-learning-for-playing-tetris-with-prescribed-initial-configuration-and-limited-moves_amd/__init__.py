@@ -1,0 +1,22 @@
+"""MI355X-native batched Tetris-piclim environment (Tetris with a prescribed initial configuration, L lines
+to clear, at most M moves on a 20x10 board).
+
+The package holds only what the hot path needs: `csrc/` (hand-written HIP kernels for gfx950 + the C ABI of
+include/tetris_piclim.h) and `env.py`, the host-side mirror of the reference's `Tetris` interface.
+The directory name is not a Python identifier; import it as `import tetris_piclim` (alias module at the repo
+root) or with importlib.import_module.
+"""
+from . import _lib
+from ._lib import LIB_PATH, SYMBOLS, TplError, build_library, shape_info
+
+__all__ = ["BatchedTetris", "Tetris", "OBS_DIM", "NUM_ACTIONS", "RUNNING", "WON", "LOST", "TplError",
+           "build_library", "shape_info", "LIB_PATH", "SYMBOLS"]
+
+
+def __getattr__(name):
+    # env.py needs torch; keep `import tetris_piclim` cheap for callers that only build or bind the library
+    if name in ("BatchedTetris", "Tetris", "OBS_DIM", "NUM_ACTIONS", "RUNNING", "WON", "LOST", "env"):
+        import importlib
+        env = importlib.import_module(__name__ + ".env")
+        return env if name == "env" else getattr(env, name)
+    raise AttributeError(name)

@@ -1,0 +1,110 @@
+"""Build and bind the C-ABI shared library (include/tetris_piclim.h) with ctypes.
+
+The library is compiled in-tree for gfx950 with hipcc (csrc/libtetris_piclim.so) and loaded with ctypes; there
+is no fallback: if it cannot be built or loaded the package raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_PKG, "csrc")
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_CSRC, "libtetris_piclim.so")
+_SOURCES = [os.path.join(_CSRC, "tetris_piclim.hip"), os.path.join(_CSRC, "tpl_device.h"),
+            os.path.join(_ROOT, "include", "tetris_piclim.h")]
+
+# entry points declared in include/tetris_piclim.h (tests check that the .so exports every one of them)
+SYMBOLS = [
+    "tpl_last_error", "tpl_version", "tpl_workspace_bytes", "tpl_pool_bytes", "tpl_create", "tpl_destroy",
+    "tpl_set_options", "tpl_load_configs", "tpl_reset", "tpl_move", "tpl_step", "tpl_get_state",
+    "tpl_expand_obs", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
+    "tpl_synth_actions",
+]
+
+TPL_U8, TPL_I32, TPL_I64 = 0, 1, 2
+TPL_F32, TPL_BF16 = 0, 1
+TPL_ASSIGN_HASH, TPL_ASSIGN_SEQUENTIAL = 0, 1
+
+
+class TplError(RuntimeError):
+    """A C-ABI call returned a negative status; carries tpl_last_error()."""
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP library cannot be built (no CPU fallback exists)")
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> csrc/libtetris_piclim.so (rebuilt when a source is newer)."""
+    stale = force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in _SOURCES)
+    if stale:
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+               "-o", LIB_PATH + ".tmp", _SOURCES[0]]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        os.replace(LIB_PATH + ".tmp", LIB_PATH)
+        if verbose:
+            print("built", LIB_PATH)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(build_library())
+    vp, i32, i64, u64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+    L.tpl_last_error.restype = C.c_char_p
+    L.tpl_last_error.argtypes = []
+    L.tpl_version.restype = C.c_char_p
+    L.tpl_version.argtypes = []
+    L.tpl_workspace_bytes.restype = sz
+    L.tpl_workspace_bytes.argtypes = [i64, i32]
+    L.tpl_pool_bytes.restype = sz
+    L.tpl_pool_bytes.argtypes = [i64, i32]
+    L.tpl_create.argtypes = [C.POINTER(vp), i64, i32, i32, i32, i64, u64, vp, sz]
+    L.tpl_destroy.argtypes = [vp]
+    L.tpl_set_options.argtypes = [vp, i32, i32, f32, f32, f32]
+    L.tpl_load_configs.argtypes = [vp, vp, vp, i64, vp, sz, vp]
+    L.tpl_reset.argtypes = [vp, vp, vp]
+    L.tpl_move.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
+    L.tpl_step.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.tpl_get_state.argtypes = [vp] * 9
+    L.tpl_expand_obs.argtypes = [vp, vp, i32, vp]
+    L.tpl_get_stats.argtypes = [vp, vp, vp]
+    L.tpl_shape_info.argtypes = [i32, i32, C.POINTER(i32), C.POINTER(i32), vp, vp]
+    L.tpl_state_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i32)]
+    L.tpl_synth_configs.argtypes = [vp, u64, i64, i64, vp, vp, vp]
+    L.tpl_synth_actions.argtypes = [vp, u64, i64, i64, u64, vp, vp]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int:
+            fn.restype = i32
+    _lib = L
+    return L
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise TplError(f"tetris_piclim status {status}: {lib().tpl_last_error().decode()}")
+
+
+def shape_info(piece: int, rotations: int):
+    """get_tetromino(piece, rotations) as the device table encodes it (host-side decode, no GPU needed)."""
+    h, w = C.c_int32(), C.c_int32()
+    masks = (C.c_uint8 * 4)()
+    topo = (C.c_uint8 * 4)()
+    check(lib().tpl_shape_info(piece, rotations, C.byref(h), C.byref(w), masks, topo))
+    return h.value, w.value, list(masks)[: h.value], list(topo)[: w.value]

@@ -1,0 +1,638 @@
+// tetris_piclim.hip -- kernels and C ABI (include/tetris_piclim.h) of the batched Tetris-piclim environment.
+// gfx950 only.  The per-lane move lives in tpl_device.h; this file holds the kernels around it, the handle
+// and the extern "C" entry points.  Citations "(:NNN)" are lines of the reference's game/tetris.py.
+#include "../../include/tetris_piclim.h"
+#include "tpl_device.h"
+
+#include <hip/hip_bf16.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+namespace tpl {
+
+constexpr int kBlock = 256;
+constexpr int kStatShards = 256;
+constexpr int kStatStride = 16;   // uint64 per shard -> one 128-B line each
+
+// ---------------------------------------------------------------------------------------------- handle
+struct Pool {
+    uint4* a = nullptr;        // [n_cfg] plane A of the initial state
+    uint4* b = nullptr;        // [n_cfg] plane B (cur/nxt filled in, counters zero)
+    uint32_t* queue = nullptr; // [n_cfg][W]
+    int64_t n_cfg = 0;
+    void* owned = nullptr;
+};
+
+}  // namespace tpl
+
+struct tpl_env {
+    int64_t n = 0;
+    int32_t L = 0, M = 0, W = 0, device = 0;
+    int64_t global_offset = 0;
+    uint64_t seed = 0;
+    int32_t auto_reset = 0, assign_mode = 0;
+    float r_line = 1.0f, r_win = 0.0f, r_lose = 0.0f;
+    uint4* plane_a = nullptr;
+    uint4* plane_b = nullptr;
+    uint32_t* queue = nullptr;          // [W][n]
+    unsigned long long* stats = nullptr;// [kStatShards][kStatStride]
+    void* owned = nullptr;
+    tpl::Pool pool;
+};
+
+namespace tpl {
+
+// ---------------------------------------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define TPL_HIP(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) return fail(TPL_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));  \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int queue_words(int M) { return (M + 2 + kPiecesPerWord - 1) / kPiecesPerWord; }
+
+// ---------------------------------------------------------------------------------------------- kernels
+struct StepArgs {
+    uint4* plane_a;
+    uint4* plane_b;
+    uint32_t* queue;
+    int64_t n;
+    uint32_t L, M, W;
+    const void* act0;          // action, or rot
+    const void* act1;          // loc (move form) or null (action form)
+    int32_t dtype;
+    float* reward;
+    uint8_t* done;
+    uint8_t* cleared;
+    float r_line, r_win, r_lose;
+    // auto-reset
+    const uint4* pool_a;
+    const uint4* pool_b;
+    const uint32_t* pool_queue;
+    uint32_t n_cfg;
+    int32_t assign_mode;
+    uint64_t seed;
+    int64_t global_offset;
+    unsigned long long* stats;
+};
+
+__device__ __forceinline__ uint32_t load_int(const void* p, int32_t dtype, int64_t i) {
+    if (dtype == TPL_U8) return ((const uint8_t*)p)[i];
+    if (dtype == TPL_I32) return (uint32_t)((const int32_t*)p)[i];
+    return (uint32_t)((const long long*)p)[i];
+}
+
+// (re)initialise lane's board from pool entry `cfg`: state planes from the pool, piece list copied into the
+// board's own queue words.  reset()/load_warm_reset() (:438-449), with counters zeroed.
+__device__ __forceinline__ void load_config(const uint4* pool_a, const uint4* pool_b, const uint32_t* pool_queue,
+                                            uint32_t cfg, uint32_t W, uint32_t* queue, int64_t n, int64_t i,
+                                            uint32_t episode, uint4& A, uint4& B) {
+    A = pool_a[cfg];
+    const uint4 pb = pool_b[cfg];
+    B = make_uint4(pb.x, pb.y, pb.z, episode << 16);
+    const uint32_t* src = pool_queue + (size_t)cfg * W;
+    for (uint32_t w = 0; w < W; ++w) queue[(size_t)w * n + i] = src[w];
+}
+
+// One Tetris.move per board (:354-422).  ACTION form: act0 = rot*10+loc; MOVE form: act0 = rot, act1 = loc.
+template <bool kActionForm, bool kAutoReset>
+__global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs p) {
+    __shared__ ShapeWord s_shape[32];
+    __shared__ uint32_t s_stat[4];
+    if (threadIdx.x < 32) s_shape[threadIdx.x] = kShapeTable[threadIdx.x];
+    if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
+    __syncthreads();
+
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i < p.n;
+    bool finished = false;
+    if (valid) {
+        const uint4 A = p.plane_a[i];
+        const uint4 B = p.plane_b[i];
+        uint32_t rot, loc;
+        if (kActionForm) {
+            const uint32_t a = load_int(p.act0, p.dtype, i);
+            rot = a / 10u;
+            loc = a - rot * 10u;
+        } else {
+            rot = load_int(p.act0, p.dtype, i);
+            loc = load_int(p.act1, p.dtype, i);
+        }
+        Board s;
+        unpack_board(A, B, s);
+
+        float reward = 0.0f;
+        uint32_t n_clear = 0;
+        bool done = true;
+        if (s.state == ST_RUNNING) {
+            // the piece two ahead of the one falling now becomes `nxt`; its word does not depend on the move
+            const uint32_t ahead = s.moves + 2u;      // cursor == moves_used while running
+            const uint32_t qi = ahead / (uint32_t)kPiecesPerWord;
+            const uint32_t qword = p.queue[(size_t)qi * p.n + i];
+            const uint32_t fetched = (qword >> (3u * (ahead - qi * kPiecesPerWord))) & 7u;
+
+            bool topout;
+            n_clear = move_board(s, s_shape, rot, loc, p.L, p.M, topout);
+            // pieces.pop(0) (:356): the falling piece is consumed even when the move tops out
+            s.cur = s.nxt;
+            s.nxt = fetched;
+
+            reward = p.r_line * (float)n_clear;
+            if (s.state == ST_WON) reward = reward + p.r_win;
+            if (s.state >= ST_LOST_LIMIT) reward = reward + p.r_lose;
+            done = s.state != ST_RUNNING;
+
+            uint4 A2, B2;
+            if (done) {
+                finished = true;
+                atomicAdd(&s_stat[0], 1u);
+                atomicAdd(&s_stat[1], s.lines);
+                atomicAdd(&s_stat[2], s.state == ST_WON ? 1u : 0u);
+                atomicAdd(&s_stat[3], s.state == ST_LOST_TOPOUT ? 1u : 0u);
+            }
+            if (kAutoReset && done) {
+                const uint32_t ep = (s.episode + 1u) & 0xFFFFu;
+                const uint32_t cfg = assign_config((uint64_t)(p.global_offset + i), ep, p.seed, p.n_cfg, p.assign_mode);
+                load_config(p.pool_a, p.pool_b, p.pool_queue, cfg, p.W, p.queue, p.n, i, ep, A2, B2);
+            } else {
+                pack_board(s, A2, B2);
+            }
+            p.plane_a[i] = A2;
+            p.plane_b[i] = B2;
+        }
+        if (p.reward) p.reward[i] = reward;
+        if (p.done) p.done[i] = done ? 1 : 0;
+        if (p.cleared) p.cleared[i] = (uint8_t)n_clear;
+    }
+
+    // per-block statistics of the episodes that finished in this step -> one sharded 64-bit atomic per counter
+    if (__syncthreads_or(finished ? 1 : 0)) {
+        if (threadIdx.x < 4) {
+            const uint32_t v = s_stat[threadIdx.x];
+            if (v) atomicAdd(&p.stats[(size_t)(blockIdx.x % kStatShards) * kStatStride + threadIdx.x],
+                             (unsigned long long)v);
+        }
+    }
+}
+
+// Tetris.reset() (:438-443) for every board (mask == null, episode 0) or the masked ones (next episode).
+__global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs p, const uint8_t* mask) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= p.n) return;
+    uint32_t ep = 0;
+    if (mask) {
+        if (!mask[i]) return;
+        ep = ((p.plane_b[i].w >> 16) + 1u) & 0xFFFFu;
+    }
+    const uint32_t cfg = assign_config((uint64_t)(p.global_offset + i), ep, p.seed, p.n_cfg, p.assign_mode);
+    uint4 A, B;
+    load_config(p.pool_a, p.pool_b, p.pool_queue, cfg, p.W, p.queue, p.n, i, ep, A, B);
+    p.plane_a[i] = A;
+    p.plane_b[i] = B;
+}
+
+// interchange (rows u16[20], pieces u8[M+1]) -> pool entries in the resident layout
+__global__ __launch_bounds__(kBlock) void pack_configs_kernel(const uint16_t* rows, const uint8_t* pieces, int64_t n_cfg,
+                                                             uint32_t M, uint32_t W, uint4* pool_a, uint4* pool_b,
+                                                             uint32_t* pool_queue) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_cfg) return;
+    uint16_t r[kRows];
+#pragma unroll
+    for (int k = 0; k < kRows; ++k) r[k] = rows[i * kRows + k];
+    Board s;
+    rows_to_cols(r, s.c);
+    const uint8_t* pc = pieces + (size_t)i * (M + 1);
+    s.cur = pc[0] & 7u;
+    s.nxt = M >= 1 ? (pc[1] & 7u) : 7u;
+    s.state = ST_RUNNING; s.lines = 0; s.moves = 0; s.episode = 0;
+    uint4 A, B;
+    pack_board(s, A, B);
+    pool_a[i] = A;
+    pool_b[i] = B;
+    for (uint32_t w = 0; w < W; ++w) {
+        uint32_t word = 0;
+        for (uint32_t j = 0; j < (uint32_t)kPiecesPerWord; ++j) {
+            const uint32_t idx = w * kPiecesPerWord + j;
+            const uint32_t v = idx <= M ? (pc[idx] & 7u) : 7u;
+            word |= v << (3u * j);
+        }
+        pool_queue[(size_t)i * W + w] = word;
+    }
+}
+
+// get_state (:435-436) + public attributes, resident layout -> interchange layout
+__global__ __launch_bounds__(kBlock) void export_kernel(const uint4* plane_a, const uint4* plane_b, int64_t n, uint32_t M,
+                                                       uint16_t* rows, uint8_t* cur, uint8_t* nxt, uint8_t* lines,
+                                                       uint8_t* moves, uint8_t* state, uint8_t* pieces_left) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Board s;
+    unpack_board(plane_a[i], plane_b[i], s);
+    if (rows) {
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) rows[i * kRows + r] = (uint16_t)row_of_cols(s.c, r);
+    }
+    if (cur) cur[i] = (uint8_t)s.cur;
+    if (nxt) nxt[i] = (uint8_t)s.nxt;
+    if (lines) lines[i] = (uint8_t)s.lines;
+    if (moves) moves[i] = (uint8_t)s.moves;
+    if (state) state[i] = (uint8_t)(s.state == ST_LOST_TOPOUT ? ST_LOST_LIMIT : s.state);
+    if (pieces_left) pieces_left[i] = (uint8_t)(M + 1u - s.moves - (s.state == ST_LOST_TOPOUT ? 1u : 0u));
+}
+
+// Observation [n][217]: a wave expands its 64 boards cooperatively so that every store instruction writes
+// 256 contiguous bytes.  Each lane first turns its own board into a row-major 200-bit cell vector
+// (7 words) + one feature word in LDS; then for each board all 64 lanes emit its 217 values.
+template <typename T>
+__device__ __forceinline__ T obs_cast(float v);
+template <> __device__ __forceinline__ float obs_cast<float>(float v) { return v; }
+template <> __device__ __forceinline__ __hip_bfloat16 obs_cast<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void expand_obs_kernel(const uint4* plane_a, const uint4* plane_b, int64_t n,
+                                                           uint32_t L, uint32_t M, T* out) {
+    __shared__ uint32_t s_bits[kBlock / 64][64][9];   // 7 cell words + features, padded to 9 (odd stride)
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t base = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * 64;
+    const int64_t i = base + lane;
+    if (i < n) {
+        Board s;
+        unpack_board(plane_a[i], plane_b[i], s);
+        uint32_t words[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            const uint32_t row = row_of_cols(s.c, r);
+            const int bit = r * 10;
+            words[bit >> 5] |= row << (bit & 31);
+            if ((bit & 31) > 22) words[(bit >> 5) + 1] |= row >> (32 - (bit & 31));
+        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k) s_bits[wave][lane][k] = words[k];
+        const uint32_t terminal = s.state != ST_RUNNING ? 1u : 0u;
+        s_bits[wave][lane][7] = s.cur | (s.nxt << 3) | (terminal << 6) | (s.lines << 8) | (s.moves << 16);
+    }
+    __syncthreads();
+    const int64_t count = (n - base) < 64 ? (n - base) : 64;
+    for (int64_t j = 0; j < count; ++j) {
+        const uint32_t* bits = s_bits[wave][j];
+        T* o = out + (base + j) * TPL_OBS_DIM;
+        const uint32_t f = bits[7];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = lane + 64 * t;
+            if (e < 200) {
+                o[e] = obs_cast<T>((float)((bits[e >> 5] >> (e & 31)) & 1u));
+            } else if (e < TPL_OBS_DIM) {
+                float v;
+                if (e < 207) v = ((f & 7u) == (uint32_t)(e - 200)) ? 1.0f : 0.0f;
+                else if (e < 214) v = (((f >> 3) & 7u) == (uint32_t)(e - 207)) ? 1.0f : 0.0f;
+                else if (e == 214) v = (float)((int)L - (int)((f >> 8) & 0xFFu));
+                else if (e == 215) v = (float)((int)M - (int)((f >> 16) & 0xFFu));
+                else v = (float)((f >> 6) & 1u);
+                o[e] = obs_cast<T>(v);
+            }
+        }
+    }
+}
+
+__global__ void reduce_stats_kernel(const unsigned long long* shards, unsigned long long* out) {
+    const int k = threadIdx.x;   // 4 threads
+    unsigned long long s = 0;
+    for (int i = 0; i < kStatShards; ++i) s += shards[(size_t)i * kStatStride + k];
+    out[k] = s;
+}
+
+// synthetic workload of SURVEY 8(d) -- same arithmetic as oracle/tetris_oracle.c
+__global__ __launch_bounds__(kBlock) void synth_configs_kernel(uint64_t seed, int64_t first, int64_t count, uint32_t L,
+                                                              uint32_t M, uint16_t* rows, uint8_t* pieces) {
+    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (b >= count) return;
+    const uint64_t g = (uint64_t)(first + b);
+    if (rows) {
+        const uint32_t filled = L < (uint32_t)kRows ? L : (uint32_t)kRows;
+        for (uint32_t r = 0; r < (uint32_t)kRows; ++r) {
+            uint32_t v = 0;
+            if (r >= kRows - filled) {
+                const uint64_t h = rng(seed, 0, g, r);
+                v = (uint32_t)(h & 0x3FFu);
+                if (v == 0x3FFu) v &= ~(1u << (uint32_t)((h >> 10) % 10u));
+            }
+            rows[b * kRows + r] = (uint16_t)v;
+        }
+    }
+    if (pieces) {
+        const uint32_t len = M + 1;
+        uint8_t* out = pieces + (size_t)b * len;
+        uint32_t produced = 0;
+        for (uint32_t bag = 0; produced < len; ++bag) {
+            const uint64_t h = rng(seed, 1, g, bag);
+            // the 7-bag as seven 3-bit fields of one register; Fisher-Yates by field swaps
+            uint32_t a = 0u | 1u << 3 | 2u << 6 | 3u << 9 | 4u << 12 | 5u << 15 | 6u << 18;
+            for (int j = 6; j >= 1; --j) {
+                const uint32_t k = (uint32_t)((h >> (8 * (6 - j))) & 0xFFu) % (uint32_t)(j + 1);
+                const uint32_t vj = (a >> (3 * j)) & 7u, vk = (a >> (3 * k)) & 7u;
+                a = (a & ~(7u << (3 * j))) | (vk << (3 * j));
+                a = (a & ~(7u << (3 * k))) | (vj << (3 * k));
+            }
+            for (int j = 0; j < 7 && produced < len; ++j) out[produced++] = (uint8_t)((a >> (3 * j)) & 7u);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void synth_actions_kernel(uint64_t seed, int64_t first, int64_t count, uint64_t step,
+                                                              uint8_t* action) {
+    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (b >= count) return;
+    const uint64_t h = rng(seed, 2, (uint64_t)(first + b), step);
+    const uint32_t rot = (uint32_t)(h & 3u);
+    const uint32_t loc = (uint32_t)((h >> 8) & 0xFFFFu) % 10u;
+    action[b] = (uint8_t)(rot * 10u + loc);
+}
+
+static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+static StepArgs make_args(const tpl_env* e) {
+    StepArgs a{};
+    a.plane_a = e->plane_a; a.plane_b = e->plane_b; a.queue = e->queue;
+    a.n = e->n; a.L = (uint32_t)e->L; a.M = (uint32_t)e->M; a.W = (uint32_t)e->W;
+    a.r_line = e->r_line; a.r_win = e->r_win; a.r_lose = e->r_lose;
+    a.pool_a = e->pool.a; a.pool_b = e->pool.b; a.pool_queue = e->pool.queue;
+    a.n_cfg = (uint32_t)e->pool.n_cfg; a.assign_mode = e->assign_mode; a.seed = e->seed;
+    a.global_offset = e->global_offset; a.stats = e->stats;
+    return a;
+}
+
+static int launch_step(tpl_env* e, const void* act0, const void* act1, int32_t dtype, float* reward, uint8_t* done,
+                       uint8_t* cleared, hipStream_t stream) {
+    if (dtype != TPL_U8 && dtype != TPL_I32 && dtype != TPL_I64) return fail(TPL_ERR_ARG, "unknown integer dtype %d", dtype);
+    if (e->auto_reset && e->pool.n_cfg == 0) return fail(TPL_ERR_STATE, "auto_reset needs tpl_load_configs first");
+    StepArgs a = make_args(e);
+    a.act0 = act0; a.act1 = act1; a.dtype = dtype; a.reward = reward; a.done = done; a.cleared = cleared;
+    const dim3 grid(blocks_for(e->n)), block(kBlock);
+    const bool action_form = act1 == nullptr;
+    if (action_form) {
+        if (e->auto_reset) hipLaunchKernelGGL((step_kernel<true, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((step_kernel<true, false>), grid, block, 0, stream, a);
+    } else {
+        if (e->auto_reset) hipLaunchKernelGGL((step_kernel<false, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((step_kernel<false, false>), grid, block, 0, stream, a);
+    }
+    TPL_HIP(hipGetLastError());
+    return TPL_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+}  // namespace tpl
+
+using namespace tpl;
+
+// ============================================================================================== C ABI
+extern "C" {
+
+const char* tpl_last_error(void) { return g_err; }
+
+const char* tpl_version(void) { return "tetris_piclim 0.1.0 (gfx950)"; }
+
+size_t tpl_workspace_bytes(int64_t num_envs, int32_t M) {
+    if (num_envs <= 0 || M < 1) return 0;
+    const size_t n = (size_t)num_envs;
+    return align_up(n * sizeof(uint4), 256) * 2 + align_up(n * sizeof(uint32_t) * (size_t)queue_words(M), 256) +
+           align_up((size_t)kStatShards * kStatStride * sizeof(unsigned long long), 256);
+}
+
+size_t tpl_pool_bytes(int64_t n_cfg, int32_t M) {
+    if (n_cfg <= 0 || M < 1) return 0;
+    const size_t n = (size_t)n_cfg;
+    return align_up(n * sizeof(uint4), 256) * 2 + align_up(n * sizeof(uint32_t) * (size_t)queue_words(M), 256);
+}
+
+int tpl_create(tpl_env** out, int64_t num_envs, int32_t L, int32_t M, int32_t device_id, int64_t global_offset,
+               uint64_t seed, void* workspace, size_t workspace_bytes) {
+    if (!out) return fail(TPL_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (num_envs <= 0 || num_envs > ((int64_t)1 << 31)) return fail(TPL_ERR_ARG, "num_envs %lld out of range", (long long)num_envs);
+    if (L < 1 || L > 250) return fail(TPL_ERR_ARG, "L=%d out of range [1, 250]", L);
+    if (M < 1 || M > 254) return fail(TPL_ERR_ARG, "M=%d out of range [1, 254]", M);
+    if (global_offset < 0) return fail(TPL_ERR_ARG, "global_offset is negative");
+    int ndev = 0;
+    TPL_HIP(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(TPL_ERR_ARG, "device %d not in [0, %d)", device_id, ndev);
+    DeviceGuard guard(device_id);
+    if (!guard.ok) return fail(TPL_ERR_HIP, "hipSetDevice(%d) failed", device_id);
+
+    const size_t need = tpl_workspace_bytes(num_envs, M);
+    tpl_env* e = new (std::nothrow) tpl_env();
+    if (!e) return fail(TPL_ERR_NOMEM, "host allocation failed");
+    e->n = num_envs; e->L = L; e->M = M; e->W = queue_words(M); e->device = device_id;
+    e->global_offset = global_offset; e->seed = seed;
+    char* base = (char*)workspace;
+    if (base) {
+        if (workspace_bytes < need) { delete e; return fail(TPL_ERR_ARG, "workspace has %zu bytes, need %zu", workspace_bytes, need); }
+        if (((uintptr_t)base & 255u) != 0) { delete e; return fail(TPL_ERR_ARG, "workspace must be 256-byte aligned"); }
+    } else {
+        hipError_t err = hipMalloc((void**)&base, need);
+        if (err != hipSuccess) { delete e; return fail(TPL_ERR_NOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(err)); }
+        e->owned = base;
+    }
+    const size_t n = (size_t)num_envs;
+    e->plane_a = (uint4*)base; base += align_up(n * sizeof(uint4), 256);
+    e->plane_b = (uint4*)base; base += align_up(n * sizeof(uint4), 256);
+    e->queue = (uint32_t*)base; base += align_up(n * sizeof(uint32_t) * (size_t)e->W, 256);
+    e->stats = (unsigned long long*)base;
+    hipError_t err = hipMemset(e->plane_a, 0, need);   // every board: empty, running, no pieces
+    if (err != hipSuccess) {
+        if (e->owned) (void)hipFree(e->owned);
+        delete e;
+        return fail(TPL_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(err));
+    }
+    *out = e;
+    return TPL_OK;
+}
+
+int tpl_destroy(tpl_env* e) {
+    if (!e) return TPL_OK;
+    DeviceGuard guard(e->device);
+    if (e->owned) (void)hipFree(e->owned);
+    if (e->pool.owned) (void)hipFree(e->pool.owned);
+    delete e;
+    return TPL_OK;
+}
+
+int tpl_set_options(tpl_env* e, int32_t auto_reset, int32_t assign_mode, float per_line, float win, float lose) {
+    if (!e) return fail(TPL_ERR_ARG, "env is null");
+    if (assign_mode != TPL_ASSIGN_HASH && assign_mode != TPL_ASSIGN_SEQUENTIAL) return fail(TPL_ERR_ARG, "unknown assign_mode %d", assign_mode);
+    e->auto_reset = auto_reset ? 1 : 0; e->assign_mode = assign_mode;
+    e->r_line = per_line; e->r_win = win; e->r_lose = lose;
+    return TPL_OK;
+}
+
+int tpl_load_configs(tpl_env* e, const uint16_t* rows, const uint8_t* pieces, int64_t n_cfg, void* pool_mem,
+                     size_t pool_bytes, void* stream) {
+    if (!e) return fail(TPL_ERR_ARG, "env is null");
+    if (!rows || !pieces) return fail(TPL_ERR_ARG, "rows/pieces is null");
+    if (n_cfg <= 0 || n_cfg >= ((int64_t)1 << 32)) return fail(TPL_ERR_ARG, "n_cfg %lld out of range", (long long)n_cfg);
+    DeviceGuard guard(e->device);
+    const size_t need = tpl_pool_bytes(n_cfg, e->M);
+    char* base = (char*)pool_mem;
+    void* newly_owned = nullptr;
+    if (base) {
+        if (pool_bytes < need) return fail(TPL_ERR_ARG, "pool_mem has %zu bytes, need %zu", pool_bytes, need);
+        if (((uintptr_t)base & 255u) != 0) return fail(TPL_ERR_ARG, "pool_mem must be 256-byte aligned");
+    } else {
+        hipError_t err = hipMalloc((void**)&base, need);
+        if (err != hipSuccess) return fail(TPL_ERR_NOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(err));
+        newly_owned = base;
+    }
+    if (e->pool.owned) {
+        // the previous pool may still be read by enqueued work
+        TPL_HIP(hipStreamSynchronize((hipStream_t)stream));
+        (void)hipFree(e->pool.owned);
+    }
+    const size_t n = (size_t)n_cfg;
+    e->pool.owned = newly_owned;
+    e->pool.a = (uint4*)base; base += align_up(n * sizeof(uint4), 256);
+    e->pool.b = (uint4*)base; base += align_up(n * sizeof(uint4), 256);
+    e->pool.queue = (uint32_t*)base;
+    e->pool.n_cfg = n_cfg;
+    hipLaunchKernelGGL(pack_configs_kernel, dim3(blocks_for(n_cfg)), dim3(kBlock), 0, (hipStream_t)stream, rows, pieces,
+                       n_cfg, (uint32_t)e->M, (uint32_t)e->W, e->pool.a, e->pool.b, e->pool.queue);
+    TPL_HIP(hipGetLastError());
+    return TPL_OK;
+}
+
+int tpl_reset(tpl_env* e, const uint8_t* mask, void* stream) {
+    if (!e) return fail(TPL_ERR_ARG, "env is null");
+    if (e->pool.n_cfg == 0) return fail(TPL_ERR_STATE, "tpl_reset needs tpl_load_configs first");
+    DeviceGuard guard(e->device);
+    if (!mask)
+        TPL_HIP(hipMemsetAsync(e->stats, 0, (size_t)kStatShards * kStatStride * sizeof(unsigned long long), (hipStream_t)stream));
+    hipLaunchKernelGGL(reset_kernel, dim3(blocks_for(e->n)), dim3(kBlock), 0, (hipStream_t)stream, make_args(e), mask);
+    TPL_HIP(hipGetLastError());
+    return TPL_OK;
+}
+
+int tpl_move(tpl_env* e, const void* rot, const void* loc, int32_t dtype, float* reward, uint8_t* done,
+             uint8_t* cleared, void* stream) {
+    if (!e) return fail(TPL_ERR_ARG, "env is null");
+    if (!rot || !loc) return fail(TPL_ERR_ARG, "rot/loc is null");
+    DeviceGuard guard(e->device);
+    return launch_step(e, rot, loc, dtype, reward, done, cleared, (hipStream_t)stream);
+}
+
+int tpl_step(tpl_env* e, const void* action, int32_t dtype, float* reward, uint8_t* done, void* stream) {
+    if (!e) return fail(TPL_ERR_ARG, "env is null");
+    if (!action) return fail(TPL_ERR_ARG, "action is null");
+    DeviceGuard guard(e->device);
+    return launch_step(e, action, nullptr, dtype, reward, done, nullptr, (hipStream_t)stream);
+}
+
+int tpl_get_state(tpl_env* e, uint16_t* rows, uint8_t* cur, uint8_t* nxt, uint8_t* lines, uint8_t* moves,
+                  uint8_t* state, uint8_t* pieces_left, void* stream) {
+    if (!e) return fail(TPL_ERR_ARG, "env is null");
+    DeviceGuard guard(e->device);
+    hipLaunchKernelGGL(export_kernel, dim3(blocks_for(e->n)), dim3(kBlock), 0, (hipStream_t)stream, e->plane_a, e->plane_b,
+                       e->n, (uint32_t)e->M, rows, cur, nxt, lines, moves, state, pieces_left);
+    TPL_HIP(hipGetLastError());
+    return TPL_OK;
+}
+
+int tpl_expand_obs(tpl_env* e, void* out, int32_t dtype, void* stream) {
+    if (!e) return fail(TPL_ERR_ARG, "env is null");
+    if (!out) return fail(TPL_ERR_ARG, "out is null");
+    DeviceGuard guard(e->device);
+    const dim3 grid(blocks_for(e->n)), block(kBlock);
+    if (dtype == TPL_F32)
+        hipLaunchKernelGGL(expand_obs_kernel<float>, grid, block, 0, (hipStream_t)stream, e->plane_a, e->plane_b, e->n,
+                           (uint32_t)e->L, (uint32_t)e->M, (float*)out);
+    else if (dtype == TPL_BF16)
+        hipLaunchKernelGGL(expand_obs_kernel<__hip_bfloat16>, grid, block, 0, (hipStream_t)stream, e->plane_a, e->plane_b,
+                           e->n, (uint32_t)e->L, (uint32_t)e->M, (__hip_bfloat16*)out);
+    else
+        return fail(TPL_ERR_ARG, "unknown observation dtype %d", dtype);
+    TPL_HIP(hipGetLastError());
+    return TPL_OK;
+}
+
+int tpl_get_stats(tpl_env* e, uint64_t* out, void* stream) {
+    if (!e) return fail(TPL_ERR_ARG, "env is null");
+    if (!out) return fail(TPL_ERR_ARG, "out is null");
+    DeviceGuard guard(e->device);
+    hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(4), 0, (hipStream_t)stream, e->stats, (unsigned long long*)out);
+    TPL_HIP(hipGetLastError());
+    return TPL_OK;
+}
+
+int tpl_shape_info(int32_t piece, int32_t rotations, int32_t* h, int32_t* w, uint8_t* masks, uint8_t* revtopo) {
+    if (piece < 0 || piece > 6 || rotations < 0) return fail(TPL_ERR_ARG, "piece %d / rotations %d out of range", piece, rotations);
+    const ShapeWord sh = kShapeTableHost[piece * 4 + (rotations & 3)];
+    const int ww = (int)((sh.x >> 16) & 7u), hh = (int)((sh.x >> 19) & 7u);
+    if (h) *h = hh;
+    if (w) *w = ww;
+    for (int k = 0; k < 4; ++k) {
+        if (masks) {
+            uint32_t m = 0;
+            for (int c = 0; c < 4; ++c) m |= ((sh.x >> (4 * c + k)) & 1u) << c;
+            masks[k] = (uint8_t)m;
+        }
+        if (revtopo) revtopo[k] = k < ww ? (uint8_t)(3u - ((sh.y >> (8 * k)) & 0xFFu)) : 0;
+    }
+    return TPL_OK;
+}
+
+int tpl_state_ptrs(tpl_env* e, void** plane_a, void** plane_b, void** queue, int32_t* queue_words_out) {
+    if (!e) return fail(TPL_ERR_ARG, "env is null");
+    if (plane_a) *plane_a = e->plane_a;
+    if (plane_b) *plane_b = e->plane_b;
+    if (queue) *queue = e->queue;
+    if (queue_words_out) *queue_words_out = e->W;
+    return TPL_OK;
+}
+
+int tpl_synth_configs(tpl_env* e, uint64_t seed, int64_t first, int64_t count, uint16_t* rows, uint8_t* pieces,
+                      void* stream) {
+    if (!e) return fail(TPL_ERR_ARG, "env is null");
+    if (count <= 0) return fail(TPL_ERR_ARG, "count must be positive");
+    DeviceGuard guard(e->device);
+    hipLaunchKernelGGL(synth_configs_kernel, dim3(blocks_for(count)), dim3(kBlock), 0, (hipStream_t)stream, seed, first,
+                       count, (uint32_t)e->L, (uint32_t)e->M, rows, pieces);
+    TPL_HIP(hipGetLastError());
+    return TPL_OK;
+}
+
+int tpl_synth_actions(tpl_env* e, uint64_t seed, int64_t first, int64_t count, uint64_t step, uint8_t* action,
+                      void* stream) {
+    if (!e) return fail(TPL_ERR_ARG, "env is null");
+    if (count <= 0 || !action) return fail(TPL_ERR_ARG, "bad count/action");
+    DeviceGuard guard(e->device);
+    hipLaunchKernelGGL(synth_actions_kernel, dim3(blocks_for(count)), dim3(kBlock), 0, (hipStream_t)stream, seed, first,
+                       count, step, action);
+    TPL_HIP(hipGetLastError());
+    return TPL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,254 @@
+// tpl_device.h -- resident board layout and the per-lane move for gfx950 (CDNA4, wave64).
+//
+// One board per lane.  The board is held TRANSPOSED: ten 20-bit column words (bit r = row r, row 0 = top),
+// because the reference's drop rule is column-top based (game/tetris.py:427-433): a column's top is one
+// v_ffbl on its word.  Citations "(:NNN)" are lines of the reference's game/tetris.py.
+//
+// Resident state, 32 B per board in two uint4 planes (SoA, plane[i] is board i -> 1 KiB per wave-load):
+//   A.x = col0 | col1<<20        A.y = col1>>12 | col2<<8       (three 20-bit columns per 64 bits)
+//   A.z = col3 | col4<<20        A.w = col4>>12 | col5<<8
+//   B.x = col6 | col7<<20        B.y = col7>>12 | col8<<8
+//   B.z = col9 | cur<<20 | nxt<<23 | state<<26                  (state: 0 run, 1 won, 2 lost@limit, 3 lost@top-out)
+//   B.w = lines_cleared | moves_used<<8 | episode<<16
+// Piece queue: queue[w][i], ten 3-bit piece ids per 32-bit word, entry j of a board's list in word j/10;
+// entries past the end of the list read 7.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tpl {
+
+constexpr int kRows = 20;
+constexpr int kCols = 10;
+constexpr uint32_t kColMask = 0xFFFFFu;
+constexpr int kPiecesPerWord = 10;
+
+enum : uint32_t { ST_RUNNING = 0, ST_WON = 1, ST_LOST_LIMIT = 2, ST_LOST_TOPOUT = 3 };
+
+struct Board {
+    uint32_t c[kCols];   // column words
+    uint32_t cur, nxt, state, lines, moves, episode;
+};
+
+// ---- shape table --------------------------------------------------------------------------------------
+// `tetrominos` (:23-57) re-encoded per (piece, rotations & 3) for the column layout.  Two words per entry:
+//   .x  bits 0-15: four nibbles, nibble c = the piece's column c as a bit-per-row pattern (bit i = mask row i)
+//       bits 16-18: width, bits 19-21: height
+//   .y  byte c = 3 - reverse_topography[c] for a covered column, 64 for columns past the piece's width
+// so that  drop = min_c(top[c] + byte_c) - 4  ==  min_c(top[c] - revtopo[c]) - 1   (:424-425, :433).
+// get_tetromino's `rotations % len` (:60-61) is folded in: len is 1, 2 or 4, so (rotations & 3) % len
+// indexes the same entry as rotations % len for any non-negative rotations.
+struct ShapeWord { uint32_t x, y; };
+
+__host__ __device__ constexpr ShapeWord make_shape(int h, int w, int m0, int m1, int m2, int m3,
+                                                   int t0, int t1, int t2, int t3) {
+    const int m[4] = {m0, m1, m2, m3};
+    const int t[4] = {t0, t1, t2, t3};
+    uint32_t x = 0, y = 0;
+    for (int c = 0; c < 4; ++c) {
+        uint32_t colbits = 0;
+        for (int i = 0; i < 4; ++i) colbits |= (uint32_t)((m[i] >> c) & 1) << i;
+        x |= colbits << (4 * c);
+        y |= (uint32_t)(c < w ? 3 - t[c] : 64) << (8 * c);
+    }
+    x |= (uint32_t)w << 16 | (uint32_t)h << 19;
+    return ShapeWord{x, y};
+}
+
+// rows: (h, w, row masks top->bottom with bit x = mask column x, reverse topography)
+#define TPL_I0 make_shape(1, 4, 15, 0, 0, 0, 0, 0, 0, 0)   /* :25 */
+#define TPL_I1 make_shape(4, 1, 1, 1, 1, 1, 3, 0, 0, 0)    /* :26 */
+#define TPL_L0 make_shape(2, 3, 4, 7, 0, 0, 1, 1, 1, 0)    /* :29 */
+#define TPL_L1 make_shape(3, 2, 3, 2, 2, 0, 0, 2, 0, 0)    /* :30 */
+#define TPL_L2 make_shape(2, 3, 7, 1, 0, 0, 1, 0, 0, 0)    /* :31 */
+#define TPL_L3 make_shape(3, 2, 1, 1, 3, 0, 2, 2, 0, 0)    /* :32 */
+#define TPL_J0 make_shape(2, 3, 1, 7, 0, 0, 1, 1, 1, 0)    /* :35 */
+#define TPL_J1 make_shape(3, 2, 2, 2, 3, 0, 2, 2, 0, 0)    /* :36 */
+#define TPL_J2 make_shape(2, 3, 7, 4, 0, 0, 0, 0, 1, 0)    /* :37 */
+#define TPL_J3 make_shape(3, 2, 3, 1, 1, 0, 2, 0, 0, 0)    /* :38 */
+#define TPL_T0 make_shape(2, 3, 2, 7, 0, 0, 1, 1, 1, 0)    /* :41 */
+#define TPL_T1 make_shape(3, 2, 2, 3, 2, 0, 1, 2, 0, 0)    /* :42 */
+#define TPL_T2 make_shape(2, 3, 7, 2, 0, 0, 0, 1, 0, 0)    /* :43 */
+#define TPL_T3 make_shape(3, 2, 1, 3, 1, 0, 2, 1, 0, 0)    /* :44 */
+#define TPL_S0 make_shape(2, 3, 6, 3, 0, 0, 1, 1, 0, 0)    /* :47 */
+#define TPL_S1 make_shape(3, 2, 1, 3, 2, 0, 1, 2, 0, 0)    /* :48 */
+#define TPL_Z0 make_shape(2, 3, 3, 6, 0, 0, 0, 1, 1, 0)    /* :51 */
+#define TPL_Z1 make_shape(3, 2, 2, 3, 1, 0, 2, 1, 0, 0)    /* :52 */
+#define TPL_O0 make_shape(2, 2, 3, 3, 0, 0, 1, 1, 0, 0)    /* :55 */
+
+// [piece][rotations & 3]; piece ids I0 L1 J2 T3 S4 Z5 O6 (:8-16); slot 7 is the "no piece" id and is never used
+// by a running board.
+#define TPL_SHAPE_LIST                                                                                    \
+    TPL_I0, TPL_I1, TPL_I0, TPL_I1, TPL_L0, TPL_L1, TPL_L2, TPL_L3, TPL_J0, TPL_J1, TPL_J2, TPL_J3, TPL_T0,  \
+    TPL_T1, TPL_T2, TPL_T3, TPL_S0, TPL_S1, TPL_S0, TPL_S1, TPL_Z0, TPL_Z1, TPL_Z0, TPL_Z1, TPL_O0, TPL_O0,  \
+    TPL_O0, TPL_O0, TPL_O0, TPL_O0, TPL_O0, TPL_O0
+__device__ __constant__ const ShapeWord kShapeTable[32] = {TPL_SHAPE_LIST};
+constexpr ShapeWord kShapeTableHost[32] = {TPL_SHAPE_LIST};   // same entries, for tpl_shape_info on the host
+
+// ---- pack / unpack ------------------------------------------------------------------------------------
+__device__ __forceinline__ void unpack3(uint32_t lo, uint32_t hi, uint32_t& a, uint32_t& b, uint32_t& c) {
+    a = lo & kColMask;
+    b = __builtin_amdgcn_alignbit(hi, lo, 20) & kColMask;   // ({hi,lo} >> 20)
+    c = (hi >> 8) & kColMask;
+}
+
+__device__ __forceinline__ void pack3(uint32_t a, uint32_t b, uint32_t c, uint32_t& lo, uint32_t& hi) {
+    lo = a | (b << 20);
+    hi = (b >> 12) | (c << 8);
+}
+
+__device__ __forceinline__ void unpack_board(const uint4& A, const uint4& B, Board& s) {
+    unpack3(A.x, A.y, s.c[0], s.c[1], s.c[2]);
+    unpack3(A.z, A.w, s.c[3], s.c[4], s.c[5]);
+    unpack3(B.x, B.y, s.c[6], s.c[7], s.c[8]);
+    s.c[9] = B.z & kColMask;
+    s.cur = (B.z >> 20) & 7u;
+    s.nxt = (B.z >> 23) & 7u;
+    s.state = (B.z >> 26) & 3u;
+    s.lines = B.w & 0xFFu;
+    s.moves = (B.w >> 8) & 0xFFu;
+    s.episode = B.w >> 16;
+}
+
+__device__ __forceinline__ void pack_board(const Board& s, uint4& A, uint4& B) {
+    pack3(s.c[0], s.c[1], s.c[2], A.x, A.y);
+    pack3(s.c[3], s.c[4], s.c[5], A.z, A.w);
+    pack3(s.c[6], s.c[7], s.c[8], B.x, B.y);
+    B.z = s.c[9] | (s.cur << 20) | (s.nxt << 23) | (s.state << 26);
+    B.w = s.lines | (s.moves << 8) | (s.episode << 16);
+}
+
+// rows (interchange, u16[20], bit x = column x) <-> columns
+__device__ __forceinline__ void rows_to_cols(const uint16_t* rows, uint32_t* c) {
+#pragma unroll
+    for (int x = 0; x < kCols; ++x) c[x] = 0;
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+        uint32_t v = rows[r];
+#pragma unroll
+        for (int x = 0; x < kCols; ++x) c[x] |= ((v >> x) & 1u) << r;
+    }
+}
+
+__device__ __forceinline__ uint32_t row_of_cols(const uint32_t* c, int r) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int x = 0; x < kCols; ++x) v |= ((c[x] >> r) & 1u) << x;
+    return v;
+}
+
+// (m & x) | (~m & y) with m all-ones or zero: v_bfi_b32
+__device__ __forceinline__ uint32_t blend(uint32_t m, uint32_t x, uint32_t y) { return (m & x) | (~m & y); }
+
+// ---- the move ------------------------------------------------------------------------------------------
+// Tetris.move(rotations, location) (:354-422) on the lane's board; the piece is s.cur, already popped from
+// the queue by the caller (:356).  `shape` is the LDS-resident table.  Returns rows cleared (0..4); sets
+// `topout` when drop < 0 (:372-374), in which case the board and moves_used are left unchanged.
+__device__ __forceinline__ uint32_t move_board(Board& s, const ShapeWord* shape, uint32_t rot, uint32_t loc,
+                                               uint32_t L, uint32_t M, bool& topout) {
+    // get_tetromino (:60-61, :359-360)
+    const ShapeWord sh = shape[s.cur * 4u + (rot & 3u)];
+    const uint32_t w = (sh.x >> 16) & 7u;
+    const uint32_t h = (sh.x >> 19) & 7u;
+
+    // right clamp only (:363-364)
+    loc = min(loc, (uint32_t)kCols - w);
+
+    // the four board columns under the piece, c[loc .. loc+3], through a 4-stage blend network keyed on the
+    // bits of loc.  Written as mask blends (one v_bfi_b32 each) on purpose: a `cond ? c[k+1] : c[k]` form is
+    // turned back into a runtime-indexed array by the compiler and lands in scratch/LDS.
+    const uint32_t m0 = 0u - (loc & 1u), m1 = 0u - ((loc >> 1) & 1u), m2 = 0u - ((loc >> 2) & 1u),
+                   m3 = 0u - ((loc >> 3) & 1u);
+    uint32_t a[10], b[10], d[4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a[k] = blend(m0, s.c[k + 1], s.c[k]);
+    a[9] = s.c[9];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) b[k] = blend(m1, a[k + 2], a[k]);
+    b[8] = a[8]; b[9] = a[9];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = blend(m2, b[k + 4], b[k]);
+    d[0] = blend(m3, b[8], d[0]);
+    d[1] = blend(m3, b[9], d[1]);
+
+    // calculate_drop_deltas (:427-433): top of each column (20 when empty, via a sentinel bit) minus the
+    // piece's reverse topography; columns past the width carry +64 and never win the min.
+    uint32_t best = 0xFFu;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t top = (uint32_t)__builtin_ctz(d[k] | (1u << kRows));
+        best = min(best, top + ((sh.y >> (8 * k)) & 0xFFu));
+    }
+    // calculate_drop (:424-425): min(deltas) - 1, with the table's +3 bias removed
+    const int drop = (int)best - 4;
+
+    // top-out (:372-374): state False; board and moves_used untouched
+    topout = drop < 0;
+    const uint32_t dshift = topout ? 0u : (uint32_t)drop;
+
+    // lock (:377-378): OR the piece's column patterns, shifted down by `drop`, into columns loc..loc+w-1.
+    // The four nibbles are moved to their columns with one 64-bit shift, then each column takes its nibble.
+    uint64_t placed = (uint64_t)(sh.x & 0xFFFFu) << (4u * loc);
+    if (topout) placed = 0;
+    const uint32_t plo = (uint32_t)placed, phi = (uint32_t)(placed >> 32);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s.c[k] |= ((plo >> (4 * k)) & 0xFu) << dshift;
+    s.c[8] |= (phi & 0xFu) << dshift;
+    s.c[9] |= ((phi >> 4) & 0xFu) << dshift;
+    s.moves += topout ? 0u : 1u;                                                  // (:379)
+
+    // full rows among the piece's rows only (:382-386)
+    uint32_t full = s.c[0];
+#pragma unroll
+    for (int k = 1; k < kCols; ++k) full &= s.c[k];
+    uint32_t clear = topout ? 0u : (full & (((1u << h) - 1u) << dshift));
+    const uint32_t n = (uint32_t)__builtin_popcount(clear);
+
+    // compaction (:397-407): drop each cleared row, rows above it move down one, an empty row enters at the top
+    while (clear) {
+        const uint32_t r = (uint32_t)__builtin_ctz(clear);
+        clear &= clear - 1u;
+        const uint32_t above = (1u << r) - 1u;          // rows 0..r-1
+        const uint32_t keep = ~((above << 1) | 1u);     // rows r+1..
+#pragma unroll
+        for (int k = 0; k < kCols; ++k) s.c[k] = (s.c[k] & keep) | ((s.c[k] & above) << 1);
+    }
+    s.lines += n;                                                                 // (:409)
+
+    // terminal tests: no-clear exit (:389-394), win before move limit (:415-422)
+    const bool won = !topout && n != 0u && s.lines >= L;
+    const bool limit = !topout && !won && s.moves >= M;
+    s.state = topout ? ST_LOST_TOPOUT : won ? ST_WON : limit ? ST_LOST_LIMIT : ST_RUNNING;
+    return n;
+}
+
+// ---- counter-based generator (same function as oracle/tetris_oracle.c) ----------------------------------
+__host__ __device__ __forceinline__ uint64_t sm64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+__host__ __device__ __forceinline__ uint64_t rng(uint64_t seed, uint64_t stream, uint64_t index, uint64_t counter) {
+    uint64_t h = sm64(seed ^ (stream * 0xD1B54A32D192ED03ULL));
+    h = sm64(h ^ index);
+    return sm64(h ^ counter);
+}
+
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+// which pool entry episode `episode` of global board `g` starts from
+__host__ __device__ __forceinline__ uint32_t assign_config(uint64_t g, uint32_t episode, uint64_t seed,
+                                                           uint32_t n_cfg, int mode) {
+    if (mode == 1) return (uint32_t)((g + (uint64_t)episode) % (uint64_t)n_cfg);
+    uint32_t h = fmix32((uint32_t)g ^ ((uint32_t)(g >> 32) * 0x9E3779B9u) ^ (uint32_t)seed);
+    h = fmix32(h + episode * 0x9E3779B1u + (uint32_t)(seed >> 32));
+    return (uint32_t)(((uint64_t)h * (uint64_t)n_cfg) >> 32);
+}
+
+}  // namespace tpl

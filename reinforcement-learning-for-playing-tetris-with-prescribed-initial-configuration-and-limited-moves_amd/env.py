@@ -1,0 +1,293 @@
+"""Host-side mirror of the reference's `Tetris` interface, batched over the C ABI.
+
+`BatchedTetris` keeps the reference's surface -- reset() / move(rotations, location) / get_state() /
+terminate() and the attributes L, M, lines_cleared, moves_used, state (game/tetris.py:140-151,354,435-451 of
+the upstream repo) -- for N boards that live on one MI355X, plus the step(action) / reward / done form that
+BASELINE.json's north_star asks for.  `Tetris` is the single-board form with the reference's exact attribute
+types, used by tests that read like the reference's own.
+
+All compute happens in csrc/tetris_piclim.hip; this module only owns torch buffers and passes raw pointers
+and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+OBS_DIM = 217
+NUM_ACTIONS = 40
+RUNNING, WON, LOST = 0, 1, 2
+
+_INT_CODES = {torch.uint8: _lib.TPL_U8, torch.int32: _lib.TPL_I32, torch.int64: _lib.TPL_I64}
+_OBS_CODES = {torch.float32: _lib.TPL_F32, torch.bfloat16: _lib.TPL_BF16}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class BatchedTetris:
+    """N independent Tetris-piclim boards on one GPU, stepped in lockstep.
+
+    Parameters mirror `Tetris(L, M, ...)` (game/tetris.py:141); the warm-reset worker processes of the
+    reference (:189-214) are replaced by a device-resident pool of prescribed configurations
+    (`load_configs`), from which resets draw.
+    """
+
+    def __init__(self, L: int, M: int, num_envs: int, device="cuda:0", seed: int = 0, global_offset: int = 0,
+                 auto_reset: bool = False, assign: str = "hash", reward=(1.0, 0.0, 0.0), config_pool=None):
+        self.L, self.M, self.num_envs = int(L), int(M), int(num_envs)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("BatchedTetris runs on a GPU only (device must be cuda:N); there is no CPU path")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: the HIP library cannot run and no fallback exists")
+        self._lib = _lib.lib()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        self.seed, self.global_offset = int(seed), int(global_offset)
+        nbytes = self._lib.tpl_workspace_bytes(self.num_envs, self.M)
+        self._workspace = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
+        h = C.c_void_p()
+        check(self._lib.tpl_create(C.byref(h), self.num_envs, self.L, self.M, idx, self.global_offset, self.seed,
+                                   _ptr(self._workspace), nbytes))
+        self._h = h
+        self._pool_mem = None
+        self._pool = None
+        self.n_configs = 0
+        self.auto_reset = bool(auto_reset)
+        self.assign = assign
+        self.reward_params = tuple(float(x) for x in reward)
+        self._apply_options()
+        if config_pool is not None:
+            self.load_configs(*config_pool)
+
+    # ------------------------------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _apply_options(self):
+        mode = {"hash": _lib.TPL_ASSIGN_HASH, "sequential": _lib.TPL_ASSIGN_SEQUENTIAL}[self.assign]
+        check(self._lib.tpl_set_options(self._h, int(self.auto_reset), mode, *self.reward_params))
+
+    def set_options(self, auto_reset=None, assign=None, reward=None):
+        if auto_reset is not None:
+            self.auto_reset = bool(auto_reset)
+        if assign is not None:
+            self.assign = assign
+        if reward is not None:
+            self.reward_params = tuple(float(x) for x in reward)
+        self._apply_options()
+
+    def _dev(self, x, dtype):
+        if isinstance(x, torch.Tensor):
+            return x.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(self.device)
+
+    def _int_arg(self, x):
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.ascontiguousarray(x))
+        if x.dtype not in _INT_CODES:
+            x = x.to(torch.int64)
+        x = x.to(self.device).contiguous()
+        if x.numel() != self.num_envs:
+            raise ValueError(f"expected {self.num_envs} values, got {x.numel()}")
+        return x, _INT_CODES[x.dtype]
+
+    # ------------------------------------------------------------------------------------------ configs
+    def load_configs(self, rows, pieces) -> None:
+        """Upload a pool of prescribed (board, pieces) configurations (the supply behind reset()).
+
+        rows: [n_cfg, 20] uint16 (bit x = column x) or [n_cfg, 20, 10] bool; pieces: [n_cfg, M+1] uint8."""
+        if not isinstance(rows, torch.Tensor):
+            rows = np.asarray(rows)
+            if rows.ndim == 3:
+                rows = (rows.astype(np.uint16) << np.arange(10, dtype=np.uint16)).sum(-1).astype(np.uint16)
+            rows = torch.from_numpy(np.ascontiguousarray(rows.astype(np.uint16)).view(np.int16))
+        elif rows.dim() == 3:
+            rows = (rows.to(torch.int32) << torch.arange(10, device=rows.device, dtype=torch.int32)).sum(-1).to(torch.int16)
+        rows = rows.to(self.device).contiguous()
+        if rows.dtype not in (torch.int16, torch.uint16):
+            rows = rows.to(torch.int16)
+        pieces = self._dev(pieces, torch.uint8)
+        n_cfg = rows.shape[0]
+        if rows.shape != (n_cfg, 20) or pieces.shape != (n_cfg, self.M + 1):
+            raise ValueError(f"rows must be [n,20] and pieces [n,{self.M + 1}]; got {tuple(rows.shape)} {tuple(pieces.shape)}")
+        nbytes = self._lib.tpl_pool_bytes(n_cfg, self.M)
+        pool_mem = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        check(self._lib.tpl_load_configs(self._h, _ptr(rows), _ptr(pieces), n_cfg, _ptr(pool_mem), nbytes, self._stream()))
+        # the previous pool may still be in use by enqueued work: keep it until this stream has moved on
+        old = self._pool_mem
+        self._pool_mem, self._pool, self.n_configs = pool_mem, (rows, pieces), n_cfg
+        if old is not None:
+            old.record_stream(torch.cuda.current_stream(self.device))
+
+    def synthetic_configs(self, count: int, seed: Optional[int] = None, first: int = 0):
+        """The synthetic boards / piece lists of SURVEY 8(d), generated on the device."""
+        seed = self.seed if seed is None else seed
+        rows = torch.empty((count, 20), dtype=torch.int16, device=self.device)
+        pieces = torch.empty((count, self.M + 1), dtype=torch.uint8, device=self.device)
+        check(self._lib.tpl_synth_configs(self._h, seed, first, count, _ptr(rows), _ptr(pieces), self._stream()))
+        return rows, pieces
+
+    def synthetic_actions(self, step: int, seed: Optional[int] = None, out: Optional[torch.Tensor] = None):
+        """Uniform synthetic actions for lockstep step `step`, keyed by global board index."""
+        seed = self.seed if seed is None else seed
+        if out is None:
+            out = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        check(self._lib.tpl_synth_actions(self._h, seed, self.global_offset, self.num_envs, step, _ptr(out), self._stream()))
+        return out
+
+    # ------------------------------------------------------------------------------------------ reference surface
+    def reset(self, mask=None) -> None:
+        """Tetris.reset() (game/tetris.py:438-443) for all boards, or for the boards where mask is true."""
+        m = None if mask is None else self._dev(mask, torch.uint8)
+        check(self._lib.tpl_reset(self._h, _ptr(m), self._stream()))
+
+    def move(self, rotations, locations) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Tetris.move(rotations, location) (game/tetris.py:354) on every board.
+
+        Returns (reward f32[N], done bool[N], rows_cleared u8[N])."""
+        rot, code = self._int_arg(rotations)
+        loc, code2 = self._int_arg(locations)
+        if code2 != code:
+            rot, loc = rot.to(torch.int64), loc.to(torch.int64)
+            code = _lib.TPL_I64
+        reward = torch.empty(self.num_envs, dtype=torch.float32, device=self.device)
+        done = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        cleared = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        check(self._lib.tpl_move(self._h, _ptr(rot), _ptr(loc), code, _ptr(reward), _ptr(done), _ptr(cleared), self._stream()))
+        return reward, done.view(torch.bool), cleared
+
+    def step_into(self, action: torch.Tensor, reward: torch.Tensor, done: torch.Tensor) -> None:
+        """step() writing into caller-owned buffers (uint8/int32/int64 action, f32 reward, uint8 done)."""
+        check(self._lib.tpl_step(self._h, _ptr(action), _INT_CODES[action.dtype], _ptr(reward), _ptr(done), self._stream()))
+
+    def step(self, action, observe: bool = True, obs_dtype=torch.float32):
+        """step(action) with action = rot*10 + loc.  Returns (obs [N,217] or None, reward, done, info)."""
+        act, code = self._int_arg(action)
+        reward = torch.empty(self.num_envs, dtype=torch.float32, device=self.device)
+        done = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        check(self._lib.tpl_step(self._h, _ptr(act), code, _ptr(reward), _ptr(done), self._stream()))
+        obs = self.observe(obs_dtype) if observe else None
+        return obs, reward, done.view(torch.bool), {}
+
+    def observe(self, dtype=torch.float32, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[N, 217] observation for Model(217, 14) (model/train.py:26)."""
+        if out is None:
+            out = torch.empty((self.num_envs, OBS_DIM), dtype=dtype, device=self.device)
+        check(self._lib.tpl_expand_obs(self._h, _ptr(out), _OBS_CODES[out.dtype], self._stream()))
+        return out
+
+    def packed_state(self) -> dict:
+        """Everything get_state() and the public attributes expose, in the interchange layout (device tensors)."""
+        n, d = self.num_envs, self.device
+        out = dict(rows=torch.empty((n, 20), dtype=torch.int16, device=d))
+        for k in ("cur", "nxt", "lines", "moves", "state", "pieces_left"):
+            out[k] = torch.empty(n, dtype=torch.uint8, device=d)
+        check(self._lib.tpl_get_state(self._h, _ptr(out["rows"]), _ptr(out["cur"]), _ptr(out["nxt"]), _ptr(out["lines"]),
+                                      _ptr(out["moves"]), _ptr(out["state"]), _ptr(out["pieces_left"]), self._stream()))
+        return out
+
+    def get_state(self):
+        """Batched Tetris.get_state() (game/tetris.py:435-436):
+        (board bool[N,20,10], pieces[0], pieces[1], L - lines_cleared, M - moves_used, state)."""
+        s = self.packed_state()
+        rows = s["rows"].to(torch.int32) & 0xFFFF
+        board = ((rows.unsqueeze(-1) >> torch.arange(10, device=self.device, dtype=torch.int32)) & 1).to(torch.bool)
+        return (board, s["cur"], s["nxt"], self.L - s["lines"].to(torch.int32), self.M - s["moves"].to(torch.int32),
+                s["state"])
+
+    lines_cleared = property(lambda self: self.packed_state()["lines"])
+    moves_used = property(lambda self: self.packed_state()["moves"])
+    state = property(lambda self: self.packed_state()["state"])
+
+    def stats(self) -> dict:
+        """Episodes finished since the last full reset: counts for the episodic-return mean (host sync)."""
+        out = torch.empty(4, dtype=torch.int64, device=self.device)
+        check(self._lib.tpl_get_stats(self._h, _ptr(out), self._stream()))
+        return dict(zip(("episodes", "lines", "wins", "topouts"), out.tolist()))
+
+    def stats_tensor(self) -> torch.Tensor:
+        """The four counters as a device int64 tensor (no host sync) -- what the RCCL all-reduce sums."""
+        out = torch.empty(4, dtype=torch.int64, device=self.device)
+        check(self._lib.tpl_get_stats(self._h, _ptr(out), self._stream()))
+        return out
+
+    def return_sum(self, stats: torch.Tensor) -> torch.Tensor:
+        """[sum of episodic returns, episodes] (f64) from a stats tensor, under the current reward parameters."""
+        per_line, win, lose = self.reward_params
+        s = stats.to(torch.float64)
+        total = per_line * s[1] + win * s[2] + lose * (s[0] - s[2])
+        return torch.stack([total, s[0]])
+
+    def terminate(self) -> None:
+        """Tetris.terminate() (game/tetris.py:451-470): releases the handle."""
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize(self.device)
+            check(self._lib.tpl_destroy(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.terminate()
+        except Exception:
+            pass
+
+
+class Tetris:
+    """One board with the reference's own surface and attribute types (game/tetris.py:140-214, 354-449).
+
+    `board` is a 20x10 numpy bool array, `pieces` a Python list, `state` None / True / False.  The prescribed
+    configuration comes from `configs=(rows, pieces)` (one or more; reset() walks through them in order)
+    instead of the reference's carving workers.
+    """
+
+    _STATE = {RUNNING: None, WON: True, LOST: False}
+
+    def __init__(self, L: int, M: int, configs, device="cuda:0"):
+        rows, pieces = configs
+        self._pieces_host = np.asarray(pieces, dtype=np.uint8).reshape(-1, M + 1)
+        self._env = BatchedTetris(L, M, 1, device=device, assign="sequential", config_pool=(rows, self._pieces_host))
+        self.L, self.M = L, M
+        self._episode = 0
+        self._env.reset()
+
+    def move(self, rotations: int, location: int) -> None:
+        self._env.move(torch.tensor([rotations], dtype=torch.int64), torch.tensor([location], dtype=torch.int64))
+
+    def reset(self) -> None:
+        self._episode += 1
+        self._env.reset(mask=[1])
+
+    def _s(self):
+        return {k: v.cpu().numpy() for k, v in self._env.packed_state().items()}
+
+    @property
+    def board(self) -> np.ndarray:
+        rows = self._s()["rows"][0].view(np.uint16)
+        return ((rows[:, None] >> np.arange(10)) & 1).astype(bool)
+
+    @property
+    def pieces(self) -> list:
+        left = int(self._s()["pieces_left"][0])
+        cfg = self._episode % self._pieces_host.shape[0]
+        return self._pieces_host[cfg][self.M + 1 - left:].tolist()
+
+    lines_cleared = property(lambda self: int(self._s()["lines"][0]))
+    moves_used = property(lambda self: int(self._s()["moves"][0]))
+    state = property(lambda self: self._STATE[int(self._s()["state"][0])])
+
+    def get_state(self):
+        s = self._s()
+        return (self.board, int(s["cur"][0]), int(s["nxt"][0]), self.L - int(s["lines"][0]),
+                self.M - int(s["moves"][0]), self._STATE[int(s["state"][0])])
+
+    def terminate(self) -> None:
+        self._env.terminate()
