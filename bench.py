@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the batched Tetris-piclim board step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one lockstep pass of the hot path (tpl_step: one Tetris.move per board, auto-reset of finished
+boards from the device pool) over one batch of synthetic actions.  Workload = BASELINE.json configs[2]:
+1,048,576 boards per GPU, L=10, M=40, synthetic boards / 7-bag piece lists / uniform actions,
+all resident in HBM before the timed region.  N > 1 shards boards by global index, one process per GPU, no
+data-path collective; one RCCL all-reduce of the episodic-return counters closes the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the step kernel against HBM with the canonical
+96 B/board-step of SURVEY 8(d); `cpu_baseline` is the CPU oracle (a scalar C port of the reference's move)
+timed on this box's host cores over a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_BOARD_STEP = 96          # 46 B read + 49 B write, rounded
+HBM_PEAK_GBS = 8000.0                   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(L, M, seed):
+    """The oracle's loop (game/performance_test.py:13-17 shape: move, reset when finished) on the host cores."""
+    from oracle import oracle as O
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    boards, steps = 65536, 40
+    O.bench_run(seed, 4096, L, M, 8, cores)                      # warm the thread pool / page in
+    done, sec = O.bench_run(seed, boards, L, M, steps, cores)
+    rate = done / sec
+    # bounded sample: scale the step count so the timed part is about 10 s of CPU work
+    steps = int(max(40, min(4000, 10.0 * rate / boards)))
+    done, sec = O.bench_run(seed, boards, L, M, steps, cores)
+    return {"value": done / sec, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{boards} boards x {steps} lockstep steps, L={L} M={M}, auto-reset, {cores} threads, {sec:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--boards", type=int, default=1 << 20, help="boards per GPU")
+    ap.add_argument("--L", type=int, default=10)
+    ap.add_argument("--M", type=int, default=40)
+    ap.add_argument("--pool", type=int, default=0, help="pool size per GPU (default: one config per board)")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import tetris_piclim as T
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    n, L, M, K, W = args.boards, args.L, args.M, args.steps, args.warmup
+    pool = args.pool or n
+    offset = rank * n                                            # batch-index sharding: contiguous blocks
+    env = T.BatchedTetris(L, M, n, device=dev, seed=args.seed, global_offset=offset, auto_reset=True, assign="hash")
+    rows, pieces = env.synthetic_configs(pool, first=offset)
+    env.load_configs(rows, pieces)
+    del rows, pieces
+    env.reset()
+    # synthetic actions for every step, staged in HBM before timing
+    actions = torch.empty((W + K, n), dtype=torch.uint8, device=dev)
+    for t in range(W + K):
+        env.synthetic_actions(t, out=actions[t])
+    reward = torch.empty(n, dtype=torch.float32, device=dev)
+    done = torch.empty(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for t in range(W):
+        env.step_into(actions[t], reward, done)
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for t in range(W, W + K):
+        env.step_into(actions[t], reward, done)
+    ev1.record()                                                  # same stream as the kernel launches
+    ret = env.return_sum(env.stats_tensor())                      # [sum of episodic returns, episodes]
+    if world > 1:
+        dist.all_reduce(ret)                                      # the one collective: RCCL sum over xGMI
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+
+    kernel_ms = ev0.elapsed_time(ev1) / K                         # average launch-to-launch duration of the step kernel
+    t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+    elapsed = float(t_all.item())
+    ret = ret.tolist()
+
+    if rank == 0:
+        total_steps = float(n) * world * K
+        achieved = ALGO_BYTES_PER_BOARD_STEP * n / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env-steps/sec (whole node) at 1M parallel 20x10 boards",
+            "value": total_steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"{n} boards per GPU x {world} GPU, random initial configs, L={L} M={M}, "
+                                   f"uniform random actions, auto-reset from a {pool}-entry device pool "
+                                   "(BASELINE configs[2])",
+                       "boards_per_gpu": n, "L": L, "M": M, "parallelism": f"batch-shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "step_kernel<action, auto_reset>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BOARD_STEP * n},
+            "mean_episodic_return": (ret[0] / ret[1]) if ret[1] else None,
+            "episodes": ret[1],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(L, M, args.seed)
+        print(json.dumps(out), flush=True)
+    env.terminate()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,7 +120,8 @@ int tpl_shape_info(int32_t piece, int32_t rotations, int32_t* h, int32_t* w, uin
 /* Raw device pointers of the resident packed state (for zero-copy inspection; layout in DESIGN.md). */
 int tpl_state_ptrs(tpl_env* env, void** plane_a, void** plane_b, void** queue, int32_t* queue_words);
 
-/* Synthetic workload of SURVEY 8(d), generated on the device, identical to the oracle's generator. */
+/* Synthetic workload of SURVEY 8(d), generated on the device from a counter-based hash
+ * keyed by (seed, stream, global board index, counter); DESIGN.md states the function. */
 int tpl_synth_configs(tpl_env* env, uint64_t seed, int64_t first, int64_t count,
                       uint16_t* rows, uint8_t* pieces, void* stream);
 int tpl_synth_actions(tpl_env* env, uint64_t seed, int64_t first, int64_t count, uint64_t step,

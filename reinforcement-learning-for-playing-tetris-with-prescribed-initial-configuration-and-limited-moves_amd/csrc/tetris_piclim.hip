@@ -318,7 +318,7 @@ __global__ void reduce_stats_kernel(const unsigned long long* shards, unsigned l
     out[k] = s;
 }
 
-// synthetic workload of SURVEY 8(d) -- same arithmetic as oracle/tetris_oracle.c
+// synthetic workload of SURVEY 8(d): boards, 7-bag piece lists, uniform actions from the counter-based generator
 __global__ __launch_bounds__(kBlock) void synth_configs_kernel(uint64_t seed, int64_t first, int64_t count, uint32_t L,
                                                               uint32_t M, uint16_t* rows, uint8_t* pieces) {
     const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;

@@ -223,7 +223,7 @@ __device__ __forceinline__ uint32_t move_board(Board& s, const ShapeWord* shape,
     return n;
 }
 
-// ---- counter-based generator (same function as oracle/tetris_oracle.c) ----------------------------------
+// ---- counter-based generator (the synthetic workload of SURVEY 8d; DESIGN.md states the function) --------
 __host__ __device__ __forceinline__ uint64_t sm64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ULL;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;

@@ -28,3 +28,14 @@ def oracle():
     from oracle import oracle as O
     O.build()
     return O
+
+
+def board_hashes(rows):
+    """FNV-1a over the 20 rows of every board (the per-step fingerprint stored in the F3 fixtures)."""
+    rows = np.asarray(rows).astype(np.uint64)
+    h = np.full(rows.shape[0], 0xcbf29ce484222325, dtype=np.uint64)
+    prime = np.uint64(0x100000001b3)
+    with np.errstate(over="ignore"):
+        for r in range(20):
+            h = (h ^ rows[:, r]) * prime
+    return h

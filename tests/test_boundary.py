@@ -1,0 +1,87 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol that
+include/tetris_piclim.h declares; the device shape table decodes to the reference's table; the product never
+touches the oracle; failures are loud.  No compute call is made here (no GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+import tetris_piclim as T
+
+PKG = os.path.dirname(T.__file__)
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "tetris_piclim.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tpl_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    path = T.build_library()
+    assert os.path.exists(path) and path.startswith(PKG)            # in-tree, not site-packages
+    lib = ctypes.CDLL(path)
+    declared = _declared_symbols()
+    assert declared, "header parse found nothing"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/tetris_piclim.h but not exported"
+    assert sorted(T.SYMBOLS) == declared                              # the binding covers the whole header
+
+
+def test_code_object_targets_gfx950_only():
+    blob = open(T.build_library(), "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"sm_"):
+        assert other not in blob
+
+
+def test_device_shape_table_matches_reference_table():
+    f = load_golden("shapes.npz")
+    for p in range(7):
+        for r in range(12):
+            h, w, masks, topo = T.shape_info(p, r)
+            rr = r % int(f["nrot"][p])
+            assert (h, w) == (f["h"][p, rr], f["w"][p, rr])
+            assert masks == f["mask"][p, rr, :h].tolist() and topo == f["revtopo"][p, rr, :w].tolist()
+    with pytest.raises(T.TplError):
+        T.shape_info(7, 0)
+
+
+def test_sizes_and_argument_errors_without_gpu():
+    lib = T._lib.lib()
+    n, M = 1 << 20, 40
+    ws = lib.tpl_workspace_bytes(n, M)
+    assert ws >= n * 32 + n * 4 * 5 and ws < n * 64                  # 32 B state + 5 queue words per board
+    assert lib.tpl_pool_bytes(1000, M) >= 1000 * 52
+    assert lib.tpl_workspace_bytes(0, M) == 0
+    h = ctypes.c_void_p()
+    assert lib.tpl_create(ctypes.byref(h), 0, 10, 40, 0, 0, 0, None, 0) < 0        # bad num_envs
+    assert b"num_envs" in lib.tpl_last_error()
+    assert lib.tpl_create(ctypes.byref(h), 16, 0, 40, 0, 0, 0, None, 0) < 0         # bad L
+    assert lib.tpl_create(ctypes.byref(h), 16, 10, 255, 0, 0, 0, None, 0) < 0       # bad M
+    assert lib.tpl_step(None, None, 0, None, None, None) < 0 and b"null" in lib.tpl_last_error()
+    assert lib.tpl_destroy(None) == 0
+
+
+def test_product_never_touches_the_oracle_or_a_cpu_fallback():
+    for base, _, files in os.walk(PKG):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(base, fn)).read()
+                assert "oracle" not in text.lower(), f"{fn} mentions the oracle"
+    src = open(os.path.join(PKG, "env.py")).read()
+    assert "no CPU path" in src
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises((RuntimeError, ValueError)):
+        T.BatchedTetris(5, 20, 16)
+    with pytest.raises(ValueError):
+        T.BatchedTetris(5, 20, 16, device="cpu")

@@ -1,0 +1,350 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden fixtures and the CPU oracle, bit-exact.
+
+Everything here is integer/byte work, so the bar is equality.  The only floating-point outputs are the reward
+(a product and at most one sum of small integers and the configured constants, computed in the same order on
+both sides) and the observation (0/1 and small integers) -- also compared for equality.
+"""
+import numpy as np
+import pytest
+
+from conftest import board_hashes, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import tetris_piclim
+    return tetris_piclim
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def _state(env):
+    s = {k: _np(v) for k, v in env.packed_state().items()}
+    s["rows"] = s["rows"].view(np.uint16)
+    return s
+
+
+def _assert_state_equal(got, want, ctx=""):
+    for k in ("rows", "cur", "nxt", "lines", "moves", "state", "pieces_left"):
+        if k in want:
+            assert np.array_equal(got[k], want[k]), f"{ctx}: {k} differs at {np.argwhere(got[k] != want[k])[:5].tolist()}"
+
+
+# ------------------------------------------------------------------------------------------------- F1
+@pytest.mark.parametrize("prefix", ["t_", "o_"])
+def test_f1_plumbing_with_reference_style_object(T, prefix):
+    """BASELINE config 1: one board, fixed piece sequence; reads like the reference's own test loop."""
+    f = load_golden("plumbing.npz")
+    if prefix == "t_":
+        L, M, pieces, actions = int(f["L"]), int(f["M"]), f["pieces"], f["actions"]
+    else:
+        L, M, pieces, actions = int(f["o_L"]), int(f["o_M"]), f["o_pieces"], f["o_actions"]
+    game = T.Tetris(L, M, configs=(np.zeros((1, 20), np.uint16), pieces[None]))
+    ref_state = {0: None, 1: True, 2: False}
+    for t, (rot, loc) in enumerate(actions):
+        game.move(int(rot), int(loc))
+        rows = (game.board.astype(np.uint16) << np.arange(10, dtype=np.uint16)).sum(1)
+        assert np.array_equal(rows, f[prefix + "rows"][t]), t
+        assert game.lines_cleared == f[prefix + "lines"][t] and game.moves_used == f[prefix + "moves"][t]
+        assert game.state is ref_state[int(f[prefix + "state"][t])]
+        assert len(game.pieces) == f[prefix + "pieces_left"][t]
+    game.terminate()
+
+
+# ------------------------------------------------------------------------------------------------- F2
+@pytest.mark.parametrize("name", ["carved_L5_M20.npz", "carved_L10_M40.npz"])
+def test_f2_carved_solutions_win(T, name):
+    """The reference's test_carving_invertability (game/main.py:49-57) on 256 boards at once."""
+    f = load_golden(name)
+    L, M = int(f["L"]), int(f["M"])
+    n = f["rows"].shape[0]
+    env = T.BatchedTetris(L, M, n, assign="sequential", config_pool=(f["rows"], f["pieces"]))
+    env.reset()
+    sol_len = f["sol_len"]
+    last = dict(rows=f["rows"].copy(), lines=np.zeros(n, np.uint8), moves=np.zeros(n, np.uint8), state=np.zeros(n, np.uint8))
+    for t in range(int(sol_len.max())):
+        active = t < sol_len
+        rot = np.where(active, f["sol"][:, min(t, M - 1), 0], 0).astype(np.int64)
+        loc = np.where(active, f["sol"][:, min(t, M - 1), 1], 0).astype(np.int64)
+        env.move(rot, loc)
+        s = _state(env)
+        last["rows"][active] = f["r_rows"][active, t]
+        last["lines"][active] = f["r_lines"][active, t]
+        last["moves"][active] = f["r_moves"][active, t]
+        last["state"][active] = f["r_state"][active, t]
+        _assert_state_equal(s, last, f"{name} step {t}")     # finished boards are frozen at their last state
+    s = _state(env)
+    assert np.all(s["state"] == T.WON) and np.all(s["lines"] >= L)
+    env.terminate()
+
+
+# ------------------------------------------------------------------------------------------------- F3
+@pytest.mark.parametrize("name", ["synthetic_L5_M20.npz", "synthetic_L10_M40.npz"])
+def test_f3_synthetic_against_reference_fingerprints(T, oracle, name):
+    f = load_golden(name)
+    L, M, seed = int(f["L"]), int(f["M"]), int(f["seed"])
+    n = f["rows"].shape[0]
+    env = T.BatchedTetris(L, M, n, seed=seed, assign="sequential")
+    # device generator == fixture inputs (which came from the CPU generator)
+    rows_d, pieces_d = env.synthetic_configs(n)
+    assert np.array_equal(_np(rows_d).view(np.uint16), f["rows"]) and np.array_equal(_np(pieces_d), f["pieces"])
+    env.load_configs(rows_d, pieces_d)
+    env.reset()
+    for t in range(M):
+        a = env.synthetic_actions(t)
+        assert np.array_equal(_np(a), f["actions"][t])
+        env.step(a, observe=False)
+        s = _state(env)
+        hashes = board_hashes(s["rows"])
+        assert np.array_equal(hashes, f["hashes"][t]), t
+        assert np.array_equal(s["state"], f["s_state"][t]) and np.array_equal(s["lines"], f["s_lines"][t])
+        assert np.array_equal(s["moves"], f["s_moves"][t])
+    s = _state(env)
+    _assert_state_equal(s, dict(rows=f["f_rows"], lines=f["f_lines"], moves=f["f_moves"], state=f["f_state"],
+                                pieces_left=f["f_pieces_left"]), name)
+    env.terminate()
+
+
+# ------------------------------------------------------------------------------------------------- F4
+def test_f4_edge_cases(T):
+    f = load_golden("edges.npz")
+    for i in range(int(f["n"])):
+        g = lambda k: f[f"c{i}_{k}"]
+        name = str(f["names"][i])
+        if int(g("lines0")) or int(g("moves0")):
+            continue      # mid-game counters cannot be injected through the public surface; oracle-only case
+        L, M = int(g("L")), int(g("M"))
+        pieces = np.full(M + 1, 0, np.uint8)
+        given = g("pieces")
+        pieces[: len(given)] = given[: M + 1]
+        game = T.Tetris(L, M, configs=(g("rows0")[None], pieces[None]))
+        for t, (rot, loc) in enumerate(g("actions")):
+            game.move(int(rot), int(loc))
+            rows = (game.board.astype(np.uint16) << np.arange(10, dtype=np.uint16)).sum(1)
+            assert np.array_equal(rows, g("rows")[t]), (name, t)
+            assert (game.lines_cleared, game.moves_used) == (g("lines")[t], g("moves")[t]), (name, t)
+            assert game.state is {0: None, 1: True, 2: False}[int(g("state")[t])], (name, t)
+            # the fixture's piece list may be shorter than M+1 (the reference does not care); compare consumption
+            assert (M + 1) - len(game.pieces) == len(given) - int(g("pieces_left")[t]), (name, t)
+        game.terminate()
+
+
+# ------------------------------------------------------------------------------------------------- F5
+def test_f5_random_single_moves(T):
+    f = load_golden("random_moves.npz")
+    sel = (f["lines0"] == 0) & (f["moves0"] == 0)
+    checked = 0
+    for L in np.unique(f["L"]):
+        for M in np.unique(f["M"]):
+            idx = np.nonzero(sel & (f["L"] == L) & (f["M"] == M))[0]
+            if len(idx) == 0:
+                continue
+            pieces = np.zeros((len(idx), int(M) + 1), np.uint8)
+            pieces[:, 0] = f["piece"][idx]
+            env = T.BatchedTetris(int(L), int(M), len(idx), assign="sequential", config_pool=(f["rows"][idx], pieces))
+            env.reset()
+            env.move(f["rot"][idx].astype(np.int32), f["loc"][idx].astype(np.int32))
+            s = _state(env)
+            _assert_state_equal(s, dict(rows=f["o_rows"][idx], lines=f["o_lines"][idx], moves=f["o_moves"][idx],
+                                        state=f["o_state"][idx]), f"L={L} M={M}")
+            checked += len(idx)
+            env.terminate()
+    assert checked > 300
+
+
+# ------------------------------------------------------------------------------------------------- vs oracle
+def _dense_boards(rng, n):
+    """Tall, dense boards with nearly-full rows so that clears, multi-clears and top-outs all occur."""
+    height = rng.integers(0, 21, n)
+    cells = rng.random((n, 20, 10)) < rng.uniform(0.3, 0.95, (n, 1, 1))
+    near = rng.random((n, 20)) < 0.5
+    holes = rng.integers(0, 10, (n, 20))
+    full = np.ones((n, 20, 10), bool)
+    full[np.arange(n)[:, None], np.arange(20)[None, :], holes] = False
+    cells = np.where(near[:, :, None], full, cells)
+    cells &= (np.arange(20)[None, :, None] >= (20 - height)[:, None, None])
+    return (cells.astype(np.uint16) << np.arange(10, dtype=np.uint16)).sum(-1).astype(np.uint16)
+
+
+@pytest.mark.parametrize("L,M,n", [(3, 12, 8192), (10, 40, 65536), (250, 254, 4096), (1, 1, 1024)])
+def test_move_matches_oracle_on_dense_random_boards(T, oracle, L, M, n):
+    rng = np.random.default_rng(L * 1000 + M)
+    rows = _dense_boards(rng, n)
+    pieces = rng.integers(0, 7, (n, M + 1)).astype(np.uint8)
+    gpu = T.BatchedTetris(L, M, n, assign="sequential", reward=(1.5, 7.0, -2.0), config_pool=(rows, pieces))
+    cpu = oracle.Env(n, L, M)
+    cpu.set_pool(rows, pieces)
+    cpu.set_options(auto_reset=False, assign_mode=1, per_line=1.5, win=7.0, lose=-2.0)
+    gpu.reset(); cpu.reset()
+    _assert_state_equal(_state(gpu), cpu.get_state(), "after reset")
+    steps = min(M, 48)
+    for t in range(steps):
+        rot = rng.integers(0, 9, n).astype(np.uint8)        # > 3: exercises rotations % len
+        loc = rng.integers(0, 11, n).astype(np.uint8)       # 10: exercises the right clamp
+        r_g, d_g, c_g = gpu.move(rot, loc)
+        r_c, d_c, c_c = cpu.move(rot, loc)
+        assert np.array_equal(_np(r_g), r_c) and np.array_equal(_np(d_g).astype(np.uint8), d_c) and np.array_equal(_np(c_g), c_c), t
+        _assert_state_equal(_state(gpu), cpu.get_state(), f"step {t}")
+    gpu.terminate()
+
+
+@pytest.mark.parametrize("dtype", ["uint8", "int32", "int64"])
+def test_action_dtypes(T, oracle, dtype):
+    import torch
+    L, M, n = 5, 20, 4096
+    gpu = T.BatchedTetris(L, M, n, seed=11, assign="sequential")
+    rows, pieces = gpu.synthetic_configs(n)
+    gpu.load_configs(rows, pieces)
+    gpu.reset()
+    cpu = oracle.Env(n, L, M, 0, 11)
+    cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
+    cpu.set_options(assign_mode=1)
+    cpu.reset()
+    for t in range(6):
+        a = gpu.synthetic_actions(t)
+        _, r_g, d_g, _ = gpu.step(a.to(getattr(torch, dtype)), observe=False)
+        r_c, d_c = cpu.step(_np(a))
+        assert np.array_equal(_np(r_g), r_c) and np.array_equal(_np(d_g).astype(np.uint8), d_c)
+    _assert_state_equal(_state(gpu), cpu.get_state(), dtype)
+    gpu.terminate()
+
+
+@pytest.mark.parametrize("assign", ["hash", "sequential"])
+def test_auto_reset_rollout_matches_oracle(T, oracle, assign):
+    """BASELINE config 2 shape: 65,536 boards, L=5 M=20, auto-reset from a pool, statistics."""
+    L, M, n, pool, seed = 5, 20, 65536, 4096, 5
+    gpu = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True, assign=assign, reward=(1.0, 5.0, -1.0))
+    rows, pieces = gpu.synthetic_configs(pool)
+    gpu.load_configs(rows, pieces)
+    gpu.reset()
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
+    cpu.set_options(auto_reset=True, assign_mode=0 if assign == "hash" else 1, per_line=1.0, win=5.0, lose=-1.0)
+    cpu.reset()
+    _assert_state_equal(_state(gpu), cpu.get_state(), "reset")
+    for t in range(3 * M):
+        a = gpu.synthetic_actions(t)
+        _, r_g, d_g, _ = gpu.step(a, observe=False)
+        r_c, d_c = cpu.step(_np(a))
+        assert np.array_equal(_np(r_g), r_c) and np.array_equal(_np(d_g).astype(np.uint8), d_c), t
+        if t % 7 == 0 or t == 3 * M - 1:
+            _assert_state_equal(_state(gpu), cpu.get_state(), f"step {t}")
+    assert gpu.stats() == cpu.stats()
+    assert gpu.stats()["episodes"] > n
+    # masked reset
+    mask = (np.arange(n) % 5 == 0).astype(np.uint8)
+    gpu.reset(mask); cpu.reset(mask)
+    _assert_state_equal(_state(gpu), cpu.get_state(), "masked reset")
+    gpu.terminate()
+
+
+def test_observation_matches_oracle(T, oracle):
+    import torch
+    L, M, n = 10, 40, 1000          # not a multiple of 64: exercises the ragged tail
+    gpu = T.BatchedTetris(L, M, n, seed=2, assign="sequential")
+    rows, pieces = gpu.synthetic_configs(n)
+    gpu.load_configs(rows, pieces)
+    gpu.reset()
+    cpu = oracle.Env(n, L, M, 0, 2)
+    cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
+    cpu.set_options(assign_mode=1)
+    cpu.reset()
+    for t in range(12):
+        a = gpu.synthetic_actions(t)
+        obs, _, _, _ = gpu.step(a)
+        cpu.step(_np(a))
+        want = cpu.expand_obs()
+        assert np.array_equal(_np(obs), want), t
+        bf = gpu.observe(torch.bfloat16)
+        assert np.array_equal(_np(bf.float()), want), t     # every value is exactly representable in bf16
+    board, cur, nxt, l_rem, m_rem, state = gpu.get_state()
+    s = cpu.get_state()
+    assert np.array_equal(_np(board).reshape(n, 200), want[:, :200].astype(bool))
+    assert np.array_equal(_np(l_rem), L - s["lines"].astype(np.int32)) and np.array_equal(_np(m_rem), M - s["moves"].astype(np.int32))
+    gpu.terminate()
+
+
+def test_sharding_is_independent_of_the_number_of_gpus(T):
+    """Two handles with global offsets reproduce one handle over the whole batch (the multi-GPU partition)."""
+    import torch
+    L, M, n, seed = 5, 20, 16384, 9
+    whole = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True)
+    rows, pieces = whole.synthetic_configs(2048)
+    parts = [T.BatchedTetris(L, M, n // 2, seed=seed, auto_reset=True, global_offset=k * (n // 2)) for k in range(2)]
+    for e in [whole] + parts:
+        e.load_configs(rows, pieces)
+        e.reset()
+    for t in range(2 * M):
+        whole.step(whole.synthetic_actions(t), observe=False)
+        for e in parts:
+            e.step(e.synthetic_actions(t), observe=False)
+    w = _state(whole)
+    p = [_state(e) for e in parts]
+    for k in w:
+        assert np.array_equal(w[k], np.concatenate([q[k] for q in p]))
+    total = sum(torch.stack([e.stats_tensor() for e in parts]))
+    assert total.tolist() == whole.stats_tensor().tolist()
+    for e in [whole] + parts:
+        e.terminate()
+
+
+def test_full_size_run_properties_and_oracle_equality(T, oracle):
+    """BASELINE's roofline configuration (1,048,576 boards, L=10, M=40): size-independent properties on every
+    step, and equality with the oracle over the whole batch at the end."""
+    L, M, n, seed = 10, 40, 1 << 20, 0
+    gpu = T.BatchedTetris(L, M, n, seed=seed, assign="sequential")
+    rows, pieces = gpu.synthetic_configs(n)
+    gpu.load_configs(rows, pieces)
+    gpu.reset()
+    for t in range(M):
+        a = gpu.synthetic_actions(t)
+        _, r, d, _ = gpu.step(a, observe=False)
+        if t % 8 == 0 or t == M - 1:
+            s = _state(gpu)
+            assert np.all(s["moves"] <= M) and np.all(s["state"] <= 2)
+            assert np.all(s["rows"] < 1024)                                    # only 10 columns ever set
+            assert np.all((s["state"] != 0) == _np(d))
+    # conservation on the final state: every successful move adds 4 cells, every cleared line removes 10
+    s = _state(gpu)
+    start_cells = _popcount(_np(rows).view(np.uint16))
+    assert np.array_equal(_popcount(s["rows"]), start_cells + 4 * s["moves"].astype(np.int64) - 10 * s["lines"].astype(np.int64))
+    # whole-batch equality with the oracle
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
+    cpu.set_options(assign_mode=1)
+    cpu.reset()
+    for t in range(M):
+        cpu.step(oracle.synth_actions(seed, 0, n, t))
+    _assert_state_equal(s, cpu.get_state(), "1M boards")
+    # idempotence: every board is finished, one more step changes nothing
+    gpu.step(gpu.synthetic_actions(M), observe=False)
+    _assert_state_equal(_state(gpu), s, "frozen")
+    gpu.terminate()
+
+
+def _popcount(rows):
+    r = rows.astype(np.uint16)
+    return np.unpackbits(r.view(np.uint8), axis=-1).reshape(r.shape[0], -1).sum(1).astype(np.int64)
+
+
+def test_ragged_sizes_and_errors(T):
+    for n in (1, 63, 65, 257):
+        env = T.BatchedTetris(4, 9, n, assign="sequential")
+        rows, pieces = env.synthetic_configs(7)
+        env.load_configs(rows, pieces)
+        env.reset()
+        env.step(env.synthetic_actions(0))
+        assert env.packed_state()["moves"].shape[0] == n
+        env.terminate()
+    env = T.BatchedTetris(4, 9, 8)
+    with pytest.raises(T.TplError):
+        env.reset()                       # no configurations loaded yet
+    with pytest.raises(ValueError):
+        env.step(np.zeros(5, np.uint8))   # wrong batch size
+    env.terminate()

@@ -7,7 +7,7 @@ F4 edge cases, F5 random single moves.
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import board_hashes, load_golden
 
 
 def _play(O, L, M, rows, pieces, actions, lines=0, moves=0):
@@ -78,13 +78,18 @@ def test_f3_synthetic(oracle, name):
     for t in range(M):
         env.step(f["actions"][t])
         s = env.get_state()
-        hashes = np.array([oracle.board_hash(r) for r in s["rows"]], dtype=np.uint64)
+        hashes = board_hashes(s["rows"])
         assert np.array_equal(hashes, f["hashes"][t]), t
         assert np.array_equal(s["state"], f["s_state"][t]) and np.array_equal(s["lines"], f["s_lines"][t])
         assert np.array_equal(s["moves"], f["s_moves"][t])
     s = env.get_state()
     assert np.array_equal(s["rows"], f["f_rows"]) and np.array_equal(s["pieces_left"], f["f_pieces_left"])
     assert np.array_equal(s["state"], f["f_state"])
+
+
+def test_board_hash_helper_matches_c(oracle):
+    rows = oracle.synth_boards(4, 0, 64, 10)
+    assert np.array_equal(board_hashes(rows), np.array([oracle.board_hash(r) for r in rows], dtype=np.uint64))
 
 
 def test_f4_edges(oracle):
