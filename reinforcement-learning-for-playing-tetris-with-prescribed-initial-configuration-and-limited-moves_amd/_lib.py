@@ -64,6 +64,10 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64/libhsa-runtime64; it must be the first HIP runtime in the process, so that
+    # this library binds to the SAME runtime (shared streams, pointers, device context).  Loading the system ROCm
+    # runtime first and torch's second leaves the process with two runtimes and no visible device.
+    import torch  # noqa: F401
     L = C.CDLL(build_library())
     vp, i32, i64, u64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
     L.tpl_last_error.restype = C.c_char_p
