@@ -118,7 +118,10 @@ int tpl_get_stats(tpl_env* env, uint64_t* out, void* stream);
 int tpl_shape_info(int32_t piece, int32_t rotations, int32_t* h, int32_t* w, uint8_t* masks, uint8_t* revtopo);
 
 /* Raw device pointers of the resident packed state (for zero-copy inspection; layout in DESIGN.md). */
-int tpl_state_ptrs(tpl_env* env, void** plane_a, void** plane_b, void** queue, int32_t* queue_words);
+int tpl_state_ptrs(tpl_env* env, void** plane_a, void** plane_b);
+
+/* Tuning knob of the step kernel: boards handled per lane (1, 2 or 4; default 2).  Results do not depend on it. */
+int tpl_set_tuning(tpl_env* env, int32_t boards_per_lane);
 
 /* Synthetic workload of SURVEY 8(d), generated on the device from a counter-based hash
  * keyed by (seed, stream, global board index, counter); DESIGN.md states the function. */

@@ -247,7 +247,7 @@ void to_env_reset(to_env* e, const uint8_t* mask) {
     for (int64_t b = 0; b < e->n; ++b) {
         if (mask && !mask[b]) continue;
         /* a full reset() starts episode numbering over; a masked reset starts the board's next episode */
-        e->episode[b] = mask ? ((e->episode[b] + 1u) & 0xFFFFu) : 0u;
+        e->episode[b] = mask ? ((e->episode[b] + 1u) & 0xFFu) : 0u;
         load_config(e, b);
     }
     if (!mask) { e->stat_episodes = e->stat_lines = e->stat_wins = e->stat_topouts = 0; }
@@ -269,7 +269,7 @@ static void env_move_one(to_env* e, int64_t b, int rot, int loc, float* reward, 
             e->stat_topouts += (res < 0);
             if (done) done[b] = 1;
             if (e->auto_reset) {
-                e->episode[b] = (e->episode[b] + 1u) & 0xFFFFu;
+                e->episode[b] = (e->episode[b] + 1u) & 0xFFu;
                 load_config(e, b);
             }
         } else if (done) {

@@ -72,7 +72,7 @@ typedef struct {
     /* per-board state */
     to_game* games;       /* [n] */
     uint8_t* pieces;      /* [n][M+1]  current episode's list */
-    uint32_t* episode;    /* [n] episodes started so far minus one (0 for the first) */
+    uint32_t* episode;    /* [n] episode number modulo 256 (0 for the first; the device keeps 8 bits) */
     /* statistics over finished episodes */
     uint64_t stat_episodes, stat_lines, stat_wins, stat_topouts;
 } to_env;

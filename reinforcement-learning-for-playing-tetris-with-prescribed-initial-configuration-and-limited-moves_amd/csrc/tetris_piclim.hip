@@ -19,9 +19,8 @@ constexpr int kStatStride = 16;   // uint64 per shard -> one 128-B line each
 
 // ---------------------------------------------------------------------------------------------- handle
 struct Pool {
-    uint4* a = nullptr;        // [n_cfg] plane A of the initial state
-    uint4* b = nullptr;        // [n_cfg] plane B (cur/nxt filled in, counters zero)
-    uint32_t* queue = nullptr; // [n_cfg][W]
+    uint8_t* rec = nullptr;    // [n_cfg] records of `stride` bytes: plane-A word, plane-B word, piece words 1..
+    uint32_t stride = 0;
     int64_t n_cfg = 0;
     void* owned = nullptr;
 };
@@ -30,14 +29,14 @@ struct Pool {
 
 struct tpl_env {
     int64_t n = 0;
-    int32_t L = 0, M = 0, W = 0, device = 0;
+    int32_t L = 0, M = 0, device = 0;
     int64_t global_offset = 0;
     uint64_t seed = 0;
     int32_t auto_reset = 0, assign_mode = 0;
     float r_line = 1.0f, r_win = 0.0f, r_lose = 0.0f;
+    int32_t boards_per_lane = 2;        // tuning knob of the step kernel (1, 2 or 4)
     uint4* plane_a = nullptr;
     uint4* plane_b = nullptr;
-    uint32_t* queue = nullptr;          // [W][n]
     unsigned long long* stats = nullptr;// [kStatShards][kStatStride]
     void* owned = nullptr;
     tpl::Pool pool;
@@ -63,15 +62,16 @@ static int fail(int code, const char* fmt, ...) {
     } while (0)
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-static inline int queue_words(int M) { return (M + 2 + kPiecesPerWord - 1) / kPiecesPerWord; }
+// piece words of a configuration: entries 0..M+1 must be addressable (pieces[1] after the last move)
+static inline int piece_words(int M) { return (M + 2 + kWindowStride - 1) / kWindowStride; }
+static inline size_t record_stride(int M) { return align_up(32 + 4 * (size_t)(piece_words(M) - 1), 64); }
 
 // ---------------------------------------------------------------------------------------------- kernels
 struct StepArgs {
     uint4* plane_a;
     uint4* plane_b;
-    uint32_t* queue;
     int64_t n;
-    uint32_t L, M, W;
+    uint32_t L, M;
     const void* act0;          // action, or rot
     const void* act1;          // loc (move form) or null (action form)
     int32_t dtype;
@@ -79,10 +79,9 @@ struct StepArgs {
     uint8_t* done;
     uint8_t* cleared;
     float r_line, r_win, r_lose;
-    // auto-reset
-    const uint4* pool_a;
-    const uint4* pool_b;
-    const uint32_t* pool_queue;
+    // configuration pool (auto-reset, window refills)
+    const uint8_t* pool;
+    uint32_t stride;
     uint32_t n_cfg;
     int32_t assign_mode;
     uint64_t seed;
@@ -96,20 +95,20 @@ __device__ __forceinline__ uint32_t load_int(const void* p, int32_t dtype, int64
     return (uint32_t)((const long long*)p)[i];
 }
 
-// (re)initialise lane's board from pool entry `cfg`: state planes from the pool, piece list copied into the
-// board's own queue words.  reset()/load_warm_reset() (:438-449), with counters zeroed.
-__device__ __forceinline__ void load_config(const uint4* pool_a, const uint4* pool_b, const uint32_t* pool_queue,
-                                            uint32_t cfg, uint32_t W, uint32_t* queue, int64_t n, int64_t i,
-                                            uint32_t episode, uint4& A, uint4& B) {
-    A = pool_a[cfg];
-    const uint4 pb = pool_b[cfg];
-    B = make_uint4(pb.x, pb.y, pb.z, episode << 16);
-    const uint32_t* src = pool_queue + (size_t)cfg * W;
-    for (uint32_t w = 0; w < W; ++w) queue[(size_t)w * n + i] = src[w];
+// (re)initialise a board from pool entry `cfg`.  reset()/load_warm_reset() (:438-449), with the counters
+// zeroed; the record's two state words are one 32-B read.
+__device__ __forceinline__ void load_config(const uint8_t* pool, uint32_t stride, uint32_t cfg, uint32_t episode,
+                                            uint4& A, uint4& B) {
+    const uint4* rec = (const uint4*)(pool + (size_t)cfg * stride);
+    A = rec[0];
+    const uint4 pb = rec[1];
+    B = make_uint4(pb.x, pb.y | ((episode >> 4) << 28), pb.z | (episode << 28), pb.w);
 }
 
 // One Tetris.move per board (:354-422).  ACTION form: act0 = rot*10+loc; MOVE form: act0 = rot, act1 = loc.
-template <bool kActionForm, bool kAutoReset>
+// Each lane owns kBpl boards (block-strided, so every load is still 1 KiB per wave); all their loads are
+// issued before the first move is computed.
+template <bool kActionForm, bool kAutoReset, int kBpl>
 __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs p) {
     __shared__ ShapeWord s_shape[32];
     __shared__ uint32_t s_stat[4];
@@ -117,39 +116,54 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs p) {
     if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
     __syncthreads();
 
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = i < p.n;
+    const int64_t base = (int64_t)blockIdx.x * (kBlock * kBpl) + threadIdx.x;
+    uint4 A[kBpl], B[kBpl];
+    uint32_t a0[kBpl], a1[kBpl];
+#pragma unroll
+    for (int k = 0; k < kBpl; ++k) {
+        const int64_t i = base + (int64_t)k * kBlock;
+        if (i < p.n) {
+            A[k] = p.plane_a[i];
+            B[k] = p.plane_b[i];
+            a0[k] = load_int(p.act0, p.dtype, i);
+            a1[k] = kActionForm ? 0u : load_int(p.act1, p.dtype, i);
+        }
+    }
+
     bool finished = false;
-    if (valid) {
-        const uint4 A = p.plane_a[i];
-        const uint4 B = p.plane_b[i];
+#pragma unroll
+    for (int k = 0; k < kBpl; ++k) {
+        const int64_t i = base + (int64_t)k * kBlock;
+        if (i >= p.n) continue;
         uint32_t rot, loc;
         if (kActionForm) {
-            const uint32_t a = load_int(p.act0, p.dtype, i);
-            rot = a / 10u;
-            loc = a - rot * 10u;
+            rot = a0[k] / 10u;
+            loc = a0[k] - rot * 10u;
         } else {
-            rot = load_int(p.act0, p.dtype, i);
-            loc = load_int(p.act1, p.dtype, i);
+            rot = a0[k];
+            loc = a1[k];
         }
         Board s;
-        unpack_board(A, B, s);
+        unpack_board(A[k], B[k], s);
 
         float reward = 0.0f;
         uint32_t n_clear = 0;
         bool done = true;
         if (s.state == ST_RUNNING) {
-            // the piece two ahead of the one falling now becomes `nxt`; its word does not depend on the move
-            const uint32_t ahead = s.moves + 2u;      // cursor == moves_used while running
-            const uint32_t qi = ahead / (uint32_t)kPiecesPerWord;
-            const uint32_t qword = p.queue[(size_t)qi * p.n + i];
-            const uint32_t fetched = (qword >> (3u * (ahead - qi * kPiecesPerWord))) & 7u;
+            // pieces.pop(0) (:356) moves the cursor to moves_used + 1 whatever the move does.  When that is a
+            // multiple of eight the window is down to its last two entries and piece word cursor/8 replaces it;
+            // the gather is issued before the move so that its latency overlaps the move.
+            const uint32_t cursor = s.moves + 1u;
+            const bool refill = (cursor & (uint32_t)(kWindowStride - 1)) == 0u && p.n_cfg != 0u;
+            uint32_t word = 0;
+            if (refill) {
+                const uint32_t cfg = assign_config((uint64_t)(p.global_offset + i), s.episode, p.seed, p.n_cfg, p.assign_mode);
+                word = *(const uint32_t*)(p.pool + (size_t)cfg * p.stride + 32u + 4u * ((cursor >> 3) - 1u));
+            }
 
             bool topout;
             n_clear = move_board(s, s_shape, rot, loc, p.L, p.M, topout);
-            // pieces.pop(0) (:356): the falling piece is consumed even when the move tops out
-            s.cur = s.nxt;
-            s.nxt = fetched;
+            s.window = refill ? word : (s.window >> 3);      // the falling piece is consumed even on a top-out
 
             reward = p.r_line * (float)n_clear;
             if (s.state == ST_WON) reward = reward + p.r_win;
@@ -165,9 +179,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs p) {
                 atomicAdd(&s_stat[3], s.state == ST_LOST_TOPOUT ? 1u : 0u);
             }
             if (kAutoReset && done) {
-                const uint32_t ep = (s.episode + 1u) & 0xFFFFu;
+                const uint32_t ep = (s.episode + 1u) & 0xFFu;
                 const uint32_t cfg = assign_config((uint64_t)(p.global_offset + i), ep, p.seed, p.n_cfg, p.assign_mode);
-                load_config(p.pool_a, p.pool_b, p.pool_queue, cfg, p.W, p.queue, p.n, i, ep, A2, B2);
+                load_config(p.pool, p.stride, cfg, ep, A2, B2);
             } else {
                 pack_board(s, A2, B2);
             }
@@ -196,19 +210,29 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs p, const u
     uint32_t ep = 0;
     if (mask) {
         if (!mask[i]) return;
-        ep = ((p.plane_b[i].w >> 16) + 1u) & 0xFFFFu;
+        Board s;
+        unpack_board(p.plane_a[i], p.plane_b[i], s);
+        ep = (s.episode + 1u) & 0xFFu;
     }
     const uint32_t cfg = assign_config((uint64_t)(p.global_offset + i), ep, p.seed, p.n_cfg, p.assign_mode);
     uint4 A, B;
-    load_config(p.pool_a, p.pool_b, p.pool_queue, cfg, p.W, p.queue, p.n, i, ep, A, B);
+    load_config(p.pool, p.stride, cfg, ep, A, B);
     p.plane_a[i] = A;
     p.plane_b[i] = B;
 }
 
-// interchange (rows u16[20], pieces u8[M+1]) -> pool entries in the resident layout
+// interchange (rows u16[20], pieces u8[M+1]) -> pool records in the resident layout
+__device__ __forceinline__ uint32_t piece_word(const uint8_t* pc, uint32_t M, uint32_t w) {
+    uint32_t word = 0;
+    for (uint32_t j = 0; j < (uint32_t)kWindowEntries; ++j) {
+        const uint32_t idx = w * kWindowStride + j;
+        word |= (idx <= M ? (uint32_t)(pc[idx] & 7u) : 7u) << (3u * j);
+    }
+    return word;
+}
+
 __global__ __launch_bounds__(kBlock) void pack_configs_kernel(const uint16_t* rows, const uint8_t* pieces, int64_t n_cfg,
-                                                             uint32_t M, uint32_t W, uint4* pool_a, uint4* pool_b,
-                                                             uint32_t* pool_queue) {
+                                                             uint32_t M, uint32_t words, uint8_t* pool, uint32_t stride) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_cfg) return;
     uint16_t r[kRows];
@@ -217,22 +241,14 @@ __global__ __launch_bounds__(kBlock) void pack_configs_kernel(const uint16_t* ro
     Board s;
     rows_to_cols(r, s.c);
     const uint8_t* pc = pieces + (size_t)i * (M + 1);
-    s.cur = pc[0] & 7u;
-    s.nxt = M >= 1 ? (pc[1] & 7u) : 7u;
+    s.window = piece_word(pc, M, 0);
     s.state = ST_RUNNING; s.lines = 0; s.moves = 0; s.episode = 0;
     uint4 A, B;
     pack_board(s, A, B);
-    pool_a[i] = A;
-    pool_b[i] = B;
-    for (uint32_t w = 0; w < W; ++w) {
-        uint32_t word = 0;
-        for (uint32_t j = 0; j < (uint32_t)kPiecesPerWord; ++j) {
-            const uint32_t idx = w * kPiecesPerWord + j;
-            const uint32_t v = idx <= M ? (pc[idx] & 7u) : 7u;
-            word |= v << (3u * j);
-        }
-        pool_queue[(size_t)i * W + w] = word;
-    }
+    uint8_t* rec = pool + (size_t)i * stride;
+    ((uint4*)rec)[0] = A;
+    ((uint4*)rec)[1] = B;
+    for (uint32_t w = 1; w < words; ++w) ((uint32_t*)(rec + 32))[w - 1] = piece_word(pc, M, w);
 }
 
 // get_state (:435-436) + public attributes, resident layout -> interchange layout
@@ -247,8 +263,8 @@ __global__ __launch_bounds__(kBlock) void export_kernel(const uint4* plane_a, co
 #pragma unroll
         for (int r = 0; r < kRows; ++r) rows[i * kRows + r] = (uint16_t)row_of_cols(s.c, r);
     }
-    if (cur) cur[i] = (uint8_t)s.cur;
-    if (nxt) nxt[i] = (uint8_t)s.nxt;
+    if (cur) cur[i] = (uint8_t)(s.window & 7u);
+    if (nxt) nxt[i] = (uint8_t)((s.window >> 3) & 7u);
     if (lines) lines[i] = (uint8_t)s.lines;
     if (moves) moves[i] = (uint8_t)s.moves;
     if (state) state[i] = (uint8_t)(s.state == ST_LOST_TOPOUT ? ST_LOST_LIMIT : s.state);
@@ -285,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void expand_obs_kernel(const uint4* plane_a
 #pragma unroll
         for (int k = 0; k < 7; ++k) s_bits[wave][lane][k] = words[k];
         const uint32_t terminal = s.state != ST_RUNNING ? 1u : 0u;
-        s_bits[wave][lane][7] = s.cur | (s.nxt << 3) | (terminal << 6) | (s.lines << 8) | (s.moves << 16);
+        s_bits[wave][lane][7] = (s.window & 63u) | (terminal << 6) | (s.lines << 8) | (s.moves << 16);
     }
     __syncthreads();
     const int64_t count = (n - base) < 64 ? (n - base) : 64;
@@ -369,13 +385,25 @@ static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1
 
 static StepArgs make_args(const tpl_env* e) {
     StepArgs a{};
-    a.plane_a = e->plane_a; a.plane_b = e->plane_b; a.queue = e->queue;
-    a.n = e->n; a.L = (uint32_t)e->L; a.M = (uint32_t)e->M; a.W = (uint32_t)e->W;
+    a.plane_a = e->plane_a; a.plane_b = e->plane_b;
+    a.n = e->n; a.L = (uint32_t)e->L; a.M = (uint32_t)e->M;
     a.r_line = e->r_line; a.r_win = e->r_win; a.r_lose = e->r_lose;
-    a.pool_a = e->pool.a; a.pool_b = e->pool.b; a.pool_queue = e->pool.queue;
+    a.pool = e->pool.rec; a.stride = e->pool.stride;
     a.n_cfg = (uint32_t)e->pool.n_cfg; a.assign_mode = e->assign_mode; a.seed = e->seed;
     a.global_offset = e->global_offset; a.stats = e->stats;
     return a;
+}
+
+template <int kBpl>
+static void launch_step_bpl(bool action_form, bool auto_reset, const StepArgs& a, hipStream_t stream) {
+    const dim3 grid((unsigned)((a.n + (int64_t)kBlock * kBpl - 1) / ((int64_t)kBlock * kBpl))), block(kBlock);
+    if (action_form) {
+        if (auto_reset) hipLaunchKernelGGL((step_kernel<true, true, kBpl>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((step_kernel<true, false, kBpl>), grid, block, 0, stream, a);
+    } else {
+        if (auto_reset) hipLaunchKernelGGL((step_kernel<false, true, kBpl>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((step_kernel<false, false, kBpl>), grid, block, 0, stream, a);
+    }
 }
 
 static int launch_step(tpl_env* e, const void* act0, const void* act1, int32_t dtype, float* reward, uint8_t* done,
@@ -384,14 +412,11 @@ static int launch_step(tpl_env* e, const void* act0, const void* act1, int32_t d
     if (e->auto_reset && e->pool.n_cfg == 0) return fail(TPL_ERR_STATE, "auto_reset needs tpl_load_configs first");
     StepArgs a = make_args(e);
     a.act0 = act0; a.act1 = act1; a.dtype = dtype; a.reward = reward; a.done = done; a.cleared = cleared;
-    const dim3 grid(blocks_for(e->n)), block(kBlock);
     const bool action_form = act1 == nullptr;
-    if (action_form) {
-        if (e->auto_reset) hipLaunchKernelGGL((step_kernel<true, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((step_kernel<true, false>), grid, block, 0, stream, a);
-    } else {
-        if (e->auto_reset) hipLaunchKernelGGL((step_kernel<false, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((step_kernel<false, false>), grid, block, 0, stream, a);
+    switch (e->boards_per_lane) {
+        case 1: launch_step_bpl<1>(action_form, e->auto_reset != 0, a, stream); break;
+        case 2: launch_step_bpl<2>(action_form, e->auto_reset != 0, a, stream); break;
+        default: launch_step_bpl<4>(action_form, e->auto_reset != 0, a, stream); break;
     }
     TPL_HIP(hipGetLastError());
     return TPL_OK;
@@ -421,14 +446,13 @@ const char* tpl_version(void) { return "tetris_piclim 0.1.0 (gfx950)"; }
 size_t tpl_workspace_bytes(int64_t num_envs, int32_t M) {
     if (num_envs <= 0 || M < 1) return 0;
     const size_t n = (size_t)num_envs;
-    return align_up(n * sizeof(uint4), 256) * 2 + align_up(n * sizeof(uint32_t) * (size_t)queue_words(M), 256) +
+    return align_up(n * sizeof(uint4), 256) * 2 +
            align_up((size_t)kStatShards * kStatStride * sizeof(unsigned long long), 256);
 }
 
 size_t tpl_pool_bytes(int64_t n_cfg, int32_t M) {
     if (n_cfg <= 0 || M < 1) return 0;
-    const size_t n = (size_t)n_cfg;
-    return align_up(n * sizeof(uint4), 256) * 2 + align_up(n * sizeof(uint32_t) * (size_t)queue_words(M), 256);
+    return (size_t)n_cfg * record_stride(M);
 }
 
 int tpl_create(tpl_env** out, int64_t num_envs, int32_t L, int32_t M, int32_t device_id, int64_t global_offset,
@@ -448,7 +472,7 @@ int tpl_create(tpl_env** out, int64_t num_envs, int32_t L, int32_t M, int32_t de
     const size_t need = tpl_workspace_bytes(num_envs, M);
     tpl_env* e = new (std::nothrow) tpl_env();
     if (!e) return fail(TPL_ERR_NOMEM, "host allocation failed");
-    e->n = num_envs; e->L = L; e->M = M; e->W = queue_words(M); e->device = device_id;
+    e->n = num_envs; e->L = L; e->M = M; e->device = device_id;
     e->global_offset = global_offset; e->seed = seed;
     char* base = (char*)workspace;
     if (base) {
@@ -462,7 +486,6 @@ int tpl_create(tpl_env** out, int64_t num_envs, int32_t L, int32_t M, int32_t de
     const size_t n = (size_t)num_envs;
     e->plane_a = (uint4*)base; base += align_up(n * sizeof(uint4), 256);
     e->plane_b = (uint4*)base; base += align_up(n * sizeof(uint4), 256);
-    e->queue = (uint32_t*)base; base += align_up(n * sizeof(uint32_t) * (size_t)e->W, 256);
     e->stats = (unsigned long long*)base;
     hipError_t err = hipMemset(e->plane_a, 0, need);   // every board: empty, running, no pieces
     if (err != hipSuccess) {
@@ -513,14 +536,13 @@ int tpl_load_configs(tpl_env* e, const uint16_t* rows, const uint8_t* pieces, in
         TPL_HIP(hipStreamSynchronize((hipStream_t)stream));
         (void)hipFree(e->pool.owned);
     }
-    const size_t n = (size_t)n_cfg;
     e->pool.owned = newly_owned;
-    e->pool.a = (uint4*)base; base += align_up(n * sizeof(uint4), 256);
-    e->pool.b = (uint4*)base; base += align_up(n * sizeof(uint4), 256);
-    e->pool.queue = (uint32_t*)base;
+    e->pool.rec = (uint8_t*)base;
+    e->pool.stride = (uint32_t)record_stride(e->M);
     e->pool.n_cfg = n_cfg;
+    TPL_HIP(hipMemsetAsync(base, 0, need, (hipStream_t)stream));     // record padding reads as zero
     hipLaunchKernelGGL(pack_configs_kernel, dim3(blocks_for(n_cfg)), dim3(kBlock), 0, (hipStream_t)stream, rows, pieces,
-                       n_cfg, (uint32_t)e->M, (uint32_t)e->W, e->pool.a, e->pool.b, e->pool.queue);
+                       n_cfg, (uint32_t)e->M, (uint32_t)piece_words(e->M), e->pool.rec, e->pool.stride);
     TPL_HIP(hipGetLastError());
     return TPL_OK;
 }
@@ -604,12 +626,17 @@ int tpl_shape_info(int32_t piece, int32_t rotations, int32_t* h, int32_t* w, uin
     return TPL_OK;
 }
 
-int tpl_state_ptrs(tpl_env* e, void** plane_a, void** plane_b, void** queue, int32_t* queue_words_out) {
+int tpl_state_ptrs(tpl_env* e, void** plane_a, void** plane_b) {
     if (!e) return fail(TPL_ERR_ARG, "env is null");
     if (plane_a) *plane_a = e->plane_a;
     if (plane_b) *plane_b = e->plane_b;
-    if (queue) *queue = e->queue;
-    if (queue_words_out) *queue_words_out = e->W;
+    return TPL_OK;
+}
+
+int tpl_set_tuning(tpl_env* e, int32_t boards_per_lane) {
+    if (!e) return fail(TPL_ERR_ARG, "env is null");
+    if (boards_per_lane != 1 && boards_per_lane != 2 && boards_per_lane != 4) return fail(TPL_ERR_ARG, "boards_per_lane must be 1, 2 or 4");
+    e->boards_per_lane = boards_per_lane;
     return TPL_OK;
 }
 

@@ -4,14 +4,20 @@
 // because the reference's drop rule is column-top based (game/tetris.py:427-433): a column's top is one
 // v_ffbl on its word.  Citations "(:NNN)" are lines of the reference's game/tetris.py.
 //
-// Resident state, 32 B per board in two uint4 planes (SoA, plane[i] is board i -> 1 KiB per wave-load):
-//   A.x = col0 | col1<<20        A.y = col1>>12 | col2<<8       (three 20-bit columns per 64 bits)
-//   A.z = col3 | col4<<20        A.w = col4>>12 | col5<<8
-//   B.x = col6 | col7<<20        B.y = col7>>12 | col8<<8
-//   B.z = col9 | cur<<20 | nxt<<23 | state<<26                  (state: 0 run, 1 won, 2 lost@limit, 3 lost@top-out)
-//   B.w = lines_cleared | moves_used<<8 | episode<<16
-// Piece queue: queue[w][i], ten 3-bit piece ids per 32-bit word, entry j of a board's list in word j/10;
-// entries past the end of the list read 7.
+// Resident state, 32 B per board in two uint4 planes (SoA, plane[i] is board i -> 1 KiB per wave-load).
+// 200 board bits + 18 counter bits + a 30-bit window of the piece list + 8 episode bits = 256:
+//   A.x = col0 | col1<<20     A.y = col1>>12 | col2<<8 | moves[3:0]<<28     (three 20-bit columns per 64 bits)
+//   A.z = col3 | col4<<20     A.w = col4>>12 | col5<<8 | moves[7:4]<<28
+//   B.x = col6 | col7<<20     B.y = col7>>12 | col8<<8 | episode[7:4]<<28
+//   B.z = col9 | lines_cleared<<20 | episode[3:0]<<28
+//   B.w = piece window (ten 3-bit ids, entry 0 = pieces[0], entry 1 = pieces[1]) | state<<30
+//         (state: 0 run, 1 won, 2 lost@limit, 3 lost@top-out)
+// Piece list of a configuration, in the pool: 32-bit words of ten 3-bit ids with a stride of EIGHT entries,
+// word w = entries [8w, 8w+10), ids past the end of the list read 7.  A board carries one such word as its
+// window: every move shifts it down by one entry, and when the cursor reaches a multiple of eight the two
+// entries left in the window are exactly the first two of word cursor/8, which is then loaded whole.  So
+// pieces[0] and pieces[1] are always in the state itself and the common step does one round trip to HBM.
+// Pool record (AoS, `stride` bytes, 64-B aligned): plane-A word, plane-B word (window = word 0), words 1..
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -22,13 +28,15 @@ namespace tpl {
 constexpr int kRows = 20;
 constexpr int kCols = 10;
 constexpr uint32_t kColMask = 0xFFFFFu;
-constexpr int kPiecesPerWord = 10;
+constexpr int kWindowStride = 8;     // entries between the starts of consecutive piece words
+constexpr int kWindowEntries = 10;
 
 enum : uint32_t { ST_RUNNING = 0, ST_WON = 1, ST_LOST_LIMIT = 2, ST_LOST_TOPOUT = 3 };
 
 struct Board {
     uint32_t c[kCols];   // column words
-    uint32_t cur, nxt, state, lines, moves, episode;
+    uint32_t window;     // piece window: entry 0 = the piece that falls next (pieces[0]), entry 1 = pieces[1]
+    uint32_t state, lines, moves, episode;
 };
 
 // ---- shape table --------------------------------------------------------------------------------------
@@ -103,20 +111,22 @@ __device__ __forceinline__ void unpack_board(const uint4& A, const uint4& B, Boa
     unpack3(A.z, A.w, s.c[3], s.c[4], s.c[5]);
     unpack3(B.x, B.y, s.c[6], s.c[7], s.c[8]);
     s.c[9] = B.z & kColMask;
-    s.cur = (B.z >> 20) & 7u;
-    s.nxt = (B.z >> 23) & 7u;
-    s.state = (B.z >> 26) & 3u;
-    s.lines = B.w & 0xFFu;
-    s.moves = (B.w >> 8) & 0xFFu;
-    s.episode = B.w >> 16;
+    s.lines = (B.z >> 20) & 0xFFu;
+    s.moves = (A.y >> 28) | ((A.w >> 28) << 4);
+    s.episode = (B.z >> 28) | ((B.y >> 28) << 4);
+    s.window = B.w & 0x3FFFFFFFu;
+    s.state = B.w >> 30;
 }
 
 __device__ __forceinline__ void pack_board(const Board& s, uint4& A, uint4& B) {
     pack3(s.c[0], s.c[1], s.c[2], A.x, A.y);
     pack3(s.c[3], s.c[4], s.c[5], A.z, A.w);
     pack3(s.c[6], s.c[7], s.c[8], B.x, B.y);
-    B.z = s.c[9] | (s.cur << 20) | (s.nxt << 23) | (s.state << 26);
-    B.w = s.lines | (s.moves << 8) | (s.episode << 16);
+    A.y |= s.moves << 28;              // low nibble (the high one shifts out)
+    A.w |= (s.moves >> 4) << 28;
+    B.y |= (s.episode >> 4) << 28;
+    B.z = s.c[9] | (s.lines << 20) | (s.episode << 28);
+    B.w = s.window | (s.state << 30);
 }
 
 // rows (interchange, u16[20], bit x = column x) <-> columns
@@ -142,13 +152,13 @@ __device__ __forceinline__ uint32_t row_of_cols(const uint32_t* c, int r) {
 __device__ __forceinline__ uint32_t blend(uint32_t m, uint32_t x, uint32_t y) { return (m & x) | (~m & y); }
 
 // ---- the move ------------------------------------------------------------------------------------------
-// Tetris.move(rotations, location) (:354-422) on the lane's board; the piece is s.cur, already popped from
-// the queue by the caller (:356).  `shape` is the LDS-resident table.  Returns rows cleared (0..4); sets
+// Tetris.move(rotations, location) (:354-422) on the lane's board; the piece is entry 0 of the window, which the
+// caller pops (:356).  `shape` is the LDS-resident table.  Returns rows cleared (0..4); sets
 // `topout` when drop < 0 (:372-374), in which case the board and moves_used are left unchanged.
 __device__ __forceinline__ uint32_t move_board(Board& s, const ShapeWord* shape, uint32_t rot, uint32_t loc,
                                                uint32_t L, uint32_t M, bool& topout) {
     // get_tetromino (:60-61, :359-360)
-    const ShapeWord sh = shape[s.cur * 4u + (rot & 3u)];
+    const ShapeWord sh = shape[(s.window & 7u) * 4u + (rot & 3u)];
     const uint32_t w = (sh.x >> 16) & 7u;
     const uint32_t h = (sh.x >> 19) & 7u;
 

@@ -76,6 +76,10 @@ class BatchedTetris:
         mode = {"hash": _lib.TPL_ASSIGN_HASH, "sequential": _lib.TPL_ASSIGN_SEQUENTIAL}[self.assign]
         check(self._lib.tpl_set_options(self._h, int(self.auto_reset), mode, *self.reward_params))
 
+    def set_tuning(self, boards_per_lane: int) -> None:
+        """Boards per lane in the step kernel (1, 2 or 4); a speed knob, results do not depend on it."""
+        check(self._lib.tpl_set_tuning(self._h, int(boards_per_lane)))
+
     def set_options(self, auto_reset=None, assign=None, reward=None):
         if auto_reset is not None:
             self.auto_reset = bool(auto_reset)
@@ -277,7 +281,7 @@ class Tetris:
     @property
     def pieces(self) -> list:
         left = int(self._s()["pieces_left"][0])
-        cfg = self._episode % self._pieces_host.shape[0]
+        cfg = (self._episode & 0xFF) % self._pieces_host.shape[0]     # the device keeps 8 episode bits
         return self._pieces_host[cfg][self.M + 1 - left:].tolist()
 
     lines_cleared = property(lambda self: int(self._s()["lines"][0]))

@@ -244,6 +244,54 @@ def test_auto_reset_rollout_matches_oracle(T, oracle, assign):
     gpu.terminate()
 
 
+@pytest.mark.parametrize("bpl", [1, 2, 4])
+def test_many_short_episodes_wrap_the_episode_counter(T, oracle, bpl):
+    """L=1, M=2: every episode lasts at most two moves, so 700 steps pass the 8-bit episode wrap; also runs
+    each boards-per-lane variant of the step kernel and a ragged batch size."""
+    L, M, n, pool, seed = 1, 2, 5000, 777, 3
+    gpu = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True, assign="hash")
+    gpu.set_tuning(bpl)
+    rows, pieces = gpu.synthetic_configs(pool)
+    gpu.load_configs(rows, pieces)
+    gpu.reset()
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
+    cpu.set_options(auto_reset=True, assign_mode=0)
+    cpu.reset()
+    for t in range(700):
+        a = gpu.synthetic_actions(t)
+        _, r_g, d_g, _ = gpu.step(a, observe=False)
+        r_c, d_c = cpu.step(_np(a))
+        if t % 50 == 0 or t == 699:
+            assert np.array_equal(_np(r_g), r_c) and np.array_equal(_np(d_g).astype(np.uint8), d_c), t
+            _assert_state_equal(_state(gpu), cpu.get_state(), f"step {t}")
+    assert gpu.stats() == cpu.stats() and gpu.stats()["episodes"] > 300 * n
+    gpu.terminate()
+
+
+@pytest.mark.parametrize("M", [7, 8, 9, 15, 16, 17, 70, 254])
+def test_piece_window_refills_at_every_word_boundary(T, oracle, M):
+    """Boards that survive all M moves (empty start, O pieces side by side never top out before M for small M;
+    otherwise whatever happens) with random piece lists: checks cur/nxt against the oracle on every step."""
+    L, n = 250, 2048
+    rng = np.random.default_rng(M)
+    rows = np.zeros((n, 20), np.uint16)
+    pieces = rng.integers(0, 7, (n, M + 1)).astype(np.uint8)
+    gpu = T.BatchedTetris(L, M, n, assign="sequential", config_pool=(rows, pieces))
+    cpu = oracle.Env(n, L, M)
+    cpu.set_pool(rows, pieces)
+    cpu.set_options(assign_mode=1)
+    gpu.reset(); cpu.reset()
+    for t in range(M):
+        # spread the pieces out so that many boards live long: column from the step index
+        rot = np.zeros(n, np.uint8)
+        loc = ((np.arange(n) + 3 * t) % 10).astype(np.uint8)
+        gpu.move(rot, loc); cpu.move(rot, loc)
+        _assert_state_equal(_state(gpu), cpu.get_state(), f"M={M} step {t}")
+    assert (cpu.get_state()["moves"] >= min(M, 8)).mean() > 0.2      # the refill path was really exercised
+    gpu.terminate()
+
+
 def test_observation_matches_oracle(T, oracle):
     import torch
     L, M, n = 10, 40, 1000          # not a multiple of 64: exercises the ragged tail

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""A/B the step kernel's tuning knobs in ONE process (interleaved rounds, median + min) on the bench workload."""
+import argparse
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--boards", type=int, default=1 << 20)
+    ap.add_argument("--L", type=int, default=10)
+    ap.add_argument("--M", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--bpl", type=int, nargs="+", default=[1, 2, 4])
+    ap.add_argument("--auto-reset", type=int, default=1)
+    args = ap.parse_args()
+    import torch
+    import tetris_piclim as T
+
+    n = args.boards
+    env = T.BatchedTetris(args.L, args.M, n, auto_reset=bool(args.auto_reset))
+    rows, pieces = env.synthetic_configs(n)
+    env.load_configs(rows, pieces)
+    env.reset()
+    K = args.steps
+    actions = torch.empty((K, n), dtype=torch.uint8, device=env.device)
+    for t in range(K):
+        env.synthetic_actions(t, out=actions[t])
+    reward = torch.empty(n, dtype=torch.float32, device=env.device)
+    done = torch.empty(n, dtype=torch.uint8, device=env.device)
+    res = {b: [] for b in args.bpl}
+    for r in range(args.rounds + 1):
+        for b in args.bpl:
+            env.set_tuning(b)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for t in range(K):
+                env.step_into(actions[t], reward, done)
+            e1.record()
+            torch.cuda.synchronize()
+            if r:
+                res[b].append(e0.elapsed_time(e1) / K * 1e3)
+    for b, v in res.items():
+        print(f"bpl={b}: median {statistics.median(v):.2f} us  min {min(v):.2f} us  -> "
+              f"{n / statistics.median(v) / 1e3:.1f} G steps/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
