@@ -72,7 +72,8 @@ def main():
 
     n, L, M, K, W = args.boards, args.L, args.M, args.steps, args.warmup
     pool = args.pool or n
-    offset = rank * n                                            # batch-index sharding: contiguous blocks
+    shard = T.sharding.weak_shard(rank, world, n)               # batch-index sharding: contiguous blocks
+    offset = shard.global_offset
     env = T.BatchedTetris(L, M, n, device=dev, seed=args.seed, global_offset=offset, auto_reset=True, assign="hash")
     rows, pieces = env.synthetic_configs(pool, first=offset)
     env.load_configs(rows, pieces)
@@ -92,9 +93,7 @@ def main():
 
     for t in range(W):
         env.step_into(actions[t], reward, done)
-    warm = env.return_sum(env.stats_tensor())                     # load the reduction kernels outside the timed region
-    if world > 1:
-        dist.all_reduce(warm)
+    T.sharding.mean_episodic_return(env.stats_tensor(), env.reward_params)   # load the reduction kernels / RCCL rings
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
@@ -105,9 +104,8 @@ def main():
     for t in range(W, W + K):
         env.step_into(actions[t], reward, done)
     ev1.record()                                                  # same stream as the kernel launches
-    ret = env.return_sum(env.stats_tensor())                      # [sum of episodic returns, episodes]
-    if world > 1:
-        dist.all_reduce(ret)                                      # the one collective: RCCL sum over xGMI
+    # the one collective of the job: RCCL all-reduce (sum) of [return sum, episodes] over xGMI
+    mean_return, episodes = T.sharding.mean_episodic_return(env.stats_tensor(), env.reward_params)
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
@@ -118,7 +116,6 @@ def main():
     if world > 1:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
     elapsed = float(t_all.item())
-    ret = ret.tolist()
 
     if rank == 0:
         total_steps = float(n) * world * K
@@ -151,8 +148,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "step_kernel<action, auto_reset>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BOARD_STEP * n},
-            "mean_episodic_return": (ret[0] / ret[1]) if ret[1] else None,
-            "episodes": ret[1],
+            "mean_episodic_return": mean_return if episodes else None,
+            "episodes": episodes,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(L, M, args.seed)

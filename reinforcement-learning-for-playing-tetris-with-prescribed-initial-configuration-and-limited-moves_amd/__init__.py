@@ -15,8 +15,10 @@ __all__ = ["BatchedTetris", "Tetris", "OBS_DIM", "NUM_ACTIONS", "RUNNING", "WON"
 
 def __getattr__(name):
     # env.py needs torch; keep `import tetris_piclim` cheap for callers that only build or bind the library
+    import importlib
     if name in ("BatchedTetris", "Tetris", "OBS_DIM", "NUM_ACTIONS", "RUNNING", "WON", "LOST", "env"):
-        import importlib
         env = importlib.import_module(__name__ + ".env")
         return env if name == "env" else getattr(env, name)
+    if name == "sharding":
+        return importlib.import_module(__name__ + ".sharding")
     raise AttributeError(name)

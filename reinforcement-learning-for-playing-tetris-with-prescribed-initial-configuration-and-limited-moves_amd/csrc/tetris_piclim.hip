@@ -86,6 +86,7 @@ struct StepArgs {
     int32_t assign_mode;
     uint64_t seed;
     int64_t global_offset;
+    uint32_t offset_mod;       // global_offset mod n_cfg
     unsigned long long* stats;
 };
 
@@ -112,10 +113,8 @@ template <bool kActionForm, bool kAutoReset, int kBpl>
 __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs p) {
     __shared__ ShapeWord s_shape[32];
     __shared__ uint32_t s_stat[4];
-    if (threadIdx.x < 32) s_shape[threadIdx.x] = kShapeTable[threadIdx.x];
-    if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
-    __syncthreads();
 
+    // board loads first: the shape table's trip to LDS then rides in their shadow instead of ahead of them
     const int64_t base = (int64_t)blockIdx.x * (kBlock * kBpl) + threadIdx.x;
     uint4 A[kBpl], B[kBpl];
     uint32_t a0[kBpl], a1[kBpl];
@@ -129,6 +128,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs p) {
             a1[k] = kActionForm ? 0u : load_int(p.act1, p.dtype, i);
         }
     }
+    if (threadIdx.x < 32) s_shape[threadIdx.x] = kShapeTable[threadIdx.x];
+    if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
+    __syncthreads();
 
     bool finished = false;
 #pragma unroll
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs p) {
             const bool refill = (cursor & (uint32_t)(kWindowStride - 1)) == 0u && p.n_cfg != 0u;
             uint32_t word = 0;
             if (refill) {
-                const uint32_t cfg = assign_config((uint64_t)(p.global_offset + i), s.episode, p.seed, p.n_cfg, p.assign_mode);
+                const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, s.episode, p.seed, p.n_cfg, p.assign_mode);
                 word = *(const uint32_t*)(p.pool + (size_t)cfg * p.stride + 32u + 4u * ((cursor >> 3) - 1u));
             }
 
@@ -172,15 +174,16 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs p) {
 
             uint4 A2, B2;
             if (done) {
+                // adds of a constant collapse to one popcount per wave; the line sum is rarely non-zero
                 finished = true;
                 atomicAdd(&s_stat[0], 1u);
-                atomicAdd(&s_stat[1], s.lines);
-                atomicAdd(&s_stat[2], s.state == ST_WON ? 1u : 0u);
-                atomicAdd(&s_stat[3], s.state == ST_LOST_TOPOUT ? 1u : 0u);
+                if (s.lines) atomicAdd(&s_stat[1], s.lines);
+                if (s.state == ST_WON) atomicAdd(&s_stat[2], 1u);
+                if (s.state == ST_LOST_TOPOUT) atomicAdd(&s_stat[3], 1u);
             }
             if (kAutoReset && done) {
                 const uint32_t ep = (s.episode + 1u) & 0xFFu;
-                const uint32_t cfg = assign_config((uint64_t)(p.global_offset + i), ep, p.seed, p.n_cfg, p.assign_mode);
+                const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, ep, p.seed, p.n_cfg, p.assign_mode);
                 load_config(p.pool, p.stride, cfg, ep, A2, B2);
             } else {
                 pack_board(s, A2, B2);
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs p, const u
         unpack_board(p.plane_a[i], p.plane_b[i], s);
         ep = (s.episode + 1u) & 0xFFu;
     }
-    const uint32_t cfg = assign_config((uint64_t)(p.global_offset + i), ep, p.seed, p.n_cfg, p.assign_mode);
+    const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, ep, p.seed, p.n_cfg, p.assign_mode);
     uint4 A, B;
     load_config(p.pool, p.stride, cfg, ep, A, B);
     p.plane_a[i] = A;
@@ -391,6 +394,7 @@ static StepArgs make_args(const tpl_env* e) {
     a.pool = e->pool.rec; a.stride = e->pool.stride;
     a.n_cfg = (uint32_t)e->pool.n_cfg; a.assign_mode = e->assign_mode; a.seed = e->seed;
     a.global_offset = e->global_offset; a.stats = e->stats;
+    a.offset_mod = e->pool.n_cfg ? (uint32_t)((uint64_t)e->global_offset % (uint64_t)e->pool.n_cfg) : 0u;
     return a;
 }
 

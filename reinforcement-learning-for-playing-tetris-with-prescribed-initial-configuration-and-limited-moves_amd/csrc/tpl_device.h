@@ -252,10 +252,20 @@ __host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
     return h;
 }
 
-// which pool entry episode `episode` of global board `g` starts from
-__host__ __device__ __forceinline__ uint32_t assign_config(uint64_t g, uint32_t episode, uint64_t seed,
-                                                           uint32_t n_cfg, int mode) {
-    if (mode == 1) return (uint32_t)((g + (uint64_t)episode) % (uint64_t)n_cfg);
+// which pool entry episode `episode` of global board `g` = global_offset + i starts from.
+// hash mode: two rounds of a 32-bit finaliser, range-reduced with a multiply-high.
+// sequential mode: (g + episode) mod n_cfg, done with 32-bit remainders only (offset_mod = global_offset mod n_cfg
+// comes from the host) because a 64-bit remainder is a long software routine on the GPU.
+__device__ __forceinline__ uint32_t assign_config(int64_t global_offset, uint32_t offset_mod, uint32_t i, uint32_t episode,
+                                                  uint64_t seed, uint32_t n_cfg, int mode) {
+    if (mode == 1) {
+        uint64_t t = (uint64_t)offset_mod + (uint64_t)(i % n_cfg);
+        if (t >= n_cfg) t -= n_cfg;
+        t += episode % n_cfg;
+        if (t >= n_cfg) t -= n_cfg;
+        return (uint32_t)t;
+    }
+    const uint64_t g = (uint64_t)global_offset + i;
     uint32_t h = fmix32((uint32_t)g ^ ((uint32_t)(g >> 32) * 0x9E3779B9u) ^ (uint32_t)seed);
     h = fmix32(h + episode * 0x9E3779B1u + (uint32_t)(seed >> 32));
     return (uint32_t)(((uint64_t)h * (uint64_t)n_cfg) >> 32);

@@ -226,10 +226,8 @@ class BatchedTetris:
 
     def return_sum(self, stats: torch.Tensor) -> torch.Tensor:
         """[sum of episodic returns, episodes] (f64) from a stats tensor, under the current reward parameters."""
-        per_line, win, lose = self.reward_params
-        s = stats.to(torch.float64)
-        total = per_line * s[1] + win * s[2] + lose * (s[0] - s[2])
-        return torch.stack([total, s[0]])
+        from .sharding import return_sum
+        return return_sum(stats, self.reward_params)
 
     def terminate(self) -> None:
         """Tetris.terminate() (game/tetris.py:451-470): releases the handle."""
