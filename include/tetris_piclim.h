@@ -98,6 +98,14 @@ int tpl_move(tpl_env* env, const void* rot, const void* loc, int32_t dtype,
 /* step(action): move(action / 10, action % 10).  The surface BASELINE.json's north_star names. */
 int tpl_step(tpl_env* env, const void* action, int32_t dtype, float* reward, uint8_t* done, void* stream);
 
+/* num_steps consecutive steps in one launch, equivalent to num_steps calls of tpl_step with
+ * action = actions + k*action_stride (uint8, device).  The loop shape of game/performance_test.py:13-17
+ * (move; reset when finished) with the board held in registers between moves.  Outputs, each optional:
+ * reward_steps f32[num_steps][n], done_steps u8[num_steps][n], reward_sum f32[n] (sum over the steps in step
+ * order), finished u32[n] (episodes the board finished). */
+int tpl_rollout(tpl_env* env, const uint8_t* actions, int64_t action_stride, int32_t num_steps,
+                float* reward_steps, uint8_t* done_steps, float* reward_sum, uint32_t* finished, void* stream);
+
 /* Replaces Tetris.get_state() (game/tetris.py:435-436) and the public attributes, batched and in the
  * interchange layout.  Any output may be NULL.  rows [n][20] u16; cur/nxt u8[n] (7 = no such piece);
  * lines/moves u8[n] (lines_cleared, moves_used -- L_rem = L - lines, M_rem = M - moves); state u8[n];
@@ -120,8 +128,9 @@ int tpl_shape_info(int32_t piece, int32_t rotations, int32_t* h, int32_t* w, uin
 /* Raw device pointers of the resident packed state (for zero-copy inspection; layout in DESIGN.md). */
 int tpl_state_ptrs(tpl_env* env, void** plane_a, void** plane_b);
 
-/* Tuning knob of the step kernel: boards handled per lane (1, 2 or 4; default 2).  Results do not depend on it. */
-int tpl_set_tuning(tpl_env* env, int32_t boards_per_lane);
+/* Tuning knobs of the step kernel: boards handled per lane (1, 2 or 4; default 2) and threads per block
+ * (64, 128, 256 or 512; default 256).  Results do not depend on them. */
+int tpl_set_tuning(tpl_env* env, int32_t boards_per_lane, int32_t block_threads);
 
 /* Synthetic workload of SURVEY 8(d), generated on the device from a counter-based hash
  * keyed by (seed, stream, global board index, counter); DESIGN.md states the function. */

@@ -22,7 +22,7 @@ SYMBOLS = [
     "tpl_last_error", "tpl_version", "tpl_workspace_bytes", "tpl_pool_bytes", "tpl_create", "tpl_destroy",
     "tpl_set_options", "tpl_load_configs", "tpl_reset", "tpl_move", "tpl_step", "tpl_get_state",
     "tpl_expand_obs", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
-    "tpl_synth_actions", "tpl_set_tuning",
+    "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout",
 ]
 
 TPL_U8, TPL_I32, TPL_I64 = 0, 1, 2
@@ -85,12 +85,13 @@ def lib() -> C.CDLL:
     L.tpl_reset.argtypes = [vp, vp, vp]
     L.tpl_move.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
     L.tpl_step.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.tpl_rollout.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, vp]
     L.tpl_get_state.argtypes = [vp] * 9
     L.tpl_expand_obs.argtypes = [vp, vp, i32, vp]
     L.tpl_get_stats.argtypes = [vp, vp, vp]
     L.tpl_shape_info.argtypes = [i32, i32, C.POINTER(i32), C.POINTER(i32), vp, vp]
     L.tpl_state_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
-    L.tpl_set_tuning.argtypes = [vp, i32]
+    L.tpl_set_tuning.argtypes = [vp, i32, i32]
     L.tpl_synth_configs.argtypes = [vp, u64, i64, i64, vp, vp, vp]
     L.tpl_synth_actions.argtypes = [vp, u64, i64, i64, u64, vp, vp]
     for name in SYMBOLS:

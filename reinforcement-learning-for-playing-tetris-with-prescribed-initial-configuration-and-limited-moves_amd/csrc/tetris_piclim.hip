@@ -34,7 +34,8 @@ struct tpl_env {
     uint64_t seed = 0;
     int32_t auto_reset = 0, assign_mode = 0;
     float r_line = 1.0f, r_win = 0.0f, r_lose = 0.0f;
-    int32_t boards_per_lane = 2;        // tuning knob of the step kernel (1, 2 or 4)
+    int32_t boards_per_lane = 2;        // tuning knobs of the step kernel: boards per lane (1, 2 or 4)
+    int32_t block_threads = 256;        //   and threads per block (64, 128, 256 or 512)
     uint4* plane_a = nullptr;
     uint4* plane_b = nullptr;
     unsigned long long* stats = nullptr;// [kStatShards][kStatStride]
@@ -109,18 +110,18 @@ __device__ __forceinline__ void load_config(const uint8_t* pool, uint32_t stride
 // One Tetris.move per board (:354-422).  ACTION form: act0 = rot*10+loc; MOVE form: act0 = rot, act1 = loc.
 // Each lane owns kBpl boards (block-strided, so every load is still 1 KiB per wave); all their loads are
 // issued before the first move is computed.
-template <bool kActionForm, bool kAutoReset, int kBpl>
-__global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs p) {
+template <bool kActionForm, bool kAutoReset, int kBpl, int kThreads>
+__global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
     __shared__ ShapeWord s_shape[32];
     __shared__ uint32_t s_stat[4];
 
     // board loads first: the shape table's trip to LDS then rides in their shadow instead of ahead of them
-    const int64_t base = (int64_t)blockIdx.x * (kBlock * kBpl) + threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * (kThreads * kBpl) + threadIdx.x;
     uint4 A[kBpl], B[kBpl];
     uint32_t a0[kBpl], a1[kBpl];
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
-        const int64_t i = base + (int64_t)k * kBlock;
+        const int64_t i = base + (int64_t)k * kThreads;
         if (i < p.n) {
             A[k] = p.plane_a[i];
             B[k] = p.plane_b[i];
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs p) {
     bool finished = false;
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
-        const int64_t i = base + (int64_t)k * kBlock;
+        const int64_t i = base + (int64_t)k * kThreads;
         if (i >= p.n) continue;
         uint32_t rot, loc;
         if (kActionForm) {
@@ -198,6 +199,106 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs p) {
 
     // per-block statistics of the episodes that finished in this step -> one sharded 64-bit atomic per counter
     if (__syncthreads_or(finished ? 1 : 0)) {
+        if (threadIdx.x < 4) {
+            const uint32_t v = s_stat[threadIdx.x];
+            if (v) atomicAdd(&p.stats[(size_t)(blockIdx.x % kStatShards) * kStatStride + threadIdx.x],
+                             (unsigned long long)v);
+        }
+    }
+}
+
+// K consecutive moves per board in ONE launch: the board stays unpacked in registers between
+// moves, so the 64 B/step state round trip of step_kernel is paid once per K steps.  Actions are pre-staged
+// as actions[k][n] (uint8, stride `action_stride` between steps).  Semantics are exactly K calls of tpl_step:
+// same freeze / auto-reset rules, same statistics, and -- when asked for -- the same per-step reward/done.
+struct RolloutArgs {
+    StepArgs s;
+    const uint8_t* actions;     // [K][stride]
+    int64_t action_stride;
+    uint32_t K;
+    float* reward_steps;        // [K][n] or null
+    uint8_t* done_steps;        // [K][n] or null
+    float* reward_sum;          // [n] or null: sum over the K steps, accumulated in step order
+    uint32_t* finished;         // [n] or null: episodes this board finished during the K steps
+};
+
+template <bool kAutoReset>
+__global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
+    const StepArgs& p = q.s;
+    __shared__ ShapeWord s_shape[32];
+    __shared__ uint32_t s_stat[4];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i < p.n;
+    uint4 A = make_uint4(0, 0, 0, 0), B = A;
+    uint32_t act = 0;
+    if (valid) {
+        A = p.plane_a[i];
+        B = p.plane_b[i];
+        act = q.actions[i];
+    }
+    if (threadIdx.x < 32) s_shape[threadIdx.x] = kShapeTable[threadIdx.x];
+    if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
+    __syncthreads();
+
+    uint32_t t_eps = 0, t_lines = 0, t_wins = 0, t_tops = 0;
+    if (valid) {
+        Board s;
+        unpack_board(A, B, s);
+        float rsum = 0.0f;
+        for (uint32_t k = 0; k < q.K; ++k) {
+            // next step's action is independent of the board: fetch it under this step's move
+            uint32_t act_next = 0;
+            if (k + 1 < q.K) act_next = q.actions[(size_t)(k + 1) * q.action_stride + i];
+            const uint32_t rot = act / 10u, loc = act - rot * 10u;
+            float reward = 0.0f;
+            bool done = true;
+            if (s.state == ST_RUNNING) {
+                const uint32_t cursor = s.moves + 1u;
+                const bool refill = (cursor & (uint32_t)(kWindowStride - 1)) == 0u && p.n_cfg != 0u;
+                uint32_t word = 0;
+                if (refill) {
+                    const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, s.episode, p.seed, p.n_cfg, p.assign_mode);
+                    word = *(const uint32_t*)(p.pool + (size_t)cfg * p.stride + 32u + 4u * ((cursor >> 3) - 1u));
+                }
+                bool topout;
+                const uint32_t n_clear = move_board(s, s_shape, rot, loc, p.L, p.M, topout);
+                s.window = refill ? word : (s.window >> 3);
+                reward = p.r_line * (float)n_clear;
+                if (s.state == ST_WON) reward = reward + p.r_win;
+                if (s.state >= ST_LOST_LIMIT) reward = reward + p.r_lose;
+                done = s.state != ST_RUNNING;
+                if (done) {
+                    t_eps += 1u;
+                    t_lines += s.lines;
+                    t_wins += s.state == ST_WON ? 1u : 0u;
+                    t_tops += s.state == ST_LOST_TOPOUT ? 1u : 0u;
+                    if (kAutoReset) {
+                        const uint32_t ep = (s.episode + 1u) & 0xFFu;
+                        const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, ep, p.seed, p.n_cfg, p.assign_mode);
+                        uint4 A2, B2;
+                        load_config(p.pool, p.stride, cfg, ep, A2, B2);
+                        unpack_board(A2, B2, s);
+                    }
+                }
+            }
+            rsum = rsum + reward;
+            if (q.reward_steps) q.reward_steps[(size_t)k * p.n + i] = reward;
+            if (q.done_steps) q.done_steps[(size_t)k * p.n + i] = done ? 1 : 0;
+            act = act_next;
+        }
+        pack_board(s, A, B);
+        p.plane_a[i] = A;
+        p.plane_b[i] = B;
+        if (q.reward_sum) q.reward_sum[i] = rsum;
+        if (q.finished) q.finished[i] = t_eps;
+    }
+    if (t_eps) {
+        atomicAdd(&s_stat[0], t_eps);
+        if (t_lines) atomicAdd(&s_stat[1], t_lines);
+        if (t_wins) atomicAdd(&s_stat[2], t_wins);
+        if (t_tops) atomicAdd(&s_stat[3], t_tops);
+    }
+    if (__syncthreads_or(t_eps ? 1 : 0)) {
         if (threadIdx.x < 4) {
             const uint32_t v = s_stat[threadIdx.x];
             if (v) atomicAdd(&p.stats[(size_t)(blockIdx.x % kStatShards) * kStatStride + threadIdx.x],
@@ -398,15 +499,26 @@ static StepArgs make_args(const tpl_env* e) {
     return a;
 }
 
-template <int kBpl>
-static void launch_step_bpl(bool action_form, bool auto_reset, const StepArgs& a, hipStream_t stream) {
-    const dim3 grid((unsigned)((a.n + (int64_t)kBlock * kBpl - 1) / ((int64_t)kBlock * kBpl))), block(kBlock);
+template <int kBpl, int kThreads>
+static void launch_step_cfg(bool action_form, bool auto_reset, const StepArgs& a, hipStream_t stream) {
+    const int64_t per_block = (int64_t)kThreads * kBpl;
+    const dim3 grid((unsigned)((a.n + per_block - 1) / per_block)), block(kThreads);
     if (action_form) {
-        if (auto_reset) hipLaunchKernelGGL((step_kernel<true, true, kBpl>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((step_kernel<true, false, kBpl>), grid, block, 0, stream, a);
+        if (auto_reset) hipLaunchKernelGGL((step_kernel<true, true, kBpl, kThreads>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((step_kernel<true, false, kBpl, kThreads>), grid, block, 0, stream, a);
     } else {
-        if (auto_reset) hipLaunchKernelGGL((step_kernel<false, true, kBpl>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((step_kernel<false, false, kBpl>), grid, block, 0, stream, a);
+        if (auto_reset) hipLaunchKernelGGL((step_kernel<false, true, kBpl, kThreads>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((step_kernel<false, false, kBpl, kThreads>), grid, block, 0, stream, a);
+    }
+}
+
+template <int kBpl>
+static void launch_step_bpl(int threads, bool action_form, bool auto_reset, const StepArgs& a, hipStream_t stream) {
+    switch (threads) {
+        case 64: launch_step_cfg<kBpl, 64>(action_form, auto_reset, a, stream); break;
+        case 128: launch_step_cfg<kBpl, 128>(action_form, auto_reset, a, stream); break;
+        case 512: launch_step_cfg<kBpl, 512>(action_form, auto_reset, a, stream); break;
+        default: launch_step_cfg<kBpl, 256>(action_form, auto_reset, a, stream); break;
     }
 }
 
@@ -418,9 +530,9 @@ static int launch_step(tpl_env* e, const void* act0, const void* act1, int32_t d
     a.act0 = act0; a.act1 = act1; a.dtype = dtype; a.reward = reward; a.done = done; a.cleared = cleared;
     const bool action_form = act1 == nullptr;
     switch (e->boards_per_lane) {
-        case 1: launch_step_bpl<1>(action_form, e->auto_reset != 0, a, stream); break;
-        case 2: launch_step_bpl<2>(action_form, e->auto_reset != 0, a, stream); break;
-        default: launch_step_bpl<4>(action_form, e->auto_reset != 0, a, stream); break;
+        case 1: launch_step_bpl<1>(e->block_threads, action_form, e->auto_reset != 0, a, stream); break;
+        case 2: launch_step_bpl<2>(e->block_threads, action_form, e->auto_reset != 0, a, stream); break;
+        default: launch_step_bpl<4>(e->block_threads, action_form, e->auto_reset != 0, a, stream); break;
     }
     TPL_HIP(hipGetLastError());
     return TPL_OK;
@@ -577,6 +689,25 @@ int tpl_step(tpl_env* e, const void* action, int32_t dtype, float* reward, uint8
     return launch_step(e, action, nullptr, dtype, reward, done, nullptr, (hipStream_t)stream);
 }
 
+int tpl_rollout(tpl_env* e, const uint8_t* actions, int64_t action_stride, int32_t num_steps, float* reward_steps,
+                uint8_t* done_steps, float* reward_sum, uint32_t* finished, void* stream) {
+    if (!e) return fail(TPL_ERR_ARG, "env is null");
+    if (!actions) return fail(TPL_ERR_ARG, "actions is null");
+    if (num_steps < 1) return fail(TPL_ERR_ARG, "num_steps must be >= 1");
+    if (action_stride < e->n) return fail(TPL_ERR_ARG, "action_stride %lld is smaller than num_envs", (long long)action_stride);
+    if (e->auto_reset && e->pool.n_cfg == 0) return fail(TPL_ERR_STATE, "auto_reset needs tpl_load_configs first");
+    DeviceGuard guard(e->device);
+    RolloutArgs q{};
+    q.s = make_args(e);
+    q.actions = actions; q.action_stride = action_stride; q.K = (uint32_t)num_steps;
+    q.reward_steps = reward_steps; q.done_steps = done_steps; q.reward_sum = reward_sum; q.finished = finished;
+    const dim3 grid(blocks_for(e->n)), block(kBlock);
+    if (e->auto_reset) hipLaunchKernelGGL(rollout_kernel<true>, grid, block, 0, (hipStream_t)stream, q);
+    else hipLaunchKernelGGL(rollout_kernel<false>, grid, block, 0, (hipStream_t)stream, q);
+    TPL_HIP(hipGetLastError());
+    return TPL_OK;
+}
+
 int tpl_get_state(tpl_env* e, uint16_t* rows, uint8_t* cur, uint8_t* nxt, uint8_t* lines, uint8_t* moves,
                   uint8_t* state, uint8_t* pieces_left, void* stream) {
     if (!e) return fail(TPL_ERR_ARG, "env is null");
@@ -637,10 +768,13 @@ int tpl_state_ptrs(tpl_env* e, void** plane_a, void** plane_b) {
     return TPL_OK;
 }
 
-int tpl_set_tuning(tpl_env* e, int32_t boards_per_lane) {
+int tpl_set_tuning(tpl_env* e, int32_t boards_per_lane, int32_t block_threads) {
     if (!e) return fail(TPL_ERR_ARG, "env is null");
     if (boards_per_lane != 1 && boards_per_lane != 2 && boards_per_lane != 4) return fail(TPL_ERR_ARG, "boards_per_lane must be 1, 2 or 4");
+    if (block_threads != 64 && block_threads != 128 && block_threads != 256 && block_threads != 512)
+        return fail(TPL_ERR_ARG, "block_threads must be 64, 128, 256 or 512");
     e->boards_per_lane = boards_per_lane;
+    e->block_threads = block_threads;
     return TPL_OK;
 }
 

@@ -76,9 +76,9 @@ class BatchedTetris:
         mode = {"hash": _lib.TPL_ASSIGN_HASH, "sequential": _lib.TPL_ASSIGN_SEQUENTIAL}[self.assign]
         check(self._lib.tpl_set_options(self._h, int(self.auto_reset), mode, *self.reward_params))
 
-    def set_tuning(self, boards_per_lane: int) -> None:
-        """Boards per lane in the step kernel (1, 2 or 4); a speed knob, results do not depend on it."""
-        check(self._lib.tpl_set_tuning(self._h, int(boards_per_lane)))
+    def set_tuning(self, boards_per_lane: int = 2, block_threads: int = 256) -> None:
+        """Step-kernel geometry (boards per lane 1/2/4, threads per block 64..512); results do not depend on it."""
+        check(self._lib.tpl_set_tuning(self._h, int(boards_per_lane), int(block_threads)))
 
     def set_options(self, auto_reset=None, assign=None, reward=None):
         if auto_reset is not None:
@@ -181,6 +181,30 @@ class BatchedTetris:
         check(self._lib.tpl_step(self._h, _ptr(act), code, _ptr(reward), _ptr(done), self._stream()))
         obs = self.observe(obs_dtype) if observe else None
         return obs, reward, done.view(torch.bool), {}
+
+    def rollout(self, actions: torch.Tensor, per_step: bool = False):
+        """K consecutive steps in one kernel launch: actions uint8 [K, N] on the device.  Equivalent to K calls
+        of step(); the board stays in registers between moves.  Returns (reward_sum f32[N], finished int32[N])
+        and, if per_step, also (reward f32[K,N], done bool[K,N])."""
+        if actions.dtype != torch.uint8 or actions.dim() != 2 or actions.shape[1] != self.num_envs:
+            raise ValueError(f"actions must be uint8 [K, {self.num_envs}]")
+        actions = actions.to(self.device)
+        if actions.stride(1) != 1:
+            actions = actions.contiguous()
+        K = actions.shape[0]
+        rsum = torch.empty(self.num_envs, dtype=torch.float32, device=self.device)
+        fin = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
+        rs = ds = None
+        if per_step:
+            rs = torch.empty((K, self.num_envs), dtype=torch.float32, device=self.device)
+            ds = torch.empty((K, self.num_envs), dtype=torch.uint8, device=self.device)
+        check(self._lib.tpl_rollout(self._h, _ptr(actions), actions.stride(0), K, _ptr(rs), _ptr(ds), _ptr(rsum), _ptr(fin),
+                                    self._stream()))
+        return (rsum, fin, rs, ds.view(torch.bool)) if per_step else (rsum, fin)
+
+    def rollout_into(self, actions: torch.Tensor, K: int) -> None:
+        """rollout() without outputs (statistics only): the throughput form used by bench.py."""
+        check(self._lib.tpl_rollout(self._h, _ptr(actions), actions.stride(0), K, None, None, None, None, self._stream()))
 
     def observe(self, dtype=torch.float32, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[N, 217] observation for Model(217, 14) (model/train.py:26)."""

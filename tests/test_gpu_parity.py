@@ -292,6 +292,48 @@ def test_piece_window_refills_at_every_word_boundary(T, oracle, M):
     gpu.terminate()
 
 
+@pytest.mark.parametrize("auto", [True, False])
+def test_fused_rollout_equals_k_single_steps_and_the_oracle(T, oracle, auto):
+    """tpl_rollout (K moves per launch, board held in registers) == K x tpl_step == the oracle."""
+    import torch
+    L, M, n, pool, seed, K = 5, 20, 10007, 999, 13, 57
+    envs = [T.BatchedTetris(L, M, n, seed=seed, auto_reset=auto, reward=(1.0, 3.0, -0.5)) for _ in range(2)]
+    rows, pieces = envs[0].synthetic_configs(pool)
+    for e in envs:
+        e.load_configs(rows, pieces)
+        e.reset()
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
+    cpu.set_options(auto_reset=auto, assign_mode=0, per_line=1.0, win=3.0, lose=-0.5)
+    cpu.reset()
+    actions = torch.stack([envs[0].synthetic_actions(t) for t in range(K)])
+    # two rollout launches (K1 + K2) to also cover resuming from a stored state
+    K1 = 20
+    rsum1, fin1, rs1, ds1 = envs[0].rollout(actions[:K1], per_step=True)
+    rsum2, fin2, rs2, ds2 = envs[0].rollout(actions[K1:], per_step=True)
+    rs, ds = torch.cat([rs1, rs2]), torch.cat([ds1, ds2])
+    acc1 = np.zeros(n, np.float32); acc2 = np.zeros(n, np.float32); fins = np.zeros(n, np.int64)
+    for t in range(K):
+        _, r_b, d_b, _ = envs[1].step(actions[t], observe=False)
+        before = cpu.get_state()["state"]
+        r_c, d_c = cpu.step(_np(actions[t]))
+        assert np.array_equal(_np(rs[t]), r_c) and np.array_equal(_np(ds[t]).astype(np.uint8), d_c), t
+        assert np.array_equal(_np(r_b), r_c) and np.array_equal(_np(d_b).astype(np.uint8), d_c), t
+        if t < K1:
+            acc1 += r_c
+        else:
+            acc2 += r_c
+        fins += (d_c == 1) & (before == 0)
+    want = cpu.get_state()
+    _assert_state_equal(_state(envs[0]), want, "rollout")
+    _assert_state_equal(_state(envs[1]), want, "steps")
+    assert np.array_equal(_np(rsum1), acc1) and np.array_equal(_np(rsum2), acc2)
+    assert np.array_equal(_np(fin1).astype(np.int64) + _np(fin2).astype(np.int64), fins)
+    assert envs[0].stats() == cpu.stats() == envs[1].stats()
+    for e in envs:
+        e.terminate()
+
+
 def test_observation_matches_oracle(T, oracle):
     import torch
     L, M, n = 10, 40, 1000          # not a multiple of 64: exercises the ragged tail

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--bpl", type=int, nargs="+", default=[1, 2, 4])
+    ap.add_argument("--threads", type=int, nargs="+", default=[256])
     ap.add_argument("--auto-reset", type=int, default=1)
     args = ap.parse_args()
     import torch
@@ -32,10 +33,11 @@ def main():
         env.synthetic_actions(t, out=actions[t])
     reward = torch.empty(n, dtype=torch.float32, device=env.device)
     done = torch.empty(n, dtype=torch.uint8, device=env.device)
-    res = {b: [] for b in args.bpl}
+    combos = [(b, th) for b in args.bpl for th in args.threads]
+    res = {c: [] for c in combos}
     for r in range(args.rounds + 1):
-        for b in args.bpl:
-            env.set_tuning(b)
+        for b in combos:
+            env.set_tuning(*b)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for t in range(K):
@@ -44,8 +46,22 @@ def main():
             torch.cuda.synchronize()
             if r:
                 res[b].append(e0.elapsed_time(e1) / K * 1e3)
+    # fused rollout: K steps per launch
+    for chunk in (8, 32, K):
+        v = []
+        for r in range(args.rounds + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for t in range(0, K - chunk + 1, chunk):
+                env.rollout_into(actions[t:t + chunk], chunk)
+            e1.record()
+            torch.cuda.synchronize()
+            if r:
+                v.append(e0.elapsed_time(e1) / ((K // chunk) * chunk) * 1e3)
+        print(f"n={n} rollout chunk={chunk}: median {statistics.median(v):.2f} us/step  -> "
+              f"{n / statistics.median(v) / 1e3:.1f} G steps/s", flush=True)
     for b, v in res.items():
-        print(f"bpl={b}: median {statistics.median(v):.2f} us  min {min(v):.2f} us  -> "
+        print(f"n={n} bpl,threads={b}: median {statistics.median(v):.2f} us  min {min(v):.2f} us  -> "
               f"{n / statistics.median(v) / 1e3:.1f} G steps/s", flush=True)
 
 
