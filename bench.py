@@ -31,13 +31,16 @@ def cpu_baseline(L, M, seed):
     """The oracle's loop (game/performance_test.py:13-17 shape: move, reset when finished) on the host cores."""
     from oracle import oracle as O
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    boards, steps = 65536, 40
+    boards, steps = 262144, 40
     O.bench_run(seed, 4096, L, M, 8, cores)                      # warm the thread pool / page in
     done, sec = O.bench_run(seed, boards, L, M, steps, cores)
     rate = done / sec
-    # bounded sample: scale the step count so the timed part is about 10 s of CPU work
-    steps = int(max(40, min(4000, 10.0 * rate / boards)))
-    done, sec = O.bench_run(seed, boards, L, M, steps, cores)
+    # bounded sample: grow the step count until the timed part is a few seconds of wall time on all cores
+    for _ in range(3):
+        if sec >= 3.0 or steps >= 20000:
+            break
+        steps = int(max(40, min(20000, 5.0 * (done / sec) / boards)))
+        done, sec = O.bench_run(seed, boards, L, M, steps, cores)
     return {"value": done / sec, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{boards} boards x {steps} lockstep steps, L={L} M={M}, auto-reset, {cores} threads, {sec:.1f}s"}
 
@@ -53,6 +56,7 @@ def main():
     ap.add_argument("--pool", type=int, default=0, help="pool size per GPU (default: one config per board)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunk", type=int, default=50, help="steps per launch of the fused-rollout side measurement (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -112,6 +116,36 @@ def main():
     elapsed = time.perf_counter() - t0
 
     kernel_ms = ev0.elapsed_time(ev1) / K                         # average launch-to-launch duration of the step kernel
+
+    # secondary figure: the fused rollout (tpl_rollout) over the same pre-staged actions, writing the
+    # same per-step reward/done outputs; chunks of `args.chunk` steps per launch.  Not part of `value`.
+    fused = None
+    if args.chunk > 0 and K >= args.chunk:
+        C_ = args.chunk
+        rs = torch.empty((C_, n), dtype=torch.float32, device=dev)
+        ds = torch.empty((C_, n), dtype=torch.uint8, device=dev)
+        lib, h, stream = env._lib, env._h, env._stream()
+        import ctypes
+        def run_chunks():
+            for t0_ in range(W, W + (K // C_) * C_, C_):
+                a = actions[t0_:t0_ + C_]
+                T._lib.check(lib.tpl_rollout(h, ctypes.c_void_p(a.data_ptr()), a.stride(0), C_, ctypes.c_void_p(rs.data_ptr()),
+                                             ctypes.c_void_p(ds.data_ptr()), None, None, stream))
+        run_chunks()
+        torch.cuda.synchronize(dev)
+        barrier()
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record()
+        run_chunks()
+        f1.record()
+        torch.cuda.synchronize(dev)
+        fused_ms = f0.elapsed_time(f1) / ((K // C_) * C_)
+        ft = torch.tensor([fused_ms], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(ft, op=dist.ReduceOp.MAX)
+        fused = {"value": float(n) * world / (float(ft.item()) * 1e-3), "unit": "env-steps/s", "steps_per_launch": C_,
+                 "ms_per_step": float(ft.item()), "outputs": "per-step reward f32 + done u8 written",
+                 "kernel": "rollout_kernel<auto_reset>"}
     t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
@@ -148,6 +182,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "step_kernel<action, auto_reset>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BOARD_STEP * n},
+            "fused_rollout": fused,
             "mean_episodic_return": mean_return if episodes else None,
             "episodes": episodes,
         }

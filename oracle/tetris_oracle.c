@@ -342,12 +342,20 @@ int64_t to_bench_run(uint64_t seed, int64_t count, int L, int M, int64_t steps, 
     uint16_t* rows = (uint16_t*)malloc((size_t)count * TO_ROWS * sizeof(uint16_t));
     uint8_t* pcs = (uint8_t*)malloc((size_t)count * (size_t)(M + 1));
     uint8_t* act = (uint8_t*)malloc((size_t)count * (size_t)steps);
-    to_synth_boards(seed, 0, count, L, rows);
-    to_synth_pieces(seed, 0, count, M, pcs);
-    for (int64_t s = 0; s < steps; ++s) to_synth_actions(seed, 0, count, (uint64_t)s, act + s * count);
     if (threads < 1) threads = 1;
-    to_env** envs = (to_env**)calloc((size_t)threads, sizeof(to_env*));
     int64_t per = (count + threads - 1) / threads;
+    /* inputs are generated before the clock starts, one slice per thread */
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(static, 1)
+#endif
+    for (int t = 0; t < threads; ++t) {
+        int64_t lo = t * per, hi = lo + per > count ? count : lo + per;
+        if (hi <= lo) continue;
+        to_synth_boards(seed, lo, hi - lo, L, rows + lo * TO_ROWS);
+        to_synth_pieces(seed, lo, hi - lo, M, pcs + lo * (M + 1));
+        for (int64_t s = 0; s < steps; ++s) to_synth_actions(seed, lo, hi - lo, (uint64_t)s, act + s * count + lo);
+    }
+    to_env** envs = (to_env**)calloc((size_t)threads, sizeof(to_env*));
     for (int t = 0; t < threads; ++t) {
         int64_t lo = t * per, hi = lo + per > count ? count : lo + per;
         if (hi <= lo) continue;
