@@ -117,6 +117,11 @@ int tpl_get_state(tpl_env* env, uint16_t* rows, uint8_t* cur, uint8_t* nxt, uint
  * 200 cells row-major (y*10+x), one-hot current piece (7), one-hot next piece (7), L_rem, M_rem, terminal. */
 int tpl_expand_obs(tpl_env* env, void* out, int32_t dtype, void* stream);
 
+/* Policy head -> action for Model(217, 14) (model/train.py:26; the reference never decodes its 14 outputs):
+ * logits [n][14] of `dtype` (TPL_F32 / TPL_BF16); action[i] = argmax(logits[i][0:4]) * 10 + argmax(logits[i][4:14]),
+ * lowest index on ties. */
+int tpl_decode_actions(tpl_env* env, const void* logits, int32_t dtype, uint8_t* action, void* stream);
+
 /* Statistics over episodes finished since the last full reset, reduced on the device into
  * out[4] (device pointer, uint64): {episodes, sum of lines_cleared at finish, wins, top-outs}. */
 int tpl_get_stats(tpl_env* env, uint64_t* out, void* stream);

@@ -19,6 +19,8 @@ def __getattr__(name):
     if name in ("BatchedTetris", "Tetris", "OBS_DIM", "NUM_ACTIONS", "RUNNING", "WON", "LOST", "env"):
         env = importlib.import_module(__name__ + ".env")
         return env if name == "env" else getattr(env, name)
-    if name == "sharding":
-        return importlib.import_module(__name__ + ".sharding")
+    if name in ("sharding", "actor"):
+        return importlib.import_module(__name__ + "." + name)
+    if name in ("Actor", "PolicyMLP"):
+        return getattr(importlib.import_module(__name__ + ".actor"), name)
     raise AttributeError(name)

@@ -22,7 +22,7 @@ SYMBOLS = [
     "tpl_last_error", "tpl_version", "tpl_workspace_bytes", "tpl_pool_bytes", "tpl_create", "tpl_destroy",
     "tpl_set_options", "tpl_load_configs", "tpl_reset", "tpl_move", "tpl_step", "tpl_get_state",
     "tpl_expand_obs", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
-    "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout",
+    "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_decode_actions",
 ]
 
 TPL_U8, TPL_I32, TPL_I64 = 0, 1, 2
@@ -88,6 +88,7 @@ def lib() -> C.CDLL:
     L.tpl_rollout.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, vp]
     L.tpl_get_state.argtypes = [vp] * 9
     L.tpl_expand_obs.argtypes = [vp, vp, i32, vp]
+    L.tpl_decode_actions.argtypes = [vp, vp, i32, vp, vp]
     L.tpl_get_stats.argtypes = [vp, vp, vp]
     L.tpl_shape_info.argtypes = [i32, i32, C.POINTER(i32), C.POINTER(i32), vp, vp]
     L.tpl_state_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]

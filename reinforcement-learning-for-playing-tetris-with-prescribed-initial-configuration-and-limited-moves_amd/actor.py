@@ -1,0 +1,85 @@
+"""Actor loop for BASELINE config 5: obs -> policy -> action -> step, entirely on the device.
+
+The policy is this build's own MLP with the reference's sizes -- Linear 217-128-128-128-128-14 with ReLU
+(model/model.py:9-20 of the upstream repo, whose constructor does not run as written: SURVEY section 0).  The
+dense layers go through torch (hipBLASLt); the environment side (observation expand, action decode, step) is
+the HIP library.  One iteration is a fixed sequence of kernel launches on one stream, so it is captured once
+into a HIP graph and replayed.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .env import OBS_DIM, BatchedTetris
+
+
+class PolicyMLP(nn.Module):
+    """Model(217, 14): five Linear layers, ReLU between them (model/model.py:9-20)."""
+
+    def __init__(self, state_space_size: int = OBS_DIM, action_space_size: int = 14, hidden: int = 128):
+        super().__init__()
+        self.layer1 = nn.Linear(state_space_size, hidden)
+        self.layer2 = nn.Linear(hidden, hidden)
+        self.layer3 = nn.Linear(hidden, hidden)
+        self.layer4 = nn.Linear(hidden, hidden)
+        self.layer5 = nn.Linear(hidden, action_space_size)
+
+    def forward(self, x):
+        x = torch.relu(self.layer1(x))
+        x = torch.relu(self.layer2(x))
+        x = torch.relu(self.layer3(x))
+        x = torch.relu(self.layer4(x))
+        return self.layer5(x)
+
+
+class Actor:
+    """Greedy actor over a BatchedTetris: buffers are allocated once, the iteration is graph-captured."""
+
+    def __init__(self, env: BatchedTetris, model: nn.Module, dtype=torch.bfloat16, use_graph: bool = True):
+        self.env, self.dtype = env, dtype
+        self.model = model.to(device=env.device, dtype=dtype).eval()
+        n, d = env.num_envs, env.device
+        self.obs = torch.empty((n, OBS_DIM), dtype=dtype, device=d)
+        self.action = torch.empty(n, dtype=torch.uint8, device=d)
+        self.reward = torch.empty(n, dtype=torch.float32, device=d)
+        self.done = torch.empty(n, dtype=torch.uint8, device=d)
+        self._graph = None
+        self._use_graph = use_graph
+
+    @torch.no_grad()
+    def _iteration(self):
+        self.env.observe(out=self.obs)
+        logits = self.model(self.obs)
+        self.env.decode_actions(logits.contiguous(), out=self.action)
+        self.env.step_into(self.action, self.reward, self.done)
+
+    def _capture(self):
+        stream = torch.cuda.Stream(self.env.device)
+        stream.wait_stream(torch.cuda.current_stream(self.env.device))
+        with torch.cuda.stream(stream):
+            for _ in range(2):                       # warm up allocator / hipBLASLt heuristics off-graph
+                saved = self.env.snapshot()
+                self._iteration()
+                self.env.restore(saved)
+        torch.cuda.current_stream(self.env.device).wait_stream(stream)
+        torch.cuda.synchronize(self.env.device)
+        g = torch.cuda.CUDAGraph()
+        saved = self.env.snapshot()
+        with torch.cuda.graph(g):
+            self._iteration()
+        self.env.restore(saved)                      # capture does not execute, but keep the state untouched regardless
+        self._graph = g
+
+    def step(self):
+        """One obs -> action -> step iteration; results in self.action / self.reward / self.done."""
+        if self._use_graph:
+            if self._graph is None:
+                self._capture()
+            self._graph.replay()
+        else:
+            self._iteration()
+
+    def run(self, steps: int):
+        for _ in range(steps):
+            self.step()

@@ -431,6 +431,34 @@ __global__ __launch_bounds__(kBlock) void expand_obs_kernel(const uint4* plane_a
     }
 }
 
+// 14 policy outputs -> one action: argmax over the 4 rotation logits, argmax over the 10 location logits
+// (lowest index wins ties; NaN never wins), action = rot*10 + loc.  Model(217, 14): model/train.py:26.
+template <typename T>
+__device__ __forceinline__ float logit_f32(T v);
+template <> __device__ __forceinline__ float logit_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float logit_f32<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void decode_actions_kernel(const T* logits, int64_t n, uint8_t* action) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const T* row = logits + i * 14;
+    uint32_t rot = 0, loc = 0;
+    float best = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float v = logit_f32<T>(row[k]);
+        if (v > best) { best = v; rot = (uint32_t)k; }
+    }
+    best = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const float v = logit_f32<T>(row[4 + k]);
+        if (v > best) { best = v; loc = (uint32_t)k; }
+    }
+    action[i] = (uint8_t)(rot * 10u + loc);
+}
+
 __global__ void reduce_stats_kernel(const unsigned long long* shards, unsigned long long* out) {
     const int k = threadIdx.x;   // 4 threads
     unsigned long long s = 0;
@@ -731,6 +759,22 @@ int tpl_expand_obs(tpl_env* e, void* out, int32_t dtype, void* stream) {
                            e->n, (uint32_t)e->L, (uint32_t)e->M, (__hip_bfloat16*)out);
     else
         return fail(TPL_ERR_ARG, "unknown observation dtype %d", dtype);
+    TPL_HIP(hipGetLastError());
+    return TPL_OK;
+}
+
+int tpl_decode_actions(tpl_env* e, const void* logits, int32_t dtype, uint8_t* action, void* stream) {
+    if (!e) return fail(TPL_ERR_ARG, "env is null");
+    if (!logits || !action) return fail(TPL_ERR_ARG, "logits/action is null");
+    DeviceGuard guard(e->device);
+    const dim3 grid(blocks_for(e->n)), block(kBlock);
+    if (dtype == TPL_F32)
+        hipLaunchKernelGGL(decode_actions_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)logits, e->n, action);
+    else if (dtype == TPL_BF16)
+        hipLaunchKernelGGL(decode_actions_kernel<__hip_bfloat16>, grid, block, 0, (hipStream_t)stream,
+                           (const __hip_bfloat16*)logits, e->n, action);
+    else
+        return fail(TPL_ERR_ARG, "unknown logits dtype %d", dtype);
     TPL_HIP(hipGetLastError());
     return TPL_OK;
 }

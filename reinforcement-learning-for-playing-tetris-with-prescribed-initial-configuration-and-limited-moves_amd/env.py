@@ -213,6 +213,15 @@ class BatchedTetris:
         check(self._lib.tpl_expand_obs(self._h, _ptr(out), _OBS_CODES[out.dtype], self._stream()))
         return out
 
+    def decode_actions(self, logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[N, 14] policy outputs (f32 or bf16) -> uint8 actions: argmax of 4 rotation logits and 10 location logits."""
+        if logits.shape != (self.num_envs, 14) or not logits.is_contiguous():
+            raise ValueError(f"logits must be contiguous [{self.num_envs}, 14]")
+        if out is None:
+            out = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        check(self._lib.tpl_decode_actions(self._h, _ptr(logits), _OBS_CODES[logits.dtype], _ptr(out), self._stream()))
+        return out
+
     def packed_state(self) -> dict:
         """Everything get_state() and the public attributes expose, in the interchange layout (device tensors)."""
         n, d = self.num_envs, self.device
@@ -235,6 +244,13 @@ class BatchedTetris:
     lines_cleared = property(lambda self: self.packed_state()["lines"])
     moves_used = property(lambda self: self.packed_state()["moves"])
     state = property(lambda self: self.packed_state()["state"])
+
+    def snapshot(self) -> torch.Tensor:
+        """Copy of the whole resident state (boards, counters, windows, statistics)."""
+        return self._workspace.clone()
+
+    def restore(self, saved: torch.Tensor) -> None:
+        self._workspace.copy_(saved)
 
     def stats(self) -> dict:
         """Episodes finished since the last full reset: counts for the episodic-return mean (host sync)."""

@@ -334,6 +334,69 @@ def test_fused_rollout_equals_k_single_steps_and_the_oracle(T, oracle, auto):
         e.terminate()
 
 
+def _argmax_first(vals):
+    best, idx = -float("inf"), 0
+    for k, v in enumerate(vals):
+        if v > best:
+            best, idx = v, k
+    return idx
+
+
+def test_decode_actions(T):
+    import torch
+    n = 5000
+    env = T.BatchedTetris(5, 20, n)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    logits = torch.randn((n, 14), device="cuda", generator=g)
+    logits[::7, 1] = logits[::7, 0]                       # ties -> lowest index
+    logits[::5, 9] = logits[::5, 6] = 9.0
+    logits[3, 2] = float("nan")                           # NaN never wins
+    for t in (logits, logits.to(torch.bfloat16)):
+        host = t.float().cpu().tolist()
+        want = torch.tensor([_argmax_first(r[:4]) * 10 + _argmax_first(r[4:]) for r in host])
+        assert torch.equal(env.decode_actions(t.contiguous()).cpu().long(), want)
+    env.terminate()
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_actor_loop_graph_equals_eager_and_the_oracle(T, oracle, dtype):
+    """BASELINE config 5 in small: obs -> MLP -> action -> step on the device, graph-captured; the recorded
+    actions replayed through the oracle give the same rewards, dones and boards."""
+    import torch
+    L, M, n, seed, steps = 10, 40, 4096, 17, 45
+    torch.manual_seed(0)
+    model = T.PolicyMLP()
+    with torch.no_grad():
+        for prm in model.parameters():                     # default init gives a near-constant argmax; spread it
+            prm.normal_(0.0, 0.35)
+        model.layer1.weight[:, 214:] = 0.0                 # let cells and pieces, not the two big counters, decide
+    actors = []
+    for use_graph in (True, False):
+        env = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True)
+        rows, pieces = env.synthetic_configs(512)
+        env.load_configs(rows, pieces)
+        env.reset()
+        actors.append(T.Actor(env, model, dtype=getattr(torch, dtype), use_graph=use_graph))
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
+    cpu.set_options(auto_reset=True, assign_mode=0)
+    cpu.reset()
+    distinct = set()
+    for t in range(steps):
+        for a in actors:
+            a.step()
+        g, e = actors
+        assert torch.equal(g.action, e.action) and torch.equal(g.reward, e.reward) and torch.equal(g.done, e.done), t
+        r_c, d_c = cpu.step(_np(g.action))
+        assert np.array_equal(_np(g.reward), r_c) and np.array_equal(_np(g.done), d_c), t
+        distinct.update(np.unique(_np(g.action)).tolist())
+    assert len(distinct) > 8                               # the policy really depends on the observation
+    _assert_state_equal(_state(actors[0].env), cpu.get_state(), "actor")
+    assert actors[0].env.stats() == cpu.stats()
+    for a in actors:
+        a.env.terminate()
+
+
 def test_observation_matches_oracle(T, oracle):
     import torch
     L, M, n = 10, 40, 1000          # not a multiple of 64: exercises the ragged tail
