@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--pool", type=int, default=0, help="pool size per GPU (default: one config per board)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--actor-boards", type=int, default=262144, help="boards of the config-5 actor-loop side measurement (0 = skip)")
     ap.add_argument("--chunk", type=int, default=50, help="steps per launch of the fused-rollout side measurement (0 = skip)")
     args = ap.parse_args()
 
@@ -151,6 +152,32 @@ def main():
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
     elapsed = float(t_all.item())
 
+    # secondary figure: BASELINE configs[4] -- 262,144 boards driven by the policy MLP, obs -> action -> step on device
+    actor = None
+    if args.actor_boards > 0 and world == 1:
+        na = args.actor_boards
+        env.terminate()
+        del actions
+        aenv = T.BatchedTetris(L, M, na, device=dev, seed=args.seed, auto_reset=True, assign="hash")
+        rows, pieces = aenv.synthetic_configs(na)
+        aenv.load_configs(rows, pieces)
+        aenv.reset()
+        torch.manual_seed(0)
+        act = T.Actor(aenv, T.PolicyMLP(), dtype=torch.bfloat16, use_graph=True)
+        act.run(20)
+        torch.cuda.synchronize(dev)
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters = 300
+        a0.record()
+        act.run(iters)
+        a1.record()
+        torch.cuda.synchronize(dev)
+        ms = a0.elapsed_time(a1) / iters
+        actor = {"value": na / (ms * 1e-3), "unit": "env-steps/s", "boards": na, "ms_per_step": ms,
+                 "policy": "MLP 217-128-128-128-128-14 bf16 (random init), greedy", "graph": True}
+        aenv.terminate()
+        env = None
+
     if rank == 0:
         total_steps = float(n) * world * K
         achieved = ALGO_BYTES_PER_BOARD_STEP * n / (kernel_ms * 1e-3) / 1e9
@@ -183,13 +210,15 @@ def main():
                          "kernel": "step_kernel<action, auto_reset>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BOARD_STEP * n},
             "fused_rollout": fused,
+            "actor_loop": actor,
             "mean_episodic_return": mean_return if episodes else None,
             "episodes": episodes,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(L, M, args.seed)
         print(json.dumps(out), flush=True)
-    env.terminate()
+    if env is not None:
+        env.terminate()
     if world > 1:
         dist.destroy_process_group()
 
