@@ -137,6 +137,17 @@ int tpl_state_ptrs(tpl_env* env, void** plane_a, void** plane_b);
  * (64, 128, 256 or 512; default 256).  Results do not depend on them. */
 int tpl_set_tuning(tpl_env* env, int32_t boards_per_lane, int32_t block_threads);
 
+/* Replaces the carving generator behind Tetris.reset() (game/tetris.py:226-352 with RandomPieceGenerator :64-108
+ * and CheckpointManager :111-137; its worker process :473-479): produces `count` solvable prescribed
+ * configurations on `threads` host threads (0 = all cores).  HOST pointers: rows [count][20] uint16,
+ * pieces [count][M+1] uint8, and optionally the carved solution [count][M][2] (rotations, location) with
+ * solution_len [count] (the reference's debug `solution`, :155-156).  Decision k of configuration first+i is
+ * lo + hash(seed, 4, first+i, k) % (hi-lo+1), so the output does not depend on `threads`.  max_iters > 0 bounds
+ * the search loop of one configuration (the reference has no bound); 1 <= L <= 16. */
+int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count, int32_t threads,
+                         int64_t max_iters, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
+                         int32_t* solution_len);
+
 /* Synthetic workload of SURVEY 8(d), generated on the device from a counter-based hash
  * keyed by (seed, stream, global board index, counter); DESIGN.md states the function. */
 int tpl_synth_configs(tpl_env* env, uint64_t seed, int64_t first, int64_t count,

@@ -64,6 +64,12 @@ def lib():
         L.to_synth_boards.argtypes = [u64, i64, i64, i32, vp]
         L.to_synth_pieces.argtypes = [u64, i64, i64, i32, vp]
         L.to_synth_actions.argtypes = [u64, i64, i64, u64, vp]
+        L.to_carve.restype = i32
+        L.to_carve.argtypes = [vp, i32, i32, i32, i32]
+        L.to_generate_config_tape.restype = i64
+        L.to_generate_config_tape.argtypes = [i32, i32, vp, i64, C.POINTER(i64), vp, vp, vp, C.POINTER(i32)]
+        L.to_generate_config_seeded.restype = i64
+        L.to_generate_config_seeded.argtypes = [i32, i32, u64, u64, i64, vp, vp, vp, C.POINTER(i32)]
         L.to_board_hash.restype = u64
         L.to_board_hash.argtypes = [vp]
         L.to_bench_run.restype = i64
@@ -196,6 +202,32 @@ def synth_actions(seed, first, count, step):
     a = np.empty(count, np.uint8)
     lib().to_synth_actions(seed, first, count, step, _p(a))
     return a
+
+
+def carve(rows, piece, rotations, location, allow_partial):
+    """Tetris.carve on a copy of rows; returns (ok, rows_after)."""
+    r = np.ascontiguousarray(rows, dtype=np.uint16).copy()
+    ok = lib().to_carve(_p(r), piece, rotations, location, int(allow_partial))
+    return bool(ok), r
+
+
+def _gen_outputs(M):
+    return np.zeros(20, np.uint16), np.zeros(M + 1, np.uint8), np.zeros((M, 2), np.uint8), C.c_int32(0)
+
+
+def generate_config_tape(L, M, tape):
+    """The carving generator driven by a tape of (lo, hi, value) decisions recorded from the reference."""
+    tape = np.ascontiguousarray(tape, dtype=np.int32).reshape(-1, 3)
+    rows, pieces, sol, n = _gen_outputs(M)
+    used = C.c_int64(0)
+    it = lib().to_generate_config_tape(L, M, _p(tape), tape.shape[0], C.byref(used), _p(rows), _p(pieces), _p(sol), C.byref(n))
+    return it, used.value, rows, pieces, sol[: n.value]
+
+
+def generate_config_seeded(L, M, seed, index, max_iters=0):
+    rows, pieces, sol, n = _gen_outputs(M)
+    it = lib().to_generate_config_seeded(L, M, seed, index, max_iters, _p(rows), _p(pieces), _p(sol), C.byref(n))
+    return it, rows, pieces, sol[: n.value]
 
 
 def board_hash(rows):

@@ -330,6 +330,218 @@ void to_env_get_stats(const to_env* e, uint64_t out[4]) {
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Carving generator (game/tetris.py:64-137, 226-352), restated on uint16 rows.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* calculate_drop_deltas (:427-433): deltas[c] = top of board column location+c (20 if empty) - revtopo[c] */
+static void drop_deltas(const uint16_t* rows, int location, const to_shape* s, int* deltas) {
+    for (int c = 0; c < s->w; ++c) {
+        int top = TO_ROWS;
+        for (int r = 0; r < TO_ROWS; ++r)
+            if ((rows[r] >> (location + c)) & 1u) { top = r; break; }
+        deltas[c] = top - (int)s->revtopo[c];
+    }
+}
+
+static int min_delta(const int* d, int w, int* argmin) {
+    int best = d[0], at = 0;
+    for (int c = 1; c < w; ++c)
+        if (d[c] < best) { best = d[c]; at = c; }   /* np.argmin: first index of the minimum */
+    if (argmin) *argmin = at;
+    return best;
+}
+
+/* calculate_carve (:313-352) */
+static int calculate_carve(uint16_t* rows, int drop, int location, const to_shape* s, int allow_partial) {
+    /* :317-318 */
+    if (drop + s->h > TO_ROWS) return 0;
+    if (drop < 0) return 0;   /* the reference would wrap around with a negative slice start; not reachable for L <= 16 */
+    /* :321-329  without partial carving every piece cell must be filled on the board */
+    if (!allow_partial) {
+        for (int i = 0; i < s->h; ++i) {
+            uint16_t m = (uint16_t)((uint16_t)s->mask[i] << location);
+            if ((rows[drop + i] & m) != m) return 0;
+        }
+    }
+    /* :332-337  save the slice, carve */
+    uint16_t saved[4];
+    for (int i = 0; i < s->h; ++i) {
+        saved[i] = rows[drop + i];
+        rows[drop + i] &= (uint16_t)~((uint16_t)s->mask[i] << location);
+    }
+    /* :341-349  the piece dropped onto the carved board must land exactly where it was carved */
+    int d[4];
+    drop_deltas(rows, location, s, d);
+    int new_drop = min_delta(d, s->w, NULL) - 1;
+    if (new_drop != drop) {
+        for (int i = 0; i < s->h; ++i) rows[drop + i] = saved[i];
+        return 0;
+    }
+    return 1;
+}
+
+/* carve (:286-311) */
+int to_carve(uint16_t* rows, int piece, int rotations, int location, int allow_partial) {
+    to_shape s;
+    to_get_tetromino(piece, rotations, &s);
+    int d[4], at;
+    drop_deltas(rows, location, &s, d);
+    int drop = min_delta(d, s.w, &at) - 1;           /* :293-295 */
+    int push = (int)s.revtopo[at] + 1;               /* :298 */
+    drop += push;                                    /* :301 */
+    int increments = allow_partial ? s.h : 1;        /* :304 */
+    for (int k = 0; k < increments; ++k) {           /* :305-308 */
+        if (calculate_carve(rows, drop, location, &s, allow_partial)) return 1;
+        drop -= 1;
+    }
+    return 0;                                        /* :311 */
+}
+
+/* random.shuffle as CPython implements it, on top of randint: for i = n-1 .. 1: j = randint(0, i); swap */
+static void shuffle(uint8_t* a, int n, to_randint_fn randint, void* ctx) {
+    for (int i = n - 1; i >= 1; --i) {
+        int j = randint(ctx, 0, i);
+        uint8_t t = a[i]; a[i] = a[j]; a[j] = t;
+    }
+}
+
+typedef struct {
+    uint16_t rows[TO_ROWS];
+    uint8_t pieces[256];
+    uint8_t sol[256][2];
+    int n_pieces;
+} carve_checkpoint;
+
+int64_t to_generate_config(int L, int M, to_randint_fn randint, void* ctx, int64_t max_iters,
+                           uint16_t* rows, uint8_t* pieces_out, uint8_t* solution, int32_t* sol_len) {
+    /* game state: board, pieces (front = first to fall), solution (parallel to the carved prefix of pieces) */
+    uint8_t pieces[256];
+    uint8_t sol[256][2];
+    int n_pieces = 0;
+    /* RandomPieceGenerator (:64-108) */
+    uint8_t bag[7];
+    int n_bag = 0;
+    /* CheckpointManager (:111-137) */
+    carve_checkpoint* cps = NULL;
+    int n_cps = 0, cap_cps = 0;
+    int attempts = 0, checkpoint_uses = 0;
+    const int max_attempts = 40, max_checkpoint_uses = 10;
+
+    /* :228 */
+    for (int r = 0; r < TO_ROWS; ++r) rows[r] = (r >= TO_ROWS - L) ? TO_FULL_ROW : 0;
+
+    int64_t iters = 0;
+    /* :234  until at least two cells of the bottom row are carved */
+    while (__builtin_popcount(rows[TO_ROWS - 1]) > 8) {
+        if (max_iters > 0 && iters >= max_iters) { free(cps); return -1; }
+        ++iters;
+        /* :236  get_random_piece through the _regenerate wrapper (:71-86) */
+        int regenerated = 0;
+        if (n_bag == 0) {
+            for (int k = 0; k < 7; ++k) bag[k] = (uint8_t)k;
+            n_bag = 7;
+            regenerated = 1;
+        }
+        int idx = randint(ctx, 0, n_bag - 1);
+        int piece = bag[idx];
+        /* :239-247  a fresh bag marks a checkpoint */
+        if (regenerated) {
+            if (n_cps == cap_cps) {
+                cap_cps = cap_cps ? 2 * cap_cps : 8;
+                cps = (carve_checkpoint*)realloc(cps, (size_t)cap_cps * sizeof(carve_checkpoint));
+            }
+            carve_checkpoint* c = &cps[n_cps++];
+            memcpy(c->rows, rows, sizeof(c->rows));
+            memcpy(c->pieces, pieces, (size_t)n_pieces);
+            memcpy(c->sol, sol, (size_t)n_pieces * 2);
+            c->n_pieces = n_pieces;
+        }
+        /* :250-253 */
+        int rotations = randint(ctx, 0, 3);
+        to_shape s;
+        to_get_tetromino(piece, rotations, &s);
+        int location = randint(ctx, 0, TO_COLS - s.w);
+        /* :257-262 */
+        if (n_pieces < M && to_carve(rows, piece, rotations, location, n_pieces == 0)) {
+            memmove(pieces + 1, pieces, (size_t)n_pieces);
+            memmove(sol + 1, sol, (size_t)n_pieces * 2);
+            pieces[0] = (uint8_t)piece;
+            sol[0][0] = (uint8_t)rotations; sol[0][1] = (uint8_t)location;
+            ++n_pieces;
+            memmove(bag + idx, bag + idx + 1, (size_t)(n_bag - idx - 1));   /* delete_index (:88-89) */
+            --n_bag;
+        } else {
+            /* :268  add_attempt (:121-123) is only evaluated when the move limit has not been reached */
+            int reload = (n_pieces >= M);
+            if (!reload) { attempts += 1; reload = attempts > max_attempts; }
+            if (reload) {
+                /* load_checkpoint (:128-137) */
+                attempts = 0;
+                if (n_cps > 1 && checkpoint_uses > max_checkpoint_uses) { --n_cps; checkpoint_uses = 0; }
+                else checkpoint_uses += 1;
+                const carve_checkpoint* c = &cps[n_cps - 1];
+                memcpy(rows, c->rows, sizeof(c->rows));            /* :275-276 */
+                memcpy(pieces, c->pieces, (size_t)c->n_pieces);
+                memcpy(sol, c->sol, (size_t)c->n_pieces * 2);
+                n_pieces = c->n_pieces;
+                for (int k = 0; k < 7; ++k) bag[k] = (uint8_t)k;   /* :278 generate_pieces */
+                n_bag = 7;
+            }
+        }
+    }
+    free(cps);
+    if (sol_len) *sol_len = n_pieces;
+    if (solution) memcpy(solution, sol, (size_t)n_pieces * 2);
+    /* :281-284  pad with get_random_sequence(M - len + 1) (:95-102): the leftover bag is shuffled first */
+    if (n_pieces <= M) {
+        int need = M - n_pieces + 1;
+        while (need > 0) {
+            if (n_bag == 0) { for (int k = 0; k < 7; ++k) bag[k] = (uint8_t)k; n_bag = 7; }   /* _regenerate wrapper */
+            shuffle(bag, n_bag, randint, ctx);                                             /* :93 */
+            int take = need < 7 ? need : 7;                                                /* [:min(length - len, 7)] */
+            if (take > n_bag) take = n_bag;
+            memcpy(pieces + n_pieces, bag, (size_t)take);
+            n_pieces += take; need -= take;
+            n_bag = 0;                                                                     /* :100 */
+        }
+    }
+    memcpy(pieces_out, pieces, (size_t)(M + 1));
+    return iters;
+}
+
+typedef struct { const int32_t* tape; int64_t n, pos; int bad; } tape_ctx;
+
+static int32_t tape_randint(void* vctx, int32_t lo, int32_t hi) {
+    tape_ctx* t = (tape_ctx*)vctx;
+    if (t->pos >= t->n) { t->bad = 1; return lo; }
+    const int32_t* e = t->tape + 3 * t->pos++;
+    if (e[0] != lo || e[1] != hi) t->bad = 1;      /* the reference asked a different question here */
+    return e[2];
+}
+
+int64_t to_generate_config_tape(int L, int M, const int32_t* tape, int64_t n, int64_t* consumed,
+                                uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* sol_len) {
+    tape_ctx t = {tape, n, 0, 0};
+    int64_t it = to_generate_config(L, M, tape_randint, &t, 0, rows, pieces, solution, sol_len);
+    if (consumed) *consumed = t.pos;
+    return t.bad ? -2 : it;
+}
+
+typedef struct { uint64_t seed, index, counter; } seeded_ctx;
+
+static int32_t seeded_randint(void* vctx, int32_t lo, int32_t hi) {
+    seeded_ctx* c = (seeded_ctx*)vctx;
+    uint64_t h = to_rng(c->seed, 4, c->index, c->counter++);
+    return lo + (int32_t)(h % (uint64_t)(hi - lo + 1));
+}
+
+int64_t to_generate_config_seeded(int L, int M, uint64_t seed, uint64_t index, int64_t max_iters,
+                                  uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* sol_len) {
+    seeded_ctx c = {seed, index, 0};
+    return to_generate_config(L, M, seeded_randint, &c, max_iters, rows, pieces, solution, sol_len);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * cpu_baseline: the loop shape of game/performance_test.py:13-17 (move; reset when finished) over
  * `count` synthetic boards in lockstep, one contiguous slice per thread.
  * ---------------------------------------------------------------------------------------------- */

@@ -99,6 +99,29 @@ void to_synth_boards(uint64_t seed, int64_t first, int64_t count, int L, uint16_
 void to_synth_pieces(uint64_t seed, int64_t first, int64_t count, int M, uint8_t* pieces /*[count][M+1]*/);
 void to_synth_actions(uint64_t seed, int64_t first, int64_t count, uint64_t step, uint8_t* action /*[count]*/);
 
+/* ---- prescribed-configuration supply: the carving generator (game/tetris.py:64-137, 226-352) ---------------
+ * Random decisions come through a callback so that the same code can be driven (a) by a tape of the decisions
+ * the reference itself made (tests/golden/carving_*.npz -- pins the generator logic bit-exactly) or (b) by the
+ * counter-based generator that the product uses.  randint(ctx, lo, hi) returns a value in [lo, hi]. */
+typedef int32_t (*to_randint_fn)(void* ctx, int32_t lo, int32_t hi);
+
+/* Tetris.carve(piece, rotations, location, allow_partial) (game/tetris.py:286-311) on rows[20]; returns 1/0. */
+int to_carve(uint16_t* rows, int piece, int rotations, int location, int allow_partial);
+
+/* Tetris._generate_initial_config (game/tetris.py:226-284) for one game.  rows[20], pieces[M+1],
+ * solution[M][2] (rotations, location) and *sol_len are outputs.  Returns the number of loop iterations, or -1
+ * if max_iters was hit (the reference has no bound). */
+int64_t to_generate_config(int L, int M, to_randint_fn randint, void* ctx, int64_t max_iters,
+                           uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* sol_len);
+
+/* (a) tape-driven: tape = [n][3] int32 (lo, hi, value); returns iterations, -2 on a tape mismatch/underrun;
+ * *consumed = decisions used. */
+int64_t to_generate_config_tape(int L, int M, const int32_t* tape, int64_t n, int64_t* consumed,
+                                uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* sol_len);
+/* (b) counter-driven: decision k of configuration `index` is lo + to_rng(seed, 4, index, k) % (hi - lo + 1). */
+int64_t to_generate_config_seeded(int L, int M, uint64_t seed, uint64_t index, int64_t max_iters,
+                                  uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* sol_len);
+
 /* FNV-1a over the 20 rows (u16 units) -- per-step fingerprint used by the golden fixtures. */
 uint64_t to_board_hash(const uint16_t* rows);
 

@@ -14,15 +14,15 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_CSRC, "libtetris_piclim.so")
-_SOURCES = [os.path.join(_CSRC, "tetris_piclim.hip"), os.path.join(_CSRC, "tpl_device.h"),
-            os.path.join(_ROOT, "include", "tetris_piclim.h")]
+_UNITS = [os.path.join(_CSRC, "tetris_piclim.hip"), os.path.join(_CSRC, "carve_generator.hip")]
+_SOURCES = _UNITS + [os.path.join(_CSRC, "tpl_device.h"), os.path.join(_ROOT, "include", "tetris_piclim.h")]
 
 # entry points declared in include/tetris_piclim.h (tests check that the .so exports every one of them)
 SYMBOLS = [
     "tpl_last_error", "tpl_version", "tpl_workspace_bytes", "tpl_pool_bytes", "tpl_create", "tpl_destroy",
     "tpl_set_options", "tpl_load_configs", "tpl_reset", "tpl_move", "tpl_step", "tpl_get_state",
     "tpl_expand_obs", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
-    "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_decode_actions",
+    "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_decode_actions", "tpl_generate_configs",
 ]
 
 TPL_U8, TPL_I32, TPL_I64 = 0, 1, 2
@@ -47,7 +47,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in _SOURCES)
     if stale:
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-               "-o", LIB_PATH + ".tmp", _SOURCES[0]]
+               "-o", LIB_PATH + ".tmp"] + _UNITS
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
@@ -93,6 +93,7 @@ def lib() -> C.CDLL:
     L.tpl_shape_info.argtypes = [i32, i32, C.POINTER(i32), C.POINTER(i32), vp, vp]
     L.tpl_state_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.tpl_set_tuning.argtypes = [vp, i32, i32]
+    L.tpl_generate_configs.argtypes = [i32, i32, u64, i64, i64, i32, i64, vp, vp, vp, vp]
     L.tpl_synth_configs.argtypes = [vp, u64, i64, i64, vp, vp, vp]
     L.tpl_synth_actions.argtypes = [vp, u64, i64, i64, u64, vp, vp]
     for name in SYMBOLS:
@@ -106,6 +107,22 @@ def lib() -> C.CDLL:
 def check(status: int) -> None:
     if status != 0:
         raise TplError(f"tetris_piclim status {status}: {lib().tpl_last_error().decode()}")
+
+
+def generate_configs(L: int, M: int, count: int, seed: int = 0, first: int = 0, threads: int = 0,
+                     max_iters: int = 0, with_solutions: bool = False):
+    """Carved (solvable) prescribed configurations, produced on the host cores (game/tetris.py:226-352).
+
+    Returns (rows uint16 [count, 20], pieces uint8 [count, M+1]) and, with_solutions, also
+    (solution uint8 [count, M, 2], solution_len int32 [count])."""
+    import numpy as np
+    rows = np.empty((count, 20), np.uint16)
+    pieces = np.empty((count, M + 1), np.uint8)
+    sol = np.zeros((count, M, 2), np.uint8) if with_solutions else None
+    sol_len = np.zeros(count, np.int32) if with_solutions else None
+    ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    check(lib().tpl_generate_configs(L, M, seed, first, count, threads, max_iters, ptr(rows), ptr(pieces), ptr(sol), ptr(sol_len)))
+    return (rows, pieces, sol, sol_len) if with_solutions else (rows, pieces)
 
 
 def shape_info(piece: int, rotations: int):

@@ -1,0 +1,197 @@
+// carve_generator.hip -- supply of prescribed initial configurations: the reference's carving generator
+// (game/tetris.py:64-137 RandomPieceGenerator/CheckpointManager, :226-284 _generate_initial_config, :286-352
+// carve/calculate_carve) as a multi-threaded native producer on the host cores.  Host code only: the search is
+// serial with backtracking per configuration, and configurations are independent, so one configuration per
+// thread task fills a pool of a million entries in about a second on the GPU box's cores.
+//
+// The board is kept in the same column form as on the device (ten 20-bit words, bit r = row r), with the same
+// encoded shape table (tpl_device.h), so a column's top is one count-trailing-zeros and a carve is one AND per
+// piece column.  Random decisions are counter-based: decision k of configuration g is
+// lo + rng(seed, 4, g, k) % (hi - lo + 1), independent of the thread count.
+#include "../../include/tetris_piclim.h"
+#include "tpl_device.h"
+
+#include <atomic>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace tpl {
+
+extern int fail_msg(int code, const char* fmt, ...);
+
+namespace {
+
+struct Decisions {
+    uint64_t seed, index, counter = 0;
+    int randint(int lo, int hi) { return lo + (int)(rng(seed, 4, index, counter++) % (uint64_t)(hi - lo + 1)); }
+};
+
+struct Shape {
+    int h, w;
+    uint32_t col[4];   // column c of the piece as a bit-per-row pattern
+    int revtopo[4];
+};
+
+inline Shape shape_of(int piece, int rotations) {
+    const ShapeWord sw = kShapeTableHost[piece * 4 + (rotations & 3)];   // get_tetromino (:60-61)
+    Shape s;
+    s.w = (int)((sw.x >> 16) & 7u);
+    s.h = (int)((sw.x >> 19) & 7u);
+    for (int c = 0; c < 4; ++c) {
+        s.col[c] = (sw.x >> (4 * c)) & 0xFu;
+        s.revtopo[c] = c < s.w ? 3 - (int)((sw.y >> (8 * c)) & 0xFFu) : 0;
+    }
+    return s;
+}
+
+struct Game {
+    uint32_t col[kCols];
+    uint8_t pieces[256];
+    uint8_t sol[256][2];
+    int n = 0;
+};
+
+// calculate_drop_deltas + calculate_drop (:424-433): returns drop, and the first column that attains the minimum
+inline int drop_of(const uint32_t* col, int loc, const Shape& s, int* argmin) {
+    int best = 1 << 20, at = 0;
+    for (int c = 0; c < s.w; ++c) {
+        const int top = __builtin_ctz(col[loc + c] | (1u << kRows));
+        const int d = top - s.revtopo[c];
+        if (d < best) { best = d; at = c; }
+    }
+    if (argmin) *argmin = at;
+    return best - 1;
+}
+
+// calculate_carve (:313-352)
+inline bool try_carve(uint32_t* col, int drop, int loc, const Shape& s, bool allow_partial) {
+    if (drop + s.h > kRows || drop < 0) return false;                       // :317-318
+    if (!allow_partial)                                                     // :321-329 every piece cell is filled
+        for (int c = 0; c < s.w; ++c)
+            if ((col[loc + c] & (s.col[c] << drop)) != (s.col[c] << drop)) return false;
+    uint32_t saved[4];
+    for (int c = 0; c < s.w; ++c) {                                         // :332-337
+        saved[c] = col[loc + c];
+        col[loc + c] &= ~(s.col[c] << drop);
+    }
+    if (drop_of(col, loc, s, nullptr) != drop) {                            // :341-349 must land where it was carved
+        for (int c = 0; c < s.w; ++c) col[loc + c] = saved[c];
+        return false;
+    }
+    return true;
+}
+
+// carve (:286-311)
+inline bool carve(uint32_t* col, int piece, int rotations, int loc, bool allow_partial) {
+    const Shape s = shape_of(piece, rotations);
+    int at;
+    int drop = drop_of(col, loc, s, &at);
+    drop += s.revtopo[at] + 1;                                              // :298-301 push the piece into the stack
+    const int tries = allow_partial ? s.h : 1;                              // :304
+    for (int k = 0; k < tries; ++k, --drop)
+        if (try_carve(col, drop, loc, s, allow_partial)) return true;
+    return false;
+}
+
+// _generate_initial_config (:226-284) for one configuration.  Returns false if max_iters (> 0) was reached.
+bool generate_one(int L, int M, uint64_t seed, uint64_t index, int64_t max_iters, uint16_t* rows_out,
+                  uint8_t* pieces_out, uint8_t* sol_out, int32_t* sol_len) {
+    Decisions rnd{seed, index};
+    Game g;
+    const uint32_t filled = L >= kRows ? kColMask : (((1u << L) - 1u) << (kRows - L));
+    for (int c = 0; c < kCols; ++c) g.col[c] = filled;                      // :228 L full rows
+    uint8_t bag[7];
+    int n_bag = 0;
+    // CheckpointManager (:111-137).  A checkpoint is added only when a fresh bag is opened, i.e. after at least
+    // seven successful carves on top of the previous one (or a reload), so M/7 + 2 entries always suffice.
+    std::vector<Game> checkpoints;
+    checkpoints.reserve((size_t)M / 7 + 3);
+    int attempts = 0, uses = 0;
+    int64_t iters = 0;
+
+    auto bottom_cells = [&] { int k = 0; for (int c = 0; c < kCols; ++c) k += (g.col[c] >> (kRows - 1)) & 1u; return k; };
+    while (bottom_cells() > 8) {                                            // :234
+        if (max_iters > 0 && iters++ >= max_iters) return false;
+        bool fresh_bag = false;                                             // _regenerate (:71-81)
+        if (n_bag == 0) { for (int k = 0; k < 7; ++k) bag[k] = (uint8_t)k; n_bag = 7; fresh_bag = true; }
+        const int idx = rnd.randint(0, n_bag - 1);                          // :85
+        const int piece = bag[idx];
+        if (fresh_bag) checkpoints.push_back(g);                            // :239-247
+        const int rotations = rnd.randint(0, 3);                            // :250
+        const int width = shape_of(piece, rotations).w;
+        const int loc = rnd.randint(0, kCols - width);                      // :253
+        if (g.n < M && carve(g.col, piece, rotations, loc, g.n == 0)) {     // :257
+            std::memmove(g.pieces + 1, g.pieces, (size_t)g.n);              // insert(0, ...) (:258-260)
+            std::memmove(g.sol + 1, g.sol, (size_t)g.n * 2);
+            g.pieces[0] = (uint8_t)piece;
+            g.sol[0][0] = (uint8_t)rotations; g.sol[0][1] = (uint8_t)loc;
+            ++g.n;
+            std::memmove(bag + idx, bag + idx + 1, (size_t)(n_bag - idx - 1));   // delete_index (:262)
+            --n_bag;
+        } else if (g.n >= M || ++attempts > 40) {                           // :268, add_attempt (:121-123)
+            attempts = 0;                                                   // load_checkpoint (:128-137)
+            if (checkpoints.size() > 1 && uses > 10) { checkpoints.pop_back(); uses = 0; }
+            else ++uses;
+            g = checkpoints.back();                                         // :275-276
+            for (int k = 0; k < 7; ++k) bag[k] = (uint8_t)k;                // :278
+            n_bag = 7;
+        }
+    }
+    if (sol_len) *sol_len = g.n;
+    if (sol_out) std::memcpy(sol_out, g.sol, (size_t)g.n * 2);
+    int need = M - g.n + 1;                                                 // :281-284 pad to M+1 pieces
+    while (need > 0) {                                                      // get_random_sequence (:95-102)
+        if (n_bag == 0) { for (int k = 0; k < 7; ++k) bag[k] = (uint8_t)k; n_bag = 7; }
+        for (int i = n_bag - 1; i >= 1; --i) {                              // random.shuffle (:93)
+            const int j = rnd.randint(0, i);
+            const uint8_t t = bag[i]; bag[i] = bag[j]; bag[j] = t;
+        }
+        const int take = need < n_bag ? need : n_bag;
+        std::memcpy(g.pieces + g.n, bag, (size_t)take);
+        g.n += take; need -= take;
+        n_bag = 0;                                                          // :100
+    }
+    std::memcpy(pieces_out, g.pieces, (size_t)(M + 1));
+    for (int r = 0; r < kRows; ++r) {                                       // columns -> interchange rows
+        uint32_t v = 0;
+        for (int c = 0; c < kCols; ++c) v |= ((g.col[c] >> r) & 1u) << c;
+        rows_out[r] = (uint16_t)v;
+    }
+    return true;
+}
+
+}  // namespace
+}  // namespace tpl
+
+extern "C" int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count, int32_t threads,
+                                    int64_t max_iters, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
+                                    int32_t* solution_len) {
+    using namespace tpl;
+    if (L < 1 || L > 16) return fail_msg(TPL_ERR_ARG, "carving needs 1 <= L <= 16 (got %d)", L);
+    if (M < 1 || M > 254) return fail_msg(TPL_ERR_ARG, "M=%d out of range [1, 254]", M);
+    if (count < 1 || first < 0 || !rows || !pieces) return fail_msg(TPL_ERR_ARG, "bad count/first/output pointers");
+    if (threads < 1) threads = (int32_t)std::thread::hardware_concurrency();
+    if (threads < 1) threads = 1;
+    if ((int64_t)threads > count) threads = (int32_t)count;
+    std::atomic<int64_t> next{0};
+    std::atomic<int64_t> failed{-1};
+    auto work = [&] {
+        for (;;) {
+            const int64_t k = next.fetch_add(1, std::memory_order_relaxed);
+            if (k >= count) return;
+            const bool ok = generate_one(L, M, seed, (uint64_t)(first + k), max_iters, rows + k * kRows,
+                                         pieces + k * (M + 1), solution ? solution + k * (int64_t)M * 2 : nullptr,
+                                         solution_len ? solution_len + k : nullptr);
+            if (!ok) failed.store(k, std::memory_order_relaxed);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+    if (failed.load() >= 0)
+        return fail_msg(TPL_ERR_STATE, "configuration %lld did not finish within %lld iterations",
+                        (long long)(first + failed.load()), (long long)max_iters);
+    return TPL_OK;
+}

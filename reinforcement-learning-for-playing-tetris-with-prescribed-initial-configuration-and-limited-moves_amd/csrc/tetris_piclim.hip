@@ -56,6 +56,15 @@ static int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// same, for the other translation units of the library
+int fail_msg(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
 #define TPL_HIP(call)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (call);                                                                         \

@@ -1,0 +1,101 @@
+"""Prescribed-configuration supply: the carving generator.
+
+CPU part: the oracle's generator is pinned to the reference by replaying the reference's own random decisions
+(tests/golden/carving_*.npz: tapes recorded from the imported reference); the product's native generator
+(host C++, in the C-ABI library) must then equal the oracle's seeded form bit for bit, for any thread count.
+GPU part: every generated configuration, replayed with its recorded solution, ends in a win on the device --
+the reference's own test_carving_invertability (game/main.py:49-57)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+@pytest.mark.parametrize("name", ["carving_L5_M20.npz", "carving_L10_M40.npz", "carving_L15_M40.npz"])
+def test_oracle_generator_reproduces_the_reference_from_its_decision_tape(oracle, name):
+    f = load_golden(name)
+    L, M = int(f["L"]), int(f["M"])
+    for k in range(f["rows"].shape[0]):
+        tape = f["tape"][f["offsets"][k]:f["offsets"][k + 1]].astype(np.int32)
+        iters, used, rows, pieces, sol = oracle.generate_config_tape(L, M, tape)
+        assert iters >= 0, "the restatement asked a different random question than the reference"
+        assert used == len(tape)
+        assert np.array_equal(rows, f["rows"][k]) and np.array_equal(pieces, f["pieces"][k])
+        assert np.array_equal(sol, f["sol"][k, : f["sol_len"][k]])
+
+
+def test_oracle_carve_single_steps(oracle):
+    """carve() against states the reference went through: re-carving a recorded solution from L full rows
+    reproduces the board (the reference's test_carving_repeatability, game/main.py:32-47)."""
+    f = load_golden("carving_L10_M40.npz")
+    L = int(f["L"])
+    for k in range(f["rows"].shape[0]):
+        rows = np.array([0x3FF if r >= 20 - L else 0 for r in range(20)], np.uint16)
+        n = int(f["sol_len"][k])
+        for i in range(n - 1, -1, -1):
+            ok, rows = oracle.carve(rows, int(f["pieces"][k, i]), int(f["sol"][k, i, 0]), int(f["sol"][k, i, 1]), i == n - 1)
+            assert ok
+        assert np.array_equal(rows, f["rows"][k])
+
+
+@pytest.mark.parametrize("L,M,n", [(5, 20, 300), (10, 40, 120), (15, 40, 4), (1, 1, 50), (3, 254, 20)])
+def test_native_generator_equals_oracle_and_configs_are_solvable(oracle, L, M, n):
+    import tetris_piclim as T
+    rows, pieces, sol, sol_len = T.generate_configs(L, M, n, seed=7, first=11, threads=3, with_solutions=True)
+    rows1, pieces1 = T.generate_configs(L, M, n, seed=7, first=11, threads=1)
+    assert np.array_equal(rows, rows1) and np.array_equal(pieces, pieces1)          # thread-count independent
+    assert pieces.max() <= 6 and np.all(rows < 1024)
+    for k in range(n):
+        it, r, p, s = oracle.generate_config_seeded(L, M, 7, 11 + k)
+        assert it >= 0
+        assert np.array_equal(r, rows[k]) and np.array_equal(p, pieces[k]) and np.array_equal(s, sol[k, : sol_len[k]])
+        # solvable by construction: replaying the solution wins (oracle's move, itself pinned to the reference)
+        g = oracle.Game(L, M, rows[k], pieces[k])
+        for rot, loc in sol[k, : sol_len[k]]:
+            assert g.state == 0
+            g.move(int(rot), int(loc))
+        assert g.state == 1 and g.lines_cleared >= L
+        assert np.all(pieces[k, : sol_len[k]] < 7) and 1 <= sol_len[k] <= M
+
+
+def test_native_generator_statistics_match_the_reference_generator():
+    """Same algorithm, different random stream: the distribution of solution lengths must look like the
+    reference's (fixtures: 64 games at L=5, 32 at L=10)."""
+    import tetris_piclim as T
+    for name, n in (("carving_L5_M20.npz", 4000), ("carving_L10_M40.npz", 2000)):
+        f = load_golden(name)
+        L, M = int(f["L"]), int(f["M"])
+        _, _, _, sol_len = T.generate_configs(L, M, n, seed=1, with_solutions=True)
+        ref = f["sol_len"].astype(float)
+        se = ref.std() / np.sqrt(len(ref)) + sol_len.std() / np.sqrt(n)
+        assert abs(sol_len.mean() - ref.mean()) < 4 * se + 0.5, (name, sol_len.mean(), ref.mean())
+
+
+def test_native_generator_argument_errors():
+    import tetris_piclim as T
+    with pytest.raises(T.TplError):
+        T.generate_configs(17, 40, 1)
+    with pytest.raises(T.TplError):
+        T.generate_configs(5, 0, 1)
+    with pytest.raises(T.TplError):
+        T.generate_configs(10, 40, 2, max_iters=3)        # cannot finish in three iterations
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,M,n", [(5, 20, 20000), (10, 40, 8192)])
+def test_generated_pool_replays_to_a_win_on_the_gpu(L, M, n):
+    import torch
+    import tetris_piclim as T
+    rows, pieces, sol, sol_len = T.generate_configs(L, M, n, seed=2, with_solutions=True)
+    env = T.BatchedTetris(L, M, n, assign="sequential", config_pool=(rows, pieces))
+    env.reset()
+    for t in range(int(sol_len.max())):
+        active = t < sol_len
+        env.move(np.where(active, sol[:, t, 0], 0).astype(np.uint8), np.where(active, sol[:, t, 1], 0).astype(np.uint8))
+        s = env.packed_state()
+        still = torch.from_numpy(t + 1 < sol_len).to(env.device)
+        assert bool(((s["state"] == 0) == still).all()), t       # running exactly until the last solution move
+    s = env.packed_state()
+    assert bool((s["state"] == T.WON).all()) and bool((s["lines"] >= L).all())
+    assert torch.equal(s["moves"].cpu(), torch.from_numpy(sol_len.astype(np.uint8)))
+    env.terminate()
