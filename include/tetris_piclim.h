@@ -122,6 +122,20 @@ int tpl_expand_obs(tpl_env* env, void* out, int32_t dtype, void* stream);
  * lowest index on ties. */
 int tpl_decode_actions(tpl_env* env, const void* logits, int32_t dtype, uint8_t* action, void* stream);
 
+/* ---- fused policy: observation -> Model(217, 14) -> action in one kernel (model/model.py:9-20, train.py:26) ----
+ * tpl_policy_pack (host): the ten parameter arrays of the five Linear layers, float32, torch layout
+ * (weight [out][in] row-major, bias [out]; sizes 128x217, 128x128 x3, 14x128) -> an image of
+ * tpl_policy_image_bytes() bytes in HOST memory `image`; copy it to the device (16-byte aligned) once.
+ * Weights are rounded to bf16 (nearest even), biases stay float32.  W1's columns are in the observation order of
+ * tpl_expand_obs.
+ * tpl_policy_act: for every board, logits = MLP(observation) with bf16 operands, float32 accumulation and bf16
+ * activations between layers, on the matrix cores; action = argmax(logits[0:4])*10 + argmax(logits[4:14]) as
+ * tpl_decode_actions.  `logits` ([n][14] float32) is optional.  The observation is never written to memory. */
+size_t tpl_policy_image_bytes(void);
+int tpl_policy_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                    const float* b3, const float* w4, const float* b4, const float* w5, const float* b5, void* image);
+int tpl_policy_act(tpl_env* env, const void* image, uint8_t* action, float* logits, void* stream);
+
 /* Statistics over episodes finished since the last full reset, reduced on the device into
  * out[4] (device pointer, uint64): {episodes, sum of lines_cleared at finish, wins, top-outs}. */
 int tpl_get_stats(tpl_env* env, uint64_t* out, void* stream);

@@ -14,8 +14,9 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_CSRC, "libtetris_piclim.so")
-_UNITS = [os.path.join(_CSRC, "tetris_piclim.hip"), os.path.join(_CSRC, "carve_generator.hip")]
-_SOURCES = _UNITS + [os.path.join(_CSRC, "tpl_device.h"), os.path.join(_ROOT, "include", "tetris_piclim.h")]
+_UNITS = [os.path.join(_CSRC, f) for f in ("tetris_piclim.hip", "carve_generator.hip", "policy_mlp.hip")]
+_SOURCES = _UNITS + [os.path.join(_CSRC, "tpl_device.h"), os.path.join(_CSRC, "tpl_internal.h"),
+                     os.path.join(_ROOT, "include", "tetris_piclim.h")]
 
 # entry points declared in include/tetris_piclim.h (tests check that the .so exports every one of them)
 SYMBOLS = [
@@ -23,6 +24,7 @@ SYMBOLS = [
     "tpl_set_options", "tpl_load_configs", "tpl_reset", "tpl_move", "tpl_step", "tpl_get_state",
     "tpl_expand_obs", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
     "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_decode_actions", "tpl_generate_configs",
+    "tpl_policy_image_bytes", "tpl_policy_pack", "tpl_policy_act",
 ]
 
 TPL_U8, TPL_I32, TPL_I64 = 0, 1, 2
@@ -89,6 +91,10 @@ def lib() -> C.CDLL:
     L.tpl_get_state.argtypes = [vp] * 9
     L.tpl_expand_obs.argtypes = [vp, vp, i32, vp]
     L.tpl_decode_actions.argtypes = [vp, vp, i32, vp, vp]
+    L.tpl_policy_image_bytes.restype = sz
+    L.tpl_policy_image_bytes.argtypes = []
+    L.tpl_policy_pack.argtypes = [vp] * 11
+    L.tpl_policy_act.argtypes = [vp, vp, vp, vp, vp]
     L.tpl_get_stats.argtypes = [vp, vp, vp]
     L.tpl_shape_info.argtypes = [i32, i32, C.POINTER(i32), C.POINTER(i32), vp, vp]
     L.tpl_state_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
@@ -123,6 +129,21 @@ def generate_configs(L: int, M: int, count: int, seed: int = 0, first: int = 0, 
     ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
     check(lib().tpl_generate_configs(L, M, seed, first, count, threads, max_iters, ptr(rows), ptr(pieces), ptr(sol), ptr(sol_len)))
     return (rows, pieces, sol, sol_len) if with_solutions else (rows, pieces)
+
+
+def pack_policy(params):
+    """Five (weight, bias) pairs of Model(217, 14) (float32 numpy, torch layout) -> packed image (numpy uint8)."""
+    import numpy as np
+    flat = []
+    for w, b in params:
+        flat += [np.ascontiguousarray(w, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)]
+    shapes = [a.shape for a in flat]
+    want = [(128, 217), (128,), (128, 128), (128,), (128, 128), (128,), (128, 128), (128,), (14, 128), (14,)]
+    if shapes != want:
+        raise ValueError(f"policy parameters must have shapes {want}, got {shapes}")
+    image = np.empty(lib().tpl_policy_image_bytes(), np.uint8)
+    check(lib().tpl_policy_pack(*[a.ctypes.data_as(C.c_void_p) for a in flat], image.ctypes.data_as(C.c_void_p)))
+    return image
 
 
 def shape_info(piece: int, rotations: int):

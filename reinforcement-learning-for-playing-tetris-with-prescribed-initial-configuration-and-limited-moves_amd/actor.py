@@ -33,11 +33,24 @@ class PolicyMLP(nn.Module):
         return self.layer5(x)
 
 
-class Actor:
-    """Greedy actor over a BatchedTetris: buffers are allocated once, the iteration is graph-captured."""
+def policy_image(model: nn.Module, device) -> torch.Tensor:
+    """The packed LDS image of a PolicyMLP for the fused kernel (weights rounded to bf16), on `device`."""
+    from ._lib import pack_policy
+    layers = [model.layer1, model.layer2, model.layer3, model.layer4, model.layer5]
+    params = [(l.weight.detach().float().cpu().numpy(), l.bias.detach().float().cpu().numpy()) for l in layers]
+    return torch.from_numpy(pack_policy(params)).to(device)
 
-    def __init__(self, env: BatchedTetris, model: nn.Module, dtype=torch.bfloat16, use_graph: bool = True):
-        self.env, self.dtype = env, dtype
+
+class Actor:
+    """Greedy actor over a BatchedTetris: buffers are allocated once, the iteration is graph-captured.
+
+    fused=False: observation kernel -> torch Linear layers -> decode kernel -> step kernel.
+    fused=True:  one MFMA kernel from the 32-B board state to the action (csrc/policy_mlp.hip) -> step kernel."""
+
+    def __init__(self, env: BatchedTetris, model: nn.Module, dtype=torch.bfloat16, use_graph: bool = True,
+                 fused: bool = False):
+        self.env, self.dtype, self.fused = env, dtype, fused
+        self.image = policy_image(model, env.device) if fused else None
         self.model = model.to(device=env.device, dtype=dtype).eval()
         n, d = env.num_envs, env.device
         self.obs = torch.empty((n, OBS_DIM), dtype=dtype, device=d)
@@ -49,6 +62,10 @@ class Actor:
 
     @torch.no_grad()
     def _iteration(self):
+        if self.fused:
+            self.env.policy_act(self.image, out=self.action)
+            self.env.step_into(self.action, self.reward, self.done)
+            return
         self.env.observe(out=self.obs)
         logits = self.model(self.obs)
         self.env.decode_actions(logits.contiguous(), out=self.action)

@@ -8,8 +8,7 @@
 // encoded shape table (tpl_device.h), so a column's top is one count-trailing-zeros and a carve is one AND per
 // piece column.  Random decisions are counter-based: decision k of configuration g is
 // lo + rng(seed, 4, g, k) % (hi - lo + 1), independent of the thread count.
-#include "../../include/tetris_piclim.h"
-#include "tpl_device.h"
+#include "tpl_internal.h"
 
 #include <atomic>
 #include <cstring>
@@ -17,8 +16,6 @@
 #include <vector>
 
 namespace tpl {
-
-extern int fail_msg(int code, const char* fmt, ...);
 
 namespace {
 

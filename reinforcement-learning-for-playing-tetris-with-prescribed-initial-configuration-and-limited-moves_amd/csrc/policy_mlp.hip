@@ -1,0 +1,345 @@
+// policy_mlp.hip -- obs -> MLP -> action in ONE kernel (BASELINE configs[4]).
+//
+// Policy: Model(217, 14) of the reference (model/model.py:9-20, model/train.py:26): Linear 217-128, 128-128,
+// 128-128, 128-128, 128-14 with ReLU between them.  This is the only GEMM-shaped work on the path, so it runs
+// on the matrix cores: v_mfma_f32_32x32x16_bf16, bf16 operands, f32 accumulation, activations rounded to bf16
+// between layers (what a bf16 torch module does).
+//
+// Everything is computed TRANSPOSED: boards run along the MFMA's N dimension (the lane), features along M/K.
+//   H_{l+1}^T [out x boards] = W_{l+1} [out x in] . H_l^T [in x boards]
+// With that orientation the 32x32 accumulator tile of one layer IS the B operand of the next (its column is on
+// the lane, its rows are the next product's k): registers 8s..8s+7 of a tile, converted pairwise to bf16, are the
+// fragment of k-step s -- no LDS round trip, no lane movement.  The k order inside such a fragment is permuted
+// (element j of lane half h is row 16s + 8(j>>2) + 4h + (j&3)); the weights are pre-packed on the host in the
+// same permuted order, lane-major, so an A fragment is one conflict-free ds_read_b128.
+//
+// All weights (158 KB of bf16 + 2 KB of f32 biases) stay resident in the CU's 160 KB LDS; a 256-thread workgroup
+// (one wave per SIMD) loads them once and then loops over board tiles.  The observation is never materialised:
+// each lane turns its board's 32-B state into the layer-1 B fragments directly (cells are 0/1, so a 4-bit
+// nibble becomes two packed bf16 registers with two multiplies).
+//
+// Internal feature order of layer 1 (the packer permutes W1's columns, so callers keep the standard order of
+// tpl_expand_obs): k = 20*x + y for the cell in row y, column x (that is how the state stores the board), then
+// the 17 extras in their standard positions 200..216, then 7 zero pads.
+#include "tpl_internal.h"
+
+#include <cstring>
+#include <vector>
+
+namespace tpl {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+constexpr int kHidden = 128;
+constexpr int kObs = 217;
+constexpr int kOut = 14;
+constexpr int kKs1 = 14;                         // k-steps of layer 1: 224 = 217 padded to a multiple of 16
+constexpr int kKsH = 8;                          // k-steps of a hidden layer: 128 / 16
+constexpr int kMt = 4;                           // 32-row output tiles of a 128-wide layer
+
+// byte offsets inside the packed image
+constexpr int kOffW1 = 0;
+constexpr int kOffW2 = kOffW1 + kMt * kKs1 * 1024;             // 57344
+constexpr int kOffW3 = kOffW2 + kMt * kKsH * 1024;
+constexpr int kOffW4 = kOffW3 + kMt * kKsH * 1024;
+constexpr int kOffW5 = kOffW4 + kMt * kKsH * 1024;             // 155648
+constexpr int kOffB = kOffW5 + kKsH * 512;                     // 159744: biases f32: 4 x 128, then 16
+constexpr int kImageBytes = kOffB + (4 * kHidden + 16) * 4;    // 161856 <= 163840
+static_assert(kImageBytes <= 160 * 1024, "policy image must fit the CU's LDS");
+static_assert(kImageBytes % 16 == 0, "image is copied in 16-byte pieces");
+
+// ---- host side: packing ----------------------------------------------------------------------------------
+static inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);   // NaN stays NaN
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+// k inside a fragment: element j of lane half h in k-step s
+static inline int frag_k(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// internal layer-1 feature index -> standard observation index (tpl_expand_obs order), or -1 for a pad
+static inline int std_feature(int k) {
+    if (k < 200) return (k % 20) * 10 + (k / 20);
+    return k < kObs ? k : -1;
+}
+
+}  // namespace tpl
+
+using namespace tpl;
+
+extern "C" size_t tpl_policy_image_bytes(void) { return (size_t)kImageBytes; }
+
+extern "C" int tpl_policy_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                               const float* b3, const float* w4, const float* b4, const float* w5, const float* b5,
+                               void* image) {
+    if (!w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !w4 || !b4 || !w5 || !b5 || !image)
+        return fail_msg(TPL_ERR_ARG, "tpl_policy_pack: null pointer");
+    std::vector<uint8_t> img((size_t)kImageBytes, 0);
+    uint16_t* p = (uint16_t*)img.data();
+    auto pack_layer = [&](int off, const float* w, int in, int ks, bool first) {
+        for (int m = 0; m < kMt; ++m)
+            for (int s = 0; s < ks; ++s)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = lane & 31, h = lane >> 5;
+                        int k = frag_k(s, h, j);
+                        if (first) k = std_feature(k);
+                        const float v = (k >= 0 && k < in) ? w[(size_t)(32 * m + r) * in + k] : 0.0f;
+                        p[off / 2 + (((m * ks + s) * 64 + lane) * 8 + j)] = bf16_rne(v);
+                    }
+    };
+    pack_layer(kOffW1, w1, kObs, kKs1, true);
+    pack_layer(kOffW2, w2, kHidden, kKsH, false);
+    pack_layer(kOffW3, w3, kHidden, kKsH, false);
+    pack_layer(kOffW4, w4, kHidden, kKsH, false);
+    for (int s = 0; s < kKsH; ++s)                          // last layer: 14 rows, stored as 16, two lane halves
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r)
+                for (int j = 0; j < 8; ++j) {
+                    const float v = r < kOut ? w5[(size_t)r * kHidden + frag_k(s, h, j)] : 0.0f;
+                    p[kOffW5 / 2 + (((s * 2 + h) * 16 + r) * 8 + j)] = bf16_rne(v);
+                }
+    float* bias = (float*)(img.data() + kOffB);
+    const float* bs[4] = {b1, b2, b3, b4};
+    for (int l = 0; l < 4; ++l)
+        for (int k = 0; k < kHidden; ++k) bias[l * kHidden + k] = bs[l][k];
+    for (int k = 0; k < kOut; ++k) bias[4 * kHidden + k] = b5[k];
+    std::memcpy(image, img.data(), (size_t)kImageBytes);
+    return TPL_OK;
+}
+
+namespace tpl {
+
+// ---- device side -----------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    f32x2 v = {a, b};
+    bf16x2 r = __builtin_convertvector(v, bf16x2);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+// two cell bits -> two packed bf16 values (1.0 = 0x3F80)
+__device__ __forceinline__ uint32_t bits_to_bf16x2(uint32_t two_bits) {
+    return ((two_bits & 1u) | ((two_bits & 2u) << 15)) * 0x3F80u;
+}
+
+struct PolicyArgs {
+    const uint4* plane_a;
+    const uint4* plane_b;
+    int64_t n;
+    int32_t L, M;
+    const uint4* image;     // packed weights, kImageBytes
+    uint8_t* action;        // [n]
+    float* logits;          // [n][14] or null
+};
+
+// relu + convert an accumulator tile to the two B fragments it provides to the next layer
+__device__ __forceinline__ void tile_to_frags(const f32x16& c, bf16x8& f0, bf16x8& f1) {
+    uint4 lo, hi;
+    lo.x = pack_bf16(fmaxf(c[0], 0.f), fmaxf(c[1], 0.f));
+    lo.y = pack_bf16(fmaxf(c[2], 0.f), fmaxf(c[3], 0.f));
+    lo.z = pack_bf16(fmaxf(c[4], 0.f), fmaxf(c[5], 0.f));
+    lo.w = pack_bf16(fmaxf(c[6], 0.f), fmaxf(c[7], 0.f));
+    hi.x = pack_bf16(fmaxf(c[8], 0.f), fmaxf(c[9], 0.f));
+    hi.y = pack_bf16(fmaxf(c[10], 0.f), fmaxf(c[11], 0.f));
+    hi.z = pack_bf16(fmaxf(c[12], 0.f), fmaxf(c[13], 0.f));
+    hi.w = pack_bf16(fmaxf(c[14], 0.f), fmaxf(c[15], 0.f));
+    f0 = __builtin_bit_cast(bf16x8, lo);
+    f1 = __builtin_bit_cast(bf16x8, hi);
+}
+
+// accumulator tile m of a layer starts as the bias of its rows: row = (reg&3) + 8(reg>>2) + 4h
+__device__ __forceinline__ f32x16 bias_tile(const float* bias, int m, int h) {
+    f32x16 c;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 b = *(const float4*)(bias + 32 * m + 8 * g + 4 * h);
+        c[4 * g + 0] = b.x; c[4 * g + 1] = b.y; c[4 * g + 2] = b.z; c[4 * g + 3] = b.w;
+    }
+    return c;
+}
+
+// one 128 -> 128 hidden layer on fragments held in registers
+template <int kNt>
+__device__ __forceinline__ void hidden_layer(const uint8_t* lds, int w_off, const float* bias, int lane, int h,
+                                             bf16x8 (&x)[kNt][kKsH]) {
+    f32x16 acc[kMt][kNt];
+#pragma unroll
+    for (int m = 0; m < kMt; ++m) {
+        const f32x16 b = bias_tile(bias, m, h);
+#pragma unroll
+        for (int t = 0; t < kNt; ++t) acc[m][t] = b;
+    }
+#pragma unroll
+    for (int s = 0; s < kKsH; ++s) {
+#pragma unroll
+        for (int m = 0; m < kMt; ++m) {
+            const bf16x8 a = *(const bf16x8*)(lds + w_off + ((m * kKsH + s) * 64 + lane) * 16);
+#pragma unroll
+            for (int t = 0; t < kNt; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, x[t][s], acc[m][t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every later A fragment up here (spills)
+    }
+#pragma unroll
+    for (int m = 0; m < kMt; ++m)
+#pragma unroll
+        for (int t = 0; t < kNt; ++t) tile_to_frags(acc[m][t], x[t][2 * m], x[t][2 * m + 1]);
+}
+
+template <int kNt>
+__global__ __launch_bounds__(256, 1) void policy_kernel(const PolicyArgs p) {
+    __shared__ uint4 s_image[kImageBytes / 16];
+    for (int i = threadIdx.x; i < kImageBytes / 16; i += 256) s_image[i] = p.image[i];
+    __syncthreads();
+    const uint8_t* lds = (const uint8_t*)s_image;
+    const float* bias = (const float*)(lds + kOffB);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t tiles = (p.n + 32 * kNt - 1) / (32 * kNt);
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+        // ---- the lane's boards -> cell bit vector (internal order: bit 20x + y) and the extra features
+        uint32_t cw[kNt][7];
+        uint32_t lm[kNt];
+        bool valid[kNt];
+#pragma unroll
+        for (int t = 0; t < kNt; ++t) {
+            const int64_t b = tile * (32 * kNt) + t * 32 + r;
+            valid[t] = b < p.n;
+            Board s;
+            if (valid[t]) {
+                unpack_board(p.plane_a[b], p.plane_b[b], s);
+            } else {
+#pragma unroll
+                for (int c = 0; c < kCols; ++c) s.c[c] = 0;
+                s.window = 0x3FFFFFFFu; s.state = 0; s.lines = 0; s.moves = 0; s.episode = 0;
+            }
+            cw[t][0] = s.c[0] | (s.c[1] << 20);
+            cw[t][1] = (s.c[1] >> 12) | (s.c[2] << 8) | (s.c[3] << 28);
+            cw[t][2] = (s.c[3] >> 4) | (s.c[4] << 16);
+            cw[t][3] = (s.c[4] >> 16) | (s.c[5] << 4) | (s.c[6] << 24);
+            cw[t][4] = (s.c[6] >> 8) | (s.c[7] << 12);
+            cw[t][5] = s.c[8] | (s.c[9] << 20);
+            const uint32_t cur = s.window & 7u, nxt = (s.window >> 3) & 7u;
+            cw[t][6] = (s.c[9] >> 12) | ((1u << (8 + cur)) & 0x7F00u) | ((1u << (15 + nxt)) & 0x3F8000u) |
+                       (s.state != ST_RUNNING ? 1u << 24 : 0u);
+            lm[t] = pack_bf16((float)(p.L - (int)s.lines), (float)(p.M - (int)s.moves));   // features 214, 215
+        }
+
+        // ---- layer 1: 224 (217) -> 128, B fragments made from bits on the fly
+        bf16x8 x[kNt][kKsH];
+        {
+            f32x16 acc[kMt][kNt];
+#pragma unroll
+            for (int m = 0; m < kMt; ++m) {
+                const f32x16 b = bias_tile(bias, m, h);
+#pragma unroll
+                for (int t = 0; t < kNt; ++t) acc[m][t] = b;
+            }
+#pragma unroll
+            for (int s = 0; s < kKs1; ++s) {
+                bf16x8 bf[kNt];
+#pragma unroll
+                for (int t = 0; t < kNt; ++t) {
+                    const uint32_t half16 = (cw[t][s >> 1] >> ((s & 1) * 16)) >> (4 * h);
+                    uint4 q;
+                    q.x = bits_to_bf16x2(half16);            // k = 16s + 4h + {0,1}
+                    q.y = bits_to_bf16x2(half16 >> 2);       //                 {2,3}
+                    q.z = bits_to_bf16x2(half16 >> 8);       // k = 16s + 8 + 4h + {0,1}
+                    q.w = bits_to_bf16x2(half16 >> 10);
+                    if (s == 13 && h == 1) q.y = lm[t];      // k = 214, 215: L_rem, M_rem
+                    bf[t] = __builtin_bit_cast(bf16x8, q);
+                }
+#pragma unroll
+                for (int m = 0; m < kMt; ++m) {
+                    const bf16x8 a = *(const bf16x8*)(lds + kOffW1 + ((m * kKs1 + s) * 64 + lane) * 16);
+#pragma unroll
+                    for (int t = 0; t < kNt; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf[t], acc[m][t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < kMt; ++m)
+#pragma unroll
+                for (int t = 0; t < kNt; ++t) tile_to_frags(acc[m][t], x[t][2 * m], x[t][2 * m + 1]);
+        }
+
+        // ---- layers 2-4
+        hidden_layer<kNt>(lds, kOffW2, bias + 1 * kHidden, lane, h, x);
+        hidden_layer<kNt>(lds, kOffW3, bias + 2 * kHidden, lane, h, x);
+        hidden_layer<kNt>(lds, kOffW4, bias + 3 * kHidden, lane, h, x);
+
+        // ---- layer 5: 128 -> 14 (rows 0..13 of one tile; lanes of rows 16..31 re-read rows 0..15, unused)
+#pragma unroll
+        for (int t = 0; t < kNt; ++t) {
+            f32x16 c;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g < 2) b = *(const float4*)(bias + 4 * kHidden + 8 * g + 4 * h);
+                c[4 * g + 0] = b.x; c[4 * g + 1] = b.y; c[4 * g + 2] = b.z; c[4 * g + 3] = b.w;
+            }
+#pragma unroll
+            for (int s = 0; s < kKsH; ++s) {
+                const bf16x8 a = *(const bf16x8*)(lds + kOffW5 + ((s * 2 + h) * 16 + (r & 15)) * 16);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, x[t][s], c, 0, 0, 0);
+            }
+            // this lane holds outputs 4h + {0..3} in c[0..3] and 8 + 4h + {0..3} in c[4..7] of board (tile, t, r)
+            const int64_t b = tile * (32 * kNt) + t * 32 + r;
+            if (p.logits && valid[t]) {
+                float* o = p.logits + b * kOut;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[4 * h + k] = c[k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (8 + 4 * h + k < kOut) o[8 + 4 * h + k] = c[4 + k];
+            }
+            // argmax of outputs 0..3 (rotation) and of outputs 4..13 (location), lowest index on ties, NaN never wins
+            float rv = -INFINITY; int ri = 0;                // rotation: all four live on the h = 0 lane
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (c[k] > rv) { rv = c[k]; ri = k; }
+            float lv = -INFINITY; int li = 99;               // location candidates of this lane, ascending index
+            if (h == 1) {                                    // outputs 4..7 -> loc 0..3, outputs 12, 13 -> loc 8, 9
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (c[k] > lv) { lv = c[k]; li = k; }
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (c[4 + k] > lv) { lv = c[4 + k]; li = 8 + k; }
+            } else {                                         // outputs 8..11 -> loc 4..7
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (c[4 + k] > lv) { lv = c[4 + k]; li = 4 + k; }
+            }
+            const float ov = __shfl_xor(lv, 32);
+            const int oi = __shfl_xor(li, 32);
+            if (ov > lv || (ov == lv && oi < li)) { lv = ov; li = oi; }
+            if (li == 99) li = 0;
+            if (h == 0 && valid[t]) p.action[b] = (uint8_t)(ri * 10 + li);
+        }
+    }
+}
+
+}  // namespace tpl
+
+extern "C" int tpl_policy_act(tpl_env* e, const void* image, uint8_t* action, float* logits, void* stream) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!image || !action) return fail_msg(TPL_ERR_ARG, "image/action is null");
+    if (((uintptr_t)image & 15u) != 0) return fail_msg(TPL_ERR_ARG, "image must be 16-byte aligned");
+    DeviceGuard guard(e->device);
+    PolicyArgs p{};
+    p.plane_a = e->plane_a; p.plane_b = e->plane_b; p.n = e->n; p.L = e->L; p.M = e->M;
+    p.image = (const uint4*)image; p.action = action; p.logits = logits;
+    constexpr int kNt = 2;
+    const int64_t tiles = (e->n + 32 * kNt - 1) / (32 * kNt);
+    int64_t groups = (tiles + 3) / 4;
+    const unsigned grid = (unsigned)(groups < 256 ? groups : 256);      // one resident workgroup per CU, looping over tiles
+    hipLaunchKernelGGL(policy_kernel<kNt>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    TPL_HIP(hipGetLastError());
+    return TPL_OK;
+}

@@ -1,8 +1,7 @@
 // tetris_piclim.hip -- kernels and C ABI (include/tetris_piclim.h) of the batched Tetris-piclim environment.
 // gfx950 only.  The per-lane move lives in tpl_device.h; this file holds the kernels around it, the handle
 // and the extern "C" entry points.  Citations "(:NNN)" are lines of the reference's game/tetris.py.
-#include "../../include/tetris_piclim.h"
-#include "tpl_device.h"
+#include "tpl_internal.h"
 
 #include <hip/hip_bf16.h>
 
@@ -13,50 +12,9 @@
 
 namespace tpl {
 
-constexpr int kBlock = 256;
-constexpr int kStatShards = 256;
-constexpr int kStatStride = 16;   // uint64 per shard -> one 128-B line each
-
-// ---------------------------------------------------------------------------------------------- handle
-struct Pool {
-    uint8_t* rec = nullptr;    // [n_cfg] records of `stride` bytes: plane-A word, plane-B word, piece words 1..
-    uint32_t stride = 0;
-    int64_t n_cfg = 0;
-    void* owned = nullptr;
-};
-
-}  // namespace tpl
-
-struct tpl_env {
-    int64_t n = 0;
-    int32_t L = 0, M = 0, device = 0;
-    int64_t global_offset = 0;
-    uint64_t seed = 0;
-    int32_t auto_reset = 0, assign_mode = 0;
-    float r_line = 1.0f, r_win = 0.0f, r_lose = 0.0f;
-    int32_t boards_per_lane = 2;        // tuning knobs of the step kernel: boards per lane (1, 2 or 4)
-    int32_t block_threads = 256;        //   and threads per block (64, 128, 256 or 512)
-    uint4* plane_a = nullptr;
-    uint4* plane_b = nullptr;
-    unsigned long long* stats = nullptr;// [kStatShards][kStatStride]
-    void* owned = nullptr;
-    tpl::Pool pool;
-};
-
-namespace tpl {
-
 // ---------------------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-// same, for the other translation units of the library
 int fail_msg(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -65,11 +23,7 @@ int fail_msg(int code, const char* fmt, ...) {
     return code;
 }
 
-#define TPL_HIP(call)                                                                                   \
-    do {                                                                                                \
-        hipError_t e_ = (call);                                                                         \
-        if (e_ != hipSuccess) return fail(TPL_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));  \
-    } while (0)
+#define fail(...) fail_msg(__VA_ARGS__)
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // piece words of a configuration: entries 0..M+1 must be addressable (pieces[1] after the last move)
@@ -574,16 +528,6 @@ static int launch_step(tpl_env* e, const void* act0, const void* act1, int32_t d
     TPL_HIP(hipGetLastError());
     return TPL_OK;
 }
-
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = true;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
-        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
-    }
-    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
 
 }  // namespace tpl
 

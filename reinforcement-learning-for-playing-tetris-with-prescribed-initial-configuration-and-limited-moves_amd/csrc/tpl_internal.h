@@ -1,0 +1,59 @@
+// tpl_internal.h -- what the translation units of libtetris_piclim.so share: the handle, error reporting, guards.
+#pragma once
+
+#include "../../include/tetris_piclim.h"
+#include "tpl_device.h"
+
+namespace tpl {
+
+constexpr int kBlock = 256;
+constexpr int kStatShards = 256;
+constexpr int kStatStride = 16;   // uint64 per shard -> one 128-B line each
+
+struct Pool {
+    uint8_t* rec = nullptr;    // [n_cfg] records of `stride` bytes: plane-A word, plane-B word, piece words 1..
+    uint32_t stride = 0;
+    int64_t n_cfg = 0;
+    void* owned = nullptr;
+};
+
+}  // namespace tpl
+
+struct tpl_env {
+    int64_t n = 0;
+    int32_t L = 0, M = 0, device = 0;
+    int64_t global_offset = 0;
+    uint64_t seed = 0;
+    int32_t auto_reset = 0, assign_mode = 0;
+    float r_line = 1.0f, r_win = 0.0f, r_lose = 0.0f;
+    int32_t boards_per_lane = 2;        // tuning knobs of the step kernel: boards per lane (1, 2 or 4)
+    int32_t block_threads = 256;        //   and threads per block (64, 128, 256 or 512)
+    uint4* plane_a = nullptr;
+    uint4* plane_b = nullptr;
+    unsigned long long* stats = nullptr;// [kStatShards][kStatStride]
+    void* owned = nullptr;
+    tpl::Pool pool;
+};
+
+namespace tpl {
+
+// sets the calling thread's tpl_last_error() message and returns `code`
+int fail_msg(int code, const char* fmt, ...);
+
+#define TPL_HIP(call)                                                                                        \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess) return ::tpl::fail_msg(TPL_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+}  // namespace tpl

@@ -222,6 +222,16 @@ class BatchedTetris:
         check(self._lib.tpl_decode_actions(self._h, _ptr(logits), _OBS_CODES[logits.dtype], _ptr(out), self._stream()))
         return out
 
+    def policy_act(self, image: torch.Tensor, out: Optional[torch.Tensor] = None, logits: Optional[torch.Tensor] = None):
+        """Fused observation -> Model(217, 14) -> action on the matrix cores.  `image` is the device copy of
+        pack_policy(...).  Returns the uint8 actions; fills `logits` ([N, 14] float32) when given."""
+        if out is None:
+            out = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        if logits is not None and (logits.shape != (self.num_envs, 14) or logits.dtype != torch.float32 or not logits.is_contiguous()):
+            raise ValueError("logits must be a contiguous float32 [N, 14] tensor")
+        check(self._lib.tpl_policy_act(self._h, _ptr(image), _ptr(out), _ptr(logits), self._stream()))
+        return out
+
     def packed_state(self) -> dict:
         """Everything get_state() and the public attributes expose, in the interchange layout (device tensors)."""
         n, d = self.num_envs, self.device

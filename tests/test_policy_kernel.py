@@ -1,0 +1,158 @@
+"""The fused policy kernel (csrc/policy_mlp.hip): 32-B board state -> Model(217, 14) on the matrix cores -> action.
+
+Two kinds of check, as the MFMA fragment layouts demand:
+  * EXACT: with small-integer sparse weights every intermediate value is an integer below 256, exactly
+    representable in bf16 and f32, so the kernel's logits must equal an integer reference bit for bit.  This pins
+    the whole wiring: weight pre-packing, permuted k order, accumulator-as-operand hand-off, observation
+    construction from the packed state, output row mapping.
+  * TOLERANCE (floating point, the one place on this path): random float weights against a float64 reference
+    that rounds weights and hidden activations to bf16 at the same points.  Differences come only from the
+    summation order inside f32 accumulation and the occasional activation that rounds the other way:
+    |logit - ref| <= 2e-2 * (1 + max|ref|) and the chosen actions agree wherever the reference's margin
+    between best and runner-up exceeds that tolerance.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16_round(a):
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return u.astype(np.uint32).view(np.float32)
+
+
+def _reference(obs, params, round_hidden=True):
+    x = obs.astype(np.float64)
+    for i, (w, b) in enumerate(params):
+        y = x @ _bf16_round(w).astype(np.float64).T + b.astype(np.float64)
+        if i < 4:
+            y = np.maximum(y, 0.0)
+            x = _bf16_round(y.astype(np.float32)).astype(np.float64) if round_hidden else y
+        else:
+            x = y
+    return x
+
+
+def _decode(logits):
+    return logits[:, :4].argmax(1) * 10 + logits[:, 4:].argmax(1)
+
+
+def _env(T, n, seed=3, steps=7):
+    env = T.BatchedTetris(10, 40, n, seed=seed, auto_reset=True)
+    rows, pieces = env.synthetic_configs(min(n, 4096))
+    env.load_configs(rows, pieces)
+    env.reset()
+    for t in range(steps):                                   # some played boards, counters and terminal flags in the mix
+        env.step(env.synthetic_actions(t), observe=False)
+    return env
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    assert torch.cuda.is_available()
+    import tetris_piclim
+    return tetris_piclim
+
+
+@pytest.mark.parametrize("n", [64, 1000, 70000])
+def test_exact_integer_weights(T, n):
+    import torch
+    rng = np.random.default_rng(n)
+
+    def sparse(out, inn, nnz, scale=1):
+        w = np.zeros((out, inn), np.float32)
+        for r in range(out):
+            w[r, rng.choice(inn, nnz, replace=False)] = rng.choice([-1, 1], nnz) * scale
+        return w
+    # cells/one-hots are 0/1; L_rem, M_rem up to 40: keep their weights zero in layer 1 so values stay small
+    w1 = sparse(128, 214, 3)
+    w1 = np.concatenate([w1, np.zeros((128, 3), np.float32)], 1)
+    w1[::5, 216] = 1                                         # the terminal flag takes part
+    w1[3, 214] = 1; w1[7, 215] = 1                           # and once each, the two counters (<= 40)
+    params = [(w1, rng.integers(0, 2, 128).astype(np.float32)),
+              (sparse(128, 128, 2), rng.integers(-1, 2, 128).astype(np.float32)),
+              (sparse(128, 128, 2), rng.integers(-1, 2, 128).astype(np.float32)),
+              (sparse(128, 128, 2), rng.integers(-1, 2, 128).astype(np.float32)),
+              (sparse(14, 128, 2), rng.integers(-2, 3, 14).astype(np.float32))]
+    env = _env(T, n)
+    obs = env.observe().cpu().numpy()
+    want = _reference(obs, params, round_hidden=False)
+    assert np.abs(want).max() < 256 and np.all(want == np.round(want))      # the construction really is exact
+    image = torch.from_numpy(T.pack_policy(params)).to(env.device)
+    logits = torch.full((n, 14), float("nan"), device=env.device)
+    action = env.policy_act(image, logits=logits)
+    got = logits.cpu().numpy()
+    assert np.array_equal(got, want.astype(np.float32))
+    assert np.array_equal(action.cpu().numpy(), _decode(want))
+    assert np.array_equal(env.decode_actions(logits).cpu().numpy(), action.cpu().numpy())   # same tie rule as the decode kernel
+    env.terminate()
+
+
+def test_random_float_weights_within_tolerance(T):
+    import torch
+    n = 20000
+    torch.manual_seed(1)
+    model = T.PolicyMLP()
+    with torch.no_grad():
+        for prm in model.parameters():
+            prm.normal_(0.0, 0.3)
+        model.layer1.weight[:, 214:216] *= 0.05              # keep the two large-valued counters from saturating everything
+    params = [(l.weight.detach().numpy(), l.bias.detach().numpy())
+              for l in (model.layer1, model.layer2, model.layer3, model.layer4, model.layer5)]
+    env = _env(T, n)
+    obs = env.observe().cpu().numpy()
+    want = _reference(obs, params)
+    image = T.actor.policy_image(model, env.device)
+    logits = torch.empty((n, 14), device=env.device)
+    action = env.policy_act(image, logits=logits).cpu().numpy()
+    got = logits.cpu().numpy().astype(np.float64)
+    tol = 2e-2 * (1.0 + np.abs(want).max())
+    assert np.abs(got - want).max() <= tol, (np.abs(got - want).max(), tol)
+    assert np.abs(got - want).mean() <= tol / 20
+    # actions agree wherever the reference's decision is clear of the tolerance
+    def margin(block):
+        s = np.sort(block, axis=1)
+        return s[:, -1] - s[:, -2]
+    clear = (margin(want[:, :4]) > 2 * tol) & (margin(want[:, 4:]) > 2 * tol)
+    assert clear.mean() > 0.5
+    assert np.array_equal(action[clear], _decode(want)[clear])
+    assert (action == _decode(want)).mean() > 0.97
+    env.terminate()
+
+
+def test_fused_actor_matches_unfused_decisions_and_steps_the_env(T, oracle):
+    """Actor(fused=True) drives the environment; its recorded actions replayed through the oracle give the same
+    rewards, dones and boards (the environment side is bit-exact whatever the policy does)."""
+    import torch
+    L, M, n, seed = 10, 40, 8192, 23
+    torch.manual_seed(2)
+    model = T.PolicyMLP()
+    with torch.no_grad():
+        for prm in model.parameters():
+            prm.normal_(0.0, 0.35)
+        model.layer1.weight[:, 214:] = 0.0
+    env = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True)
+    rows, pieces = env.synthetic_configs(1024)
+    env.load_configs(rows, pieces)
+    env.reset()
+    actor = T.Actor(env, model, use_graph=True, fused=True)
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_pool(rows.cpu().numpy().view(np.uint16), pieces.cpu().numpy())
+    cpu.set_options(auto_reset=True, assign_mode=0)
+    cpu.reset()
+    seen = set()
+    for t in range(40):
+        actor.step()
+        a = actor.action.cpu().numpy()
+        r_c, d_c = cpu.step(a)
+        assert np.array_equal(actor.reward.cpu().numpy(), r_c) and np.array_equal(actor.done.cpu().numpy(), d_c), t
+        seen.update(np.unique(a).tolist())
+    assert len(seen) > 8
+    got = {k: v.cpu().numpy() for k, v in env.packed_state().items()}
+    want = cpu.get_state()
+    for k, v in want.items():
+        assert np.array_equal(got[k].view(np.uint16) if k == "rows" else got[k], v), k
+    env.terminate()
