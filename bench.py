@@ -162,19 +162,22 @@ def main():
         rows, pieces = aenv.synthetic_configs(na)
         aenv.load_configs(rows, pieces)
         aenv.reset()
-        torch.manual_seed(0)
-        act = T.Actor(aenv, T.PolicyMLP(), dtype=torch.bfloat16, use_graph=True)
-        act.run(20)
-        torch.cuda.synchronize(dev)
-        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        iters = 300
-        a0.record()
-        act.run(iters)
-        a1.record()
-        torch.cuda.synchronize(dev)
-        ms = a0.elapsed_time(a1) / iters
-        actor = {"value": na / (ms * 1e-3), "unit": "env-steps/s", "boards": na, "ms_per_step": ms,
-                 "policy": "MLP 217-128-128-128-128-14 bf16 (random init), greedy", "graph": True}
+        actor = {"boards": na, "unit": "env-steps/s", "policy": "MLP 217-128-128-128-128-14, bf16 operands, greedy, random init"}
+        for name, fused in (("fused_mfma_kernel", True), ("torch_linear_layers", False)):
+            torch.manual_seed(0)
+            # two launches per iteration when fused: a graph replay costs more than it saves there
+            act = T.Actor(aenv, T.PolicyMLP(), dtype=torch.bfloat16, use_graph=not fused, fused=fused)
+            act.run(20)
+            torch.cuda.synchronize(dev)
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            iters = 300
+            a0.record()
+            act.run(iters)
+            a1.record()
+            torch.cuda.synchronize(dev)
+            ms = a0.elapsed_time(a1) / iters
+            actor[name] = {"value": na / (ms * 1e-3), "ms_per_step": ms}
+        actor["value"] = actor["fused_mfma_kernel"]["value"]
         aenv.terminate()
         env = None
 

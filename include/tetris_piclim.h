@@ -135,6 +135,9 @@ size_t tpl_policy_image_bytes(void);
 int tpl_policy_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                     const float* b3, const float* w4, const float* b4, const float* w5, const float* b5, void* image);
 int tpl_policy_act(tpl_env* env, const void* image, uint8_t* action, float* logits, void* stream);
+/* Geometry of the fused policy kernel (0: 4 waves x 64 boards per workgroup, 1: 8 waves x 32 boards; default 1).
+ * Results do not depend on it. */
+int tpl_set_policy_tuning(tpl_env* env, int32_t variant);
 
 /* Statistics over episodes finished since the last full reset, reduced on the device into
  * out[4] (device pointer, uint64): {episodes, sum of lines_cleared at finish, wins, top-outs}. */

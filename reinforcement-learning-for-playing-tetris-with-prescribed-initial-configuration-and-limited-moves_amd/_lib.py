@@ -24,7 +24,7 @@ SYMBOLS = [
     "tpl_set_options", "tpl_load_configs", "tpl_reset", "tpl_move", "tpl_step", "tpl_get_state",
     "tpl_expand_obs", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
     "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_decode_actions", "tpl_generate_configs",
-    "tpl_policy_image_bytes", "tpl_policy_pack", "tpl_policy_act",
+    "tpl_policy_image_bytes", "tpl_policy_pack", "tpl_policy_act", "tpl_set_policy_tuning",
 ]
 
 TPL_U8, TPL_I32, TPL_I64 = 0, 1, 2
@@ -43,19 +43,47 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP library cannot be built (no CPU fallback exists)")
 
 
+def _source_digest() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for path in _SOURCES:
+        with open(path, "rb") as f:
+            h.update(path.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> csrc/libtetris_piclim.so (rebuilt when a source is newer)."""
-    stale = force or not os.path.exists(LIB_PATH) or any(
-        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in _SOURCES)
-    if stale:
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-               "-o", LIB_PATH + ".tmp"] + _UNITS
-        res = subprocess.run(cmd, capture_output=True, text=True)
-        if res.returncode != 0:
-            raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-        os.replace(LIB_PATH + ".tmp", LIB_PATH)
-        if verbose:
-            print("built", LIB_PATH)
+    """hipcc --offload-arch=gfx950 -> csrc/libtetris_piclim.so.
+
+    Staleness is decided by a digest of the sources kept next to the library (file times do not survive a copy of
+    the tree), and concurrent callers -- the ranks of one torchrun job -- serialise on a lock file, so exactly one
+    of them compiles and the others load the finished library."""
+    stamp = LIB_PATH + ".sha256"
+    digest = _source_digest()
+
+    def fresh():
+        return os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == digest
+
+    if not force and fresh():
+        return LIB_PATH
+    import fcntl
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or not fresh():
+                tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+                cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", tmp] + _UNITS
+                res = subprocess.run(cmd, capture_output=True, text=True)
+                if res.returncode != 0:
+                    raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+                os.replace(tmp, LIB_PATH)
+                with open(stamp + ".tmp", "w") as f:
+                    f.write(digest)
+                os.replace(stamp + ".tmp", stamp)
+                if verbose:
+                    print("built", LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
@@ -95,6 +123,7 @@ def lib() -> C.CDLL:
     L.tpl_policy_image_bytes.argtypes = []
     L.tpl_policy_pack.argtypes = [vp] * 11
     L.tpl_policy_act.argtypes = [vp, vp, vp, vp, vp]
+    L.tpl_set_policy_tuning.argtypes = [vp, i32]
     L.tpl_get_stats.argtypes = [vp, vp, vp]
     L.tpl_shape_info.argtypes = [i32, i32, C.POINTER(i32), C.POINTER(i32), vp, vp]
     L.tpl_state_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]

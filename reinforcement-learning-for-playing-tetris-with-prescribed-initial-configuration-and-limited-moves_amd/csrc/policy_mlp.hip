@@ -190,18 +190,34 @@ __device__ __forceinline__ void hidden_layer(const uint8_t* lds, int w_off, cons
         for (int t = 0; t < kNt; ++t) tile_to_frags(acc[m][t], x[t][2 * m], x[t][2 * m + 1]);
 }
 
-template <int kNt>
-__global__ __launch_bounds__(256, 1) void policy_kernel(const PolicyArgs p) {
+template <int kNt, int kThreads>
+__global__ __launch_bounds__(kThreads, kThreads / 256) void policy_kernel(const PolicyArgs p) {
     __shared__ uint4 s_image[kImageBytes / 16];
-    for (int i = threadIdx.x; i < kImageBytes / 16; i += 256) s_image[i] = p.image[i];
+    // weights -> LDS, eight 16-B loads in flight per thread (a load-store-load-store loop would pay the L2
+    // latency forty times over)
+    constexpr int kPieces = kImageBytes / 16;
+    for (int base = 0; base < kPieces; base += kThreads * 8) {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * kThreads + (int)threadIdx.x;
+            v[u] = p.image[i < kPieces ? i : kPieces - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * kThreads + (int)threadIdx.x;
+            if (i < kPieces) s_image[i] = v[u];
+        }
+    }
     __syncthreads();
     const uint8_t* lds = (const uint8_t*)s_image;
     const float* bias = (const float*)(lds + kOffB);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
+    constexpr int kWaves = kThreads / 64;
     const int64_t tiles = (p.n + 32 * kNt - 1) / (32 * kNt);
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += (int64_t)gridDim.x * kWaves) {
         // ---- the lane's boards -> cell bit vector (internal order: bit 20x + y) and the extra features
         uint32_t cw[kNt][7];
         uint32_t lm[kNt];
@@ -335,11 +351,16 @@ extern "C" int tpl_policy_act(tpl_env* e, const void* image, uint8_t* action, fl
     PolicyArgs p{};
     p.plane_a = e->plane_a; p.plane_b = e->plane_b; p.n = e->n; p.L = e->L; p.M = e->M;
     p.image = (const uint4*)image; p.action = action; p.logits = logits;
-    constexpr int kNt = 2;
-    const int64_t tiles = (e->n + 32 * kNt - 1) / (32 * kNt);
-    int64_t groups = (tiles + 3) / 4;
-    const unsigned grid = (unsigned)(groups < 256 ? groups : 256);      // one resident workgroup per CU, looping over tiles
-    hipLaunchKernelGGL(policy_kernel<kNt>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    // one resident workgroup per CU (the weights fill its LDS), looping over board tiles.
+    // variant 0: 4 waves x 64 boards (one wave per SIMD); variant 1: 8 waves x 32 boards (two per SIMD, so one
+    // wave's epilogue overlaps the other's MFMAs)
+    if (e->policy_variant == 0) {
+        const int64_t groups = ((e->n + 63) / 64 + 3) / 4;
+        hipLaunchKernelGGL((policy_kernel<2, 256>), dim3((unsigned)(groups < 256 ? groups : 256)), dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        const int64_t groups = ((e->n + 31) / 32 + 7) / 8;
+        hipLaunchKernelGGL((policy_kernel<1, 512>), dim3((unsigned)(groups < 256 ? groups : 256)), dim3(512), 0, (hipStream_t)stream, p);
+    }
     TPL_HIP(hipGetLastError());
     return TPL_OK;
 }

@@ -775,6 +775,13 @@ int tpl_set_tuning(tpl_env* e, int32_t boards_per_lane, int32_t block_threads) {
     return TPL_OK;
 }
 
+int tpl_set_policy_tuning(tpl_env* e, int32_t variant) {
+    if (!e) return fail(TPL_ERR_ARG, "env is null");
+    if (variant != 0 && variant != 1) return fail(TPL_ERR_ARG, "policy variant must be 0 or 1");
+    e->policy_variant = variant;
+    return TPL_OK;
+}
+
 int tpl_synth_configs(tpl_env* e, uint64_t seed, int64_t first, int64_t count, uint16_t* rows, uint8_t* pieces,
                       void* stream) {
     if (!e) return fail(TPL_ERR_ARG, "env is null");

@@ -57,8 +57,9 @@ def T():
     return tetris_piclim
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("n", [64, 1000, 70000])
-def test_exact_integer_weights(T, n):
+def test_exact_integer_weights(T, n, variant):
     import torch
     rng = np.random.default_rng(n)
 
@@ -78,6 +79,7 @@ def test_exact_integer_weights(T, n):
               (sparse(128, 128, 2), rng.integers(-1, 2, 128).astype(np.float32)),
               (sparse(14, 128, 2), rng.integers(-2, 3, 14).astype(np.float32))]
     env = _env(T, n)
+    env.set_policy_tuning(variant)
     obs = env.observe().cpu().numpy()
     want = _reference(obs, params, round_hidden=False)
     assert np.abs(want).max() < 256 and np.all(want == np.round(want))      # the construction really is exact
