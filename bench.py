@@ -178,6 +178,23 @@ def main():
             ms = a0.elapsed_time(a1) / iters
             actor[name] = {"value": na / (ms * 1e-3), "ms_per_step": ms}
         actor["value"] = actor["fused_mfma_kernel"]["value"]
+        # the policy kernel alone, priced against the dense bf16 MFMA peak: FLOPs it issues per board (K padded to
+        # 224, the 14-row head run as one 32-row tile) over its own duration
+        image = act.image if act.image is not None else T.actor.policy_image(T.PolicyMLP(), dev)
+        out = torch.empty(na, dtype=torch.uint8, device=dev)
+        for _ in range(5):
+            aenv.policy_act(image, out=out)
+        p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        p0.record()
+        for _ in range(100):
+            aenv.policy_act(image, out=out)
+        p1.record()
+        torch.cuda.synchronize(dev)
+        pol_ms = p0.elapsed_time(p1) / 100
+        flop = 2.0 * (224 * 128 + 3 * 128 * 128 + 128 * 32) * na
+        actor["policy_kernel"] = {"ms": pol_ms, "roofline": {"bound": "mfma", "achieved": flop / (pol_ms * 1e-3) / 1e12,
+                                                              "peak": 2500.0, "unit": "TFLOP/s",
+                                                              "frac": flop / (pol_ms * 1e-3) / 1e12 / 2500.0}}
         aenv.terminate()
         env = None
 
