@@ -67,10 +67,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # TPL_BENCH_BACKEND=gloo and TPL_BENCH_ONE_GPU=1 exist only to rehearse the multi-rank path on a one-GPU box
+    backend = os.environ.get("TPL_BENCH_BACKEND", "nccl")
+    if os.environ.get("TPL_BENCH_ONE_GPU") == "1":
+        local = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -205,7 +212,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                # measured at 1,048,576 boards per launch; the kernel's traffic is linear in the board count
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch") * (n / float(1 << 20))
             except Exception:
                 traffic = None
         out = {
