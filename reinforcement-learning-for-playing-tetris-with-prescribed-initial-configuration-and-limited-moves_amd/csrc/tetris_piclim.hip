@@ -23,8 +23,6 @@ int fail_msg(int code, const char* fmt, ...) {
     return code;
 }
 
-#define fail(...) fail_msg(__VA_ARGS__)
-
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // piece words of a configuration: entries 0..M+1 must be addressable (pieces[1] after the last move)
 static inline int piece_words(int M) { return (M + 2 + kWindowStride - 1) / kWindowStride; }
@@ -515,8 +513,8 @@ static void launch_step_bpl(int threads, bool action_form, bool auto_reset, cons
 
 static int launch_step(tpl_env* e, const void* act0, const void* act1, int32_t dtype, float* reward, uint8_t* done,
                        uint8_t* cleared, hipStream_t stream) {
-    if (dtype != TPL_U8 && dtype != TPL_I32 && dtype != TPL_I64) return fail(TPL_ERR_ARG, "unknown integer dtype %d", dtype);
-    if (e->auto_reset && e->pool.n_cfg == 0) return fail(TPL_ERR_STATE, "auto_reset needs tpl_load_configs first");
+    if (dtype != TPL_U8 && dtype != TPL_I32 && dtype != TPL_I64) return fail_msg(TPL_ERR_ARG, "unknown integer dtype %d", dtype);
+    if (e->auto_reset && e->pool.n_cfg == 0) return fail_msg(TPL_ERR_STATE, "auto_reset needs tpl_load_configs first");
     StepArgs a = make_args(e);
     a.act0 = act0; a.act1 = act1; a.dtype = dtype; a.reward = reward; a.done = done; a.cleared = cleared;
     const bool action_form = act1 == nullptr;
@@ -554,30 +552,30 @@ size_t tpl_pool_bytes(int64_t n_cfg, int32_t M) {
 
 int tpl_create(tpl_env** out, int64_t num_envs, int32_t L, int32_t M, int32_t device_id, int64_t global_offset,
                uint64_t seed, void* workspace, size_t workspace_bytes) {
-    if (!out) return fail(TPL_ERR_ARG, "out is null");
+    if (!out) return fail_msg(TPL_ERR_ARG, "out is null");
     *out = nullptr;
-    if (num_envs <= 0 || num_envs > ((int64_t)1 << 31)) return fail(TPL_ERR_ARG, "num_envs %lld out of range", (long long)num_envs);
-    if (L < 1 || L > 250) return fail(TPL_ERR_ARG, "L=%d out of range [1, 250]", L);
-    if (M < 1 || M > 254) return fail(TPL_ERR_ARG, "M=%d out of range [1, 254]", M);
-    if (global_offset < 0) return fail(TPL_ERR_ARG, "global_offset is negative");
+    if (num_envs <= 0 || num_envs > ((int64_t)1 << 31)) return fail_msg(TPL_ERR_ARG, "num_envs %lld out of range", (long long)num_envs);
+    if (L < 1 || L > 250) return fail_msg(TPL_ERR_ARG, "L=%d out of range [1, 250]", L);
+    if (M < 1 || M > 254) return fail_msg(TPL_ERR_ARG, "M=%d out of range [1, 254]", M);
+    if (global_offset < 0) return fail_msg(TPL_ERR_ARG, "global_offset is negative");
     int ndev = 0;
     TPL_HIP(hipGetDeviceCount(&ndev));
-    if (device_id < 0 || device_id >= ndev) return fail(TPL_ERR_ARG, "device %d not in [0, %d)", device_id, ndev);
+    if (device_id < 0 || device_id >= ndev) return fail_msg(TPL_ERR_ARG, "device %d not in [0, %d)", device_id, ndev);
     DeviceGuard guard(device_id);
-    if (!guard.ok) return fail(TPL_ERR_HIP, "hipSetDevice(%d) failed", device_id);
+    if (!guard.ok) return fail_msg(TPL_ERR_HIP, "hipSetDevice(%d) failed", device_id);
 
     const size_t need = tpl_workspace_bytes(num_envs, M);
     tpl_env* e = new (std::nothrow) tpl_env();
-    if (!e) return fail(TPL_ERR_NOMEM, "host allocation failed");
+    if (!e) return fail_msg(TPL_ERR_NOMEM, "host allocation failed");
     e->n = num_envs; e->L = L; e->M = M; e->device = device_id;
     e->global_offset = global_offset; e->seed = seed;
     char* base = (char*)workspace;
     if (base) {
-        if (workspace_bytes < need) { delete e; return fail(TPL_ERR_ARG, "workspace has %zu bytes, need %zu", workspace_bytes, need); }
-        if (((uintptr_t)base & 255u) != 0) { delete e; return fail(TPL_ERR_ARG, "workspace must be 256-byte aligned"); }
+        if (workspace_bytes < need) { delete e; return fail_msg(TPL_ERR_ARG, "workspace has %zu bytes, need %zu", workspace_bytes, need); }
+        if (((uintptr_t)base & 255u) != 0) { delete e; return fail_msg(TPL_ERR_ARG, "workspace must be 256-byte aligned"); }
     } else {
         hipError_t err = hipMalloc((void**)&base, need);
-        if (err != hipSuccess) { delete e; return fail(TPL_ERR_NOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(err)); }
+        if (err != hipSuccess) { delete e; return fail_msg(TPL_ERR_NOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(err)); }
         e->owned = base;
     }
     const size_t n = (size_t)num_envs;
@@ -588,7 +586,7 @@ int tpl_create(tpl_env** out, int64_t num_envs, int32_t L, int32_t M, int32_t de
     if (err != hipSuccess) {
         if (e->owned) (void)hipFree(e->owned);
         delete e;
-        return fail(TPL_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(err));
+        return fail_msg(TPL_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(err));
     }
     *out = e;
     return TPL_OK;
@@ -604,8 +602,8 @@ int tpl_destroy(tpl_env* e) {
 }
 
 int tpl_set_options(tpl_env* e, int32_t auto_reset, int32_t assign_mode, float per_line, float win, float lose) {
-    if (!e) return fail(TPL_ERR_ARG, "env is null");
-    if (assign_mode != TPL_ASSIGN_HASH && assign_mode != TPL_ASSIGN_SEQUENTIAL) return fail(TPL_ERR_ARG, "unknown assign_mode %d", assign_mode);
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (assign_mode != TPL_ASSIGN_HASH && assign_mode != TPL_ASSIGN_SEQUENTIAL) return fail_msg(TPL_ERR_ARG, "unknown assign_mode %d", assign_mode);
     e->auto_reset = auto_reset ? 1 : 0; e->assign_mode = assign_mode;
     e->r_line = per_line; e->r_win = win; e->r_lose = lose;
     return TPL_OK;
@@ -613,19 +611,19 @@ int tpl_set_options(tpl_env* e, int32_t auto_reset, int32_t assign_mode, float p
 
 int tpl_load_configs(tpl_env* e, const uint16_t* rows, const uint8_t* pieces, int64_t n_cfg, void* pool_mem,
                      size_t pool_bytes, void* stream) {
-    if (!e) return fail(TPL_ERR_ARG, "env is null");
-    if (!rows || !pieces) return fail(TPL_ERR_ARG, "rows/pieces is null");
-    if (n_cfg <= 0 || n_cfg >= ((int64_t)1 << 32)) return fail(TPL_ERR_ARG, "n_cfg %lld out of range", (long long)n_cfg);
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!rows || !pieces) return fail_msg(TPL_ERR_ARG, "rows/pieces is null");
+    if (n_cfg <= 0 || n_cfg >= ((int64_t)1 << 32)) return fail_msg(TPL_ERR_ARG, "n_cfg %lld out of range", (long long)n_cfg);
     DeviceGuard guard(e->device);
     const size_t need = tpl_pool_bytes(n_cfg, e->M);
     char* base = (char*)pool_mem;
     void* newly_owned = nullptr;
     if (base) {
-        if (pool_bytes < need) return fail(TPL_ERR_ARG, "pool_mem has %zu bytes, need %zu", pool_bytes, need);
-        if (((uintptr_t)base & 255u) != 0) return fail(TPL_ERR_ARG, "pool_mem must be 256-byte aligned");
+        if (pool_bytes < need) return fail_msg(TPL_ERR_ARG, "pool_mem has %zu bytes, need %zu", pool_bytes, need);
+        if (((uintptr_t)base & 255u) != 0) return fail_msg(TPL_ERR_ARG, "pool_mem must be 256-byte aligned");
     } else {
         hipError_t err = hipMalloc((void**)&base, need);
-        if (err != hipSuccess) return fail(TPL_ERR_NOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(err));
+        if (err != hipSuccess) return fail_msg(TPL_ERR_NOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(err));
         newly_owned = base;
     }
     if (e->pool.owned) {
@@ -645,8 +643,8 @@ int tpl_load_configs(tpl_env* e, const uint16_t* rows, const uint8_t* pieces, in
 }
 
 int tpl_reset(tpl_env* e, const uint8_t* mask, void* stream) {
-    if (!e) return fail(TPL_ERR_ARG, "env is null");
-    if (e->pool.n_cfg == 0) return fail(TPL_ERR_STATE, "tpl_reset needs tpl_load_configs first");
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (e->pool.n_cfg == 0) return fail_msg(TPL_ERR_STATE, "tpl_reset needs tpl_load_configs first");
     DeviceGuard guard(e->device);
     if (!mask)
         TPL_HIP(hipMemsetAsync(e->stats, 0, (size_t)kStatShards * kStatStride * sizeof(unsigned long long), (hipStream_t)stream));
@@ -657,26 +655,26 @@ int tpl_reset(tpl_env* e, const uint8_t* mask, void* stream) {
 
 int tpl_move(tpl_env* e, const void* rot, const void* loc, int32_t dtype, float* reward, uint8_t* done,
              uint8_t* cleared, void* stream) {
-    if (!e) return fail(TPL_ERR_ARG, "env is null");
-    if (!rot || !loc) return fail(TPL_ERR_ARG, "rot/loc is null");
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!rot || !loc) return fail_msg(TPL_ERR_ARG, "rot/loc is null");
     DeviceGuard guard(e->device);
     return launch_step(e, rot, loc, dtype, reward, done, cleared, (hipStream_t)stream);
 }
 
 int tpl_step(tpl_env* e, const void* action, int32_t dtype, float* reward, uint8_t* done, void* stream) {
-    if (!e) return fail(TPL_ERR_ARG, "env is null");
-    if (!action) return fail(TPL_ERR_ARG, "action is null");
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!action) return fail_msg(TPL_ERR_ARG, "action is null");
     DeviceGuard guard(e->device);
     return launch_step(e, action, nullptr, dtype, reward, done, nullptr, (hipStream_t)stream);
 }
 
 int tpl_rollout(tpl_env* e, const uint8_t* actions, int64_t action_stride, int32_t num_steps, float* reward_steps,
                 uint8_t* done_steps, float* reward_sum, uint32_t* finished, void* stream) {
-    if (!e) return fail(TPL_ERR_ARG, "env is null");
-    if (!actions) return fail(TPL_ERR_ARG, "actions is null");
-    if (num_steps < 1) return fail(TPL_ERR_ARG, "num_steps must be >= 1");
-    if (action_stride < e->n) return fail(TPL_ERR_ARG, "action_stride %lld is smaller than num_envs", (long long)action_stride);
-    if (e->auto_reset && e->pool.n_cfg == 0) return fail(TPL_ERR_STATE, "auto_reset needs tpl_load_configs first");
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!actions) return fail_msg(TPL_ERR_ARG, "actions is null");
+    if (num_steps < 1) return fail_msg(TPL_ERR_ARG, "num_steps must be >= 1");
+    if (action_stride < e->n) return fail_msg(TPL_ERR_ARG, "action_stride %lld is smaller than num_envs", (long long)action_stride);
+    if (e->auto_reset && e->pool.n_cfg == 0) return fail_msg(TPL_ERR_STATE, "auto_reset needs tpl_load_configs first");
     DeviceGuard guard(e->device);
     RolloutArgs q{};
     q.s = make_args(e);
@@ -691,7 +689,7 @@ int tpl_rollout(tpl_env* e, const uint8_t* actions, int64_t action_stride, int32
 
 int tpl_get_state(tpl_env* e, uint16_t* rows, uint8_t* cur, uint8_t* nxt, uint8_t* lines, uint8_t* moves,
                   uint8_t* state, uint8_t* pieces_left, void* stream) {
-    if (!e) return fail(TPL_ERR_ARG, "env is null");
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
     DeviceGuard guard(e->device);
     hipLaunchKernelGGL(export_kernel, dim3(blocks_for(e->n)), dim3(kBlock), 0, (hipStream_t)stream, e->plane_a, e->plane_b,
                        e->n, (uint32_t)e->M, rows, cur, nxt, lines, moves, state, pieces_left);
@@ -700,8 +698,8 @@ int tpl_get_state(tpl_env* e, uint16_t* rows, uint8_t* cur, uint8_t* nxt, uint8_
 }
 
 int tpl_expand_obs(tpl_env* e, void* out, int32_t dtype, void* stream) {
-    if (!e) return fail(TPL_ERR_ARG, "env is null");
-    if (!out) return fail(TPL_ERR_ARG, "out is null");
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!out) return fail_msg(TPL_ERR_ARG, "out is null");
     DeviceGuard guard(e->device);
     const dim3 grid(blocks_for(e->n)), block(kBlock);
     if (dtype == TPL_F32)
@@ -711,14 +709,14 @@ int tpl_expand_obs(tpl_env* e, void* out, int32_t dtype, void* stream) {
         hipLaunchKernelGGL(expand_obs_kernel<__hip_bfloat16>, grid, block, 0, (hipStream_t)stream, e->plane_a, e->plane_b,
                            e->n, (uint32_t)e->L, (uint32_t)e->M, (__hip_bfloat16*)out);
     else
-        return fail(TPL_ERR_ARG, "unknown observation dtype %d", dtype);
+        return fail_msg(TPL_ERR_ARG, "unknown observation dtype %d", dtype);
     TPL_HIP(hipGetLastError());
     return TPL_OK;
 }
 
 int tpl_decode_actions(tpl_env* e, const void* logits, int32_t dtype, uint8_t* action, void* stream) {
-    if (!e) return fail(TPL_ERR_ARG, "env is null");
-    if (!logits || !action) return fail(TPL_ERR_ARG, "logits/action is null");
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!logits || !action) return fail_msg(TPL_ERR_ARG, "logits/action is null");
     DeviceGuard guard(e->device);
     const dim3 grid(blocks_for(e->n)), block(kBlock);
     if (dtype == TPL_F32)
@@ -727,14 +725,14 @@ int tpl_decode_actions(tpl_env* e, const void* logits, int32_t dtype, uint8_t* a
         hipLaunchKernelGGL(decode_actions_kernel<__hip_bfloat16>, grid, block, 0, (hipStream_t)stream,
                            (const __hip_bfloat16*)logits, e->n, action);
     else
-        return fail(TPL_ERR_ARG, "unknown logits dtype %d", dtype);
+        return fail_msg(TPL_ERR_ARG, "unknown logits dtype %d", dtype);
     TPL_HIP(hipGetLastError());
     return TPL_OK;
 }
 
 int tpl_get_stats(tpl_env* e, uint64_t* out, void* stream) {
-    if (!e) return fail(TPL_ERR_ARG, "env is null");
-    if (!out) return fail(TPL_ERR_ARG, "out is null");
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!out) return fail_msg(TPL_ERR_ARG, "out is null");
     DeviceGuard guard(e->device);
     hipLaunchKernelGGL(reduce_stats_kernel, dim3(1), dim3(4), 0, (hipStream_t)stream, e->stats, (unsigned long long*)out);
     TPL_HIP(hipGetLastError());
@@ -742,7 +740,7 @@ int tpl_get_stats(tpl_env* e, uint64_t* out, void* stream) {
 }
 
 int tpl_shape_info(int32_t piece, int32_t rotations, int32_t* h, int32_t* w, uint8_t* masks, uint8_t* revtopo) {
-    if (piece < 0 || piece > 6 || rotations < 0) return fail(TPL_ERR_ARG, "piece %d / rotations %d out of range", piece, rotations);
+    if (piece < 0 || piece > 6 || rotations < 0) return fail_msg(TPL_ERR_ARG, "piece %d / rotations %d out of range", piece, rotations);
     const ShapeWord sh = kShapeTableHost[piece * 4 + (rotations & 3)];
     const int ww = (int)((sh.x >> 16) & 7u), hh = (int)((sh.x >> 19) & 7u);
     if (h) *h = hh;
@@ -759,33 +757,33 @@ int tpl_shape_info(int32_t piece, int32_t rotations, int32_t* h, int32_t* w, uin
 }
 
 int tpl_state_ptrs(tpl_env* e, void** plane_a, void** plane_b) {
-    if (!e) return fail(TPL_ERR_ARG, "env is null");
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
     if (plane_a) *plane_a = e->plane_a;
     if (plane_b) *plane_b = e->plane_b;
     return TPL_OK;
 }
 
 int tpl_set_tuning(tpl_env* e, int32_t boards_per_lane, int32_t block_threads) {
-    if (!e) return fail(TPL_ERR_ARG, "env is null");
-    if (boards_per_lane != 1 && boards_per_lane != 2 && boards_per_lane != 4) return fail(TPL_ERR_ARG, "boards_per_lane must be 1, 2 or 4");
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (boards_per_lane != 1 && boards_per_lane != 2 && boards_per_lane != 4) return fail_msg(TPL_ERR_ARG, "boards_per_lane must be 1, 2 or 4");
     if (block_threads != 64 && block_threads != 128 && block_threads != 256 && block_threads != 512)
-        return fail(TPL_ERR_ARG, "block_threads must be 64, 128, 256 or 512");
+        return fail_msg(TPL_ERR_ARG, "block_threads must be 64, 128, 256 or 512");
     e->boards_per_lane = boards_per_lane;
     e->block_threads = block_threads;
     return TPL_OK;
 }
 
 int tpl_set_policy_tuning(tpl_env* e, int32_t variant) {
-    if (!e) return fail(TPL_ERR_ARG, "env is null");
-    if (variant != 0 && variant != 1) return fail(TPL_ERR_ARG, "policy variant must be 0 or 1");
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (variant != 0 && variant != 1) return fail_msg(TPL_ERR_ARG, "policy variant must be 0 or 1");
     e->policy_variant = variant;
     return TPL_OK;
 }
 
 int tpl_synth_configs(tpl_env* e, uint64_t seed, int64_t first, int64_t count, uint16_t* rows, uint8_t* pieces,
                       void* stream) {
-    if (!e) return fail(TPL_ERR_ARG, "env is null");
-    if (count <= 0) return fail(TPL_ERR_ARG, "count must be positive");
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (count <= 0) return fail_msg(TPL_ERR_ARG, "count must be positive");
     DeviceGuard guard(e->device);
     hipLaunchKernelGGL(synth_configs_kernel, dim3(blocks_for(count)), dim3(kBlock), 0, (hipStream_t)stream, seed, first,
                        count, (uint32_t)e->L, (uint32_t)e->M, rows, pieces);
@@ -795,8 +793,8 @@ int tpl_synth_configs(tpl_env* e, uint64_t seed, int64_t first, int64_t count, u
 
 int tpl_synth_actions(tpl_env* e, uint64_t seed, int64_t first, int64_t count, uint64_t step, uint8_t* action,
                       void* stream) {
-    if (!e) return fail(TPL_ERR_ARG, "env is null");
-    if (count <= 0 || !action) return fail(TPL_ERR_ARG, "bad count/action");
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (count <= 0 || !action) return fail_msg(TPL_ERR_ARG, "bad count/action");
     DeviceGuard guard(e->device);
     hipLaunchKernelGGL(synth_actions_kernel, dim3(blocks_for(count)), dim3(kBlock), 0, (hipStream_t)stream, seed, first,
                        count, step, action);
