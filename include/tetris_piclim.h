@@ -135,6 +135,15 @@ size_t tpl_policy_image_bytes(void);
 int tpl_policy_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                     const float* b3, const float* w4, const float* b4, const float* w5, const float* b5, void* image);
 int tpl_policy_act(tpl_env* env, const void* image, uint8_t* action, float* logits, void* stream);
+/* Epsilon-greedy exploration on an action array: with probability epsilon action[i] is replaced by a uniform
+ * action in [0, 40), decided by a hash of (seed, global board index, step). */
+int tpl_explore_actions(tpl_env* env, uint8_t* action, float epsilon, uint64_t seed, uint32_t step, void* stream);
+/* num_steps iterations of (tpl_policy_act, tpl_explore_actions(step0 + t), tpl_step) in ONE launch: the weights
+ * stay in LDS and the boards in registers; only the trajectory leaves the chip.  Outputs, each optional:
+ * actions u8 / rewards f32 / dones u8 [num_steps][n], and states_a / states_b [num_steps][n] 16-byte words = the
+ * resident state of every board BEFORE step t (a 32-byte observation for a replay buffer; layout in DESIGN.md). */
+int tpl_actor_rollout(tpl_env* env, const void* image, int32_t num_steps, float epsilon, uint64_t seed, uint32_t step0,
+                      uint8_t* actions, float* rewards, uint8_t* dones, void* states_a, void* states_b, void* stream);
 /* Geometry of the fused policy kernel (0: 4 waves x 64 boards per workgroup, 1: 8 waves x 32 boards; default 1).
  * Results do not depend on it. */
 int tpl_set_policy_tuning(tpl_env* env, int32_t variant);

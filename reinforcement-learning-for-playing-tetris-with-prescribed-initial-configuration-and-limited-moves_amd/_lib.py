@@ -16,6 +16,7 @@ _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_CSRC, "libtetris_piclim.so")
 _UNITS = [os.path.join(_CSRC, f) for f in ("tetris_piclim.hip", "carve_generator.hip", "policy_mlp.hip")]
 _SOURCES = _UNITS + [os.path.join(_CSRC, "tpl_device.h"), os.path.join(_CSRC, "tpl_internal.h"),
+                     os.path.join(_CSRC, "tpl_step.h"),
                      os.path.join(_ROOT, "include", "tetris_piclim.h")]
 
 # entry points declared in include/tetris_piclim.h (tests check that the .so exports every one of them)
@@ -25,6 +26,7 @@ SYMBOLS = [
     "tpl_expand_obs", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
     "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_decode_actions", "tpl_generate_configs",
     "tpl_policy_image_bytes", "tpl_policy_pack", "tpl_policy_act", "tpl_set_policy_tuning",
+    "tpl_explore_actions", "tpl_actor_rollout",
 ]
 
 TPL_U8, TPL_I32, TPL_I64 = 0, 1, 2
@@ -124,6 +126,8 @@ def lib() -> C.CDLL:
     L.tpl_policy_pack.argtypes = [vp] * 11
     L.tpl_policy_act.argtypes = [vp, vp, vp, vp, vp]
     L.tpl_set_policy_tuning.argtypes = [vp, i32]
+    L.tpl_explore_actions.argtypes = [vp, vp, f32, u64, C.c_uint32, vp]
+    L.tpl_actor_rollout.argtypes = [vp, vp, i32, f32, u64, C.c_uint32, vp, vp, vp, vp, vp, vp]
     L.tpl_get_stats.argtypes = [vp, vp, vp]
     L.tpl_shape_info.argtypes = [i32, i32, C.POINTER(i32), C.POINTER(i32), vp, vp]
     L.tpl_state_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]

@@ -22,6 +22,7 @@
 // tpl_expand_obs): k = 20*x + y for the cell in row y, column x (that is how the state stores the board), then
 // the 17 extras in their standard positions 200..216, then 7 zero pads.
 #include "tpl_internal.h"
+#include "tpl_step.h"
 
 #include <cstring>
 #include <vector>
@@ -190,18 +191,17 @@ __device__ __forceinline__ void hidden_layer(const uint8_t* lds, int w_off, cons
         for (int t = 0; t < kNt; ++t) tile_to_frags(acc[m][t], x[t][2 * m], x[t][2 * m + 1]);
 }
 
-template <int kNt, int kThreads>
-__global__ __launch_bounds__(kThreads, kThreads / 256) void policy_kernel(const PolicyArgs p) {
-    __shared__ uint4 s_image[kImageBytes / 16];
-    // weights -> LDS, eight 16-B loads in flight per thread (a load-store-load-store loop would pay the L2
-    // latency forty times over)
+// weights -> LDS, eight 16-B loads in flight per thread (a load-store-load-store loop would pay the L2 latency
+// forty times over).  Ends with a barrier.
+template <int kThreads>
+__device__ __forceinline__ void load_image(uint4* s_image, const uint4* image) {
     constexpr int kPieces = kImageBytes / 16;
     for (int base = 0; base < kPieces; base += kThreads * 8) {
         uint4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = base + u * kThreads + (int)threadIdx.x;
-            v[u] = p.image[i < kPieces ? i : kPieces - 1];
+            v[u] = image[i < kPieces ? i : kPieces - 1];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -210,15 +210,127 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void policy_kernel(const 
         }
     }
     __syncthreads();
-    const uint8_t* lds = (const uint8_t*)s_image;
+}
+
+// a board -> its cell bit vector in the internal order (bit 20x + y; extras as bits 200..213 and 216) and the
+// two numeric features (L_rem, M_rem) as a packed bf16 pair
+__device__ __forceinline__ void board_features(const Board& s, int L, int M, uint32_t (&cw)[7], uint32_t& lm) {
+    cw[0] = s.c[0] | (s.c[1] << 20);
+    cw[1] = (s.c[1] >> 12) | (s.c[2] << 8) | (s.c[3] << 28);
+    cw[2] = (s.c[3] >> 4) | (s.c[4] << 16);
+    cw[3] = (s.c[4] >> 16) | (s.c[5] << 4) | (s.c[6] << 24);
+    cw[4] = (s.c[6] >> 8) | (s.c[7] << 12);
+    cw[5] = s.c[8] | (s.c[9] << 20);
+    const uint32_t cur = s.window & 7u, nxt = (s.window >> 3) & 7u;
+    cw[6] = (s.c[9] >> 12) | ((1u << (8 + cur)) & 0x7F00u) | ((1u << (15 + nxt)) & 0x3F8000u) |
+            (s.state != ST_RUNNING ? 1u << 24 : 0u);
+    lm = pack_bf16((float)(L - (int)s.lines), (float)(M - (int)s.moves));   // features 214, 215
+}
+
+// the five layers for kNt tiles of 32 boards; c[t] ends up holding the 14 logits of board (t, r): outputs
+// 4h + {0..3} in c[t][0..3] and 8 + 4h + {0..3} in c[t][4..7]
+template <int kNt>
+__device__ __forceinline__ void policy_logits(const uint8_t* lds, int lane, int h, int r, const uint32_t (&cw)[kNt][7],
+                                              const uint32_t (&lm)[kNt], f32x16 (&c)[kNt]) {
     const float* bias = (const float*)(lds + kOffB);
+    // ---- layer 1: 224 (217) -> 128, B fragments made from bits on the fly
+    bf16x8 x[kNt][kKsH];
+    {
+        f32x16 acc[kMt][kNt];
+#pragma unroll
+        for (int m = 0; m < kMt; ++m) {
+            const f32x16 b = bias_tile(bias, m, h);
+#pragma unroll
+            for (int t = 0; t < kNt; ++t) acc[m][t] = b;
+        }
+#pragma unroll
+        for (int s = 0; s < kKs1; ++s) {
+            bf16x8 bf[kNt];
+#pragma unroll
+            for (int t = 0; t < kNt; ++t) {
+                const uint32_t half16 = (cw[t][s >> 1] >> ((s & 1) * 16)) >> (4 * h);
+                uint4 q;
+                q.x = bits_to_bf16x2(half16);            // k = 16s + 4h + {0,1}
+                q.y = bits_to_bf16x2(half16 >> 2);       //                 {2,3}
+                q.z = bits_to_bf16x2(half16 >> 8);       // k = 16s + 8 + 4h + {0,1}
+                q.w = bits_to_bf16x2(half16 >> 10);
+                if (s == 13 && h == 1) q.y = lm[t];      // k = 214, 215: L_rem, M_rem
+                bf[t] = __builtin_bit_cast(bf16x8, q);
+            }
+#pragma unroll
+            for (int m = 0; m < kMt; ++m) {
+                const bf16x8 a = *(const bf16x8*)(lds + kOffW1 + ((m * kKs1 + s) * 64 + lane) * 16);
+#pragma unroll
+                for (int t = 0; t < kNt; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf[t], acc[m][t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < kMt; ++m)
+#pragma unroll
+            for (int t = 0; t < kNt; ++t) tile_to_frags(acc[m][t], x[t][2 * m], x[t][2 * m + 1]);
+    }
+    // ---- layers 2-4
+    hidden_layer<kNt>(lds, kOffW2, bias + 1 * kHidden, lane, h, x);
+    hidden_layer<kNt>(lds, kOffW3, bias + 2 * kHidden, lane, h, x);
+    hidden_layer<kNt>(lds, kOffW4, bias + 3 * kHidden, lane, h, x);
+    // ---- layer 5: 128 -> 14 (rows 0..13 of one tile; lanes of rows 16..31 re-read rows 0..15, unused)
+#pragma unroll
+    for (int t = 0; t < kNt; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g < 2) b = *(const float4*)(bias + 4 * kHidden + 8 * g + 4 * h);
+            c[t][4 * g + 0] = b.x; c[t][4 * g + 1] = b.y; c[t][4 * g + 2] = b.z; c[t][4 * g + 3] = b.w;
+        }
+#pragma unroll
+        for (int s = 0; s < kKsH; ++s) {
+            const bf16x8 a = *(const bf16x8*)(lds + kOffW5 + ((s * 2 + h) * 16 + (r & 15)) * 16);
+            c[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, x[t][s], c[t], 0, 0, 0);
+        }
+    }
+}
+
+// argmax of outputs 0..3 (rotation) and of outputs 4..13 (location), lowest index on ties, NaN never wins; the two
+// lane halves of a board exchange their location candidates.  Every lane of the pair returns the action.
+__device__ __forceinline__ uint32_t pick_action(const f32x16& c, int h) {
+    float rv = -INFINITY; int ri = 0;                    // rotation: all four live on the h = 0 lane
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (c[k] > rv) { rv = c[k]; ri = k; }
+    float lv = -INFINITY; int li = 99;                   // location candidates of this lane, ascending index
+    if (h == 1) {                                        // outputs 4..7 -> loc 0..3, outputs 12, 13 -> loc 8, 9
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (c[k] > lv) { lv = c[k]; li = k; }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (c[4 + k] > lv) { lv = c[4 + k]; li = 8 + k; }
+    } else {                                             // outputs 8..11 -> loc 4..7
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (c[4 + k] > lv) { lv = c[4 + k]; li = 4 + k; }
+    }
+    const float ov = __shfl_xor(lv, 32);
+    const int oi = __shfl_xor(li, 32);
+    if (ov > lv || (ov == lv && oi < li)) { lv = ov; li = oi; }
+    if (li == 99) li = 0;
+    const int partner_ri = __shfl_xor(ri, 32);           // (shuffles stay outside any lane-dependent branch)
+    const int rot = h == 0 ? ri : partner_ri;            // the h = 1 lane takes the rotation from its partner
+    return (uint32_t)(rot * 10 + li);
+}
+
+template <int kNt, int kThreads>
+__global__ __launch_bounds__(kThreads, kThreads / 256) void policy_kernel(const PolicyArgs p) {
+    __shared__ uint4 s_image[kImageBytes / 16];
+    load_image<kThreads>(s_image, p.image);
+    const uint8_t* lds = (const uint8_t*)s_image;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     constexpr int kWaves = kThreads / 64;
     const int64_t tiles = (p.n + 32 * kNt - 1) / (32 * kNt);
     for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += (int64_t)gridDim.x * kWaves) {
-        // ---- the lane's boards -> cell bit vector (internal order: bit 20x + y) and the extra features
         uint32_t cw[kNt][7];
         uint32_t lm[kNt];
         bool valid[kNt];
@@ -234,111 +346,116 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void policy_kernel(const 
                 for (int c = 0; c < kCols; ++c) s.c[c] = 0;
                 s.window = 0x3FFFFFFFu; s.state = 0; s.lines = 0; s.moves = 0; s.episode = 0;
             }
-            cw[t][0] = s.c[0] | (s.c[1] << 20);
-            cw[t][1] = (s.c[1] >> 12) | (s.c[2] << 8) | (s.c[3] << 28);
-            cw[t][2] = (s.c[3] >> 4) | (s.c[4] << 16);
-            cw[t][3] = (s.c[4] >> 16) | (s.c[5] << 4) | (s.c[6] << 24);
-            cw[t][4] = (s.c[6] >> 8) | (s.c[7] << 12);
-            cw[t][5] = s.c[8] | (s.c[9] << 20);
-            const uint32_t cur = s.window & 7u, nxt = (s.window >> 3) & 7u;
-            cw[t][6] = (s.c[9] >> 12) | ((1u << (8 + cur)) & 0x7F00u) | ((1u << (15 + nxt)) & 0x3F8000u) |
-                       (s.state != ST_RUNNING ? 1u << 24 : 0u);
-            lm[t] = pack_bf16((float)(p.L - (int)s.lines), (float)(p.M - (int)s.moves));   // features 214, 215
+            board_features(s, p.L, p.M, cw[t], lm[t]);
         }
-
-        // ---- layer 1: 224 (217) -> 128, B fragments made from bits on the fly
-        bf16x8 x[kNt][kKsH];
-        {
-            f32x16 acc[kMt][kNt];
-#pragma unroll
-            for (int m = 0; m < kMt; ++m) {
-                const f32x16 b = bias_tile(bias, m, h);
-#pragma unroll
-                for (int t = 0; t < kNt; ++t) acc[m][t] = b;
-            }
-#pragma unroll
-            for (int s = 0; s < kKs1; ++s) {
-                bf16x8 bf[kNt];
-#pragma unroll
-                for (int t = 0; t < kNt; ++t) {
-                    const uint32_t half16 = (cw[t][s >> 1] >> ((s & 1) * 16)) >> (4 * h);
-                    uint4 q;
-                    q.x = bits_to_bf16x2(half16);            // k = 16s + 4h + {0,1}
-                    q.y = bits_to_bf16x2(half16 >> 2);       //                 {2,3}
-                    q.z = bits_to_bf16x2(half16 >> 8);       // k = 16s + 8 + 4h + {0,1}
-                    q.w = bits_to_bf16x2(half16 >> 10);
-                    if (s == 13 && h == 1) q.y = lm[t];      // k = 214, 215: L_rem, M_rem
-                    bf[t] = __builtin_bit_cast(bf16x8, q);
-                }
-#pragma unroll
-                for (int m = 0; m < kMt; ++m) {
-                    const bf16x8 a = *(const bf16x8*)(lds + kOffW1 + ((m * kKs1 + s) * 64 + lane) * 16);
-#pragma unroll
-                    for (int t = 0; t < kNt; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf[t], acc[m][t], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int m = 0; m < kMt; ++m)
-#pragma unroll
-                for (int t = 0; t < kNt; ++t) tile_to_frags(acc[m][t], x[t][2 * m], x[t][2 * m + 1]);
-        }
-
-        // ---- layers 2-4
-        hidden_layer<kNt>(lds, kOffW2, bias + 1 * kHidden, lane, h, x);
-        hidden_layer<kNt>(lds, kOffW3, bias + 2 * kHidden, lane, h, x);
-        hidden_layer<kNt>(lds, kOffW4, bias + 3 * kHidden, lane, h, x);
-
-        // ---- layer 5: 128 -> 14 (rows 0..13 of one tile; lanes of rows 16..31 re-read rows 0..15, unused)
+        f32x16 c[kNt];
+        policy_logits<kNt>(lds, lane, h, r, cw, lm, c);
 #pragma unroll
         for (int t = 0; t < kNt; ++t) {
-            f32x16 c;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (g < 2) b = *(const float4*)(bias + 4 * kHidden + 8 * g + 4 * h);
-                c[4 * g + 0] = b.x; c[4 * g + 1] = b.y; c[4 * g + 2] = b.z; c[4 * g + 3] = b.w;
-            }
-#pragma unroll
-            for (int s = 0; s < kKsH; ++s) {
-                const bf16x8 a = *(const bf16x8*)(lds + kOffW5 + ((s * 2 + h) * 16 + (r & 15)) * 16);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, x[t][s], c, 0, 0, 0);
-            }
-            // this lane holds outputs 4h + {0..3} in c[0..3] and 8 + 4h + {0..3} in c[4..7] of board (tile, t, r)
             const int64_t b = tile * (32 * kNt) + t * 32 + r;
             if (p.logits && valid[t]) {
                 float* o = p.logits + b * kOut;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[4 * h + k] = c[k];
+                for (int k = 0; k < 4; ++k) o[4 * h + k] = c[t][k];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (8 + 4 * h + k < kOut) o[8 + 4 * h + k] = c[4 + k];
+                    if (8 + 4 * h + k < kOut) o[8 + 4 * h + k] = c[t][4 + k];
             }
-            // argmax of outputs 0..3 (rotation) and of outputs 4..13 (location), lowest index on ties, NaN never wins
-            float rv = -INFINITY; int ri = 0;                // rotation: all four live on the h = 0 lane
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (c[k] > rv) { rv = c[k]; ri = k; }
-            float lv = -INFINITY; int li = 99;               // location candidates of this lane, ascending index
-            if (h == 1) {                                    // outputs 4..7 -> loc 0..3, outputs 12, 13 -> loc 8, 9
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (c[k] > lv) { lv = c[k]; li = k; }
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-                    if (c[4 + k] > lv) { lv = c[4 + k]; li = 8 + k; }
-            } else {                                         // outputs 8..11 -> loc 4..7
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (c[4 + k] > lv) { lv = c[4 + k]; li = 4 + k; }
-            }
-            const float ov = __shfl_xor(lv, 32);
-            const int oi = __shfl_xor(li, 32);
-            if (ov > lv || (ov == lv && oi < li)) { lv = ov; li = oi; }
-            if (li == 99) li = 0;
-            if (h == 0 && valid[t]) p.action[b] = (uint8_t)(ri * 10 + li);
+            const uint32_t action = pick_action(c[t], h);
+            if (h == 0 && valid[t]) p.action[b] = (uint8_t)action;
         }
     }
+}
+
+// epsilon-greedy exploration, keyed by (seed, global board, global step): with probability eps_q24 / 2^24 the
+// action is replaced by a uniform one in [0, 40)
+__device__ __forceinline__ uint32_t explore(uint32_t action, uint64_t seed, uint64_t g, uint32_t step, uint32_t eps_q24) {
+    uint32_t u = fmix32((uint32_t)g ^ ((uint32_t)(g >> 32) * 0x9E3779B9u) ^ (uint32_t)seed ^ 0x51ED270Bu);
+    u = fmix32(u + step * 0x9E3779B1u + (uint32_t)(seed >> 32));
+    return (u >> 8) < eps_q24 ? ((u & 0xFFu) * 40u) >> 8 : action;
+}
+
+__global__ __launch_bounds__(kBlock) void explore_kernel(uint8_t* action, int64_t n, uint64_t seed, int64_t global_offset,
+                                                        uint32_t step, uint32_t eps_q24) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) action[i] = (uint8_t)explore(action[i], seed, (uint64_t)(global_offset + i), step, eps_q24);
+}
+
+// T iterations of (policy -> epsilon-greedy -> step) in ONE launch: weights stay in LDS, boards stay in
+// registers, nothing but the trajectory leaves the chip.  Exactly T x (tpl_policy_act, tpl_explore_actions,
+// tpl_step).  One wave owns 32 boards; the two lane halves of a board carry identical copies of its state and
+// advance it identically, the h = 0 half writes.
+struct ActorArgs {
+    StepArgs s;
+    const uint4* image;
+    uint32_t T, step0, eps_q24;
+    uint64_t explore_seed;
+    uint8_t* actions;           // [T][n] or null
+    float* rewards;             // [T][n] or null
+    uint8_t* dones;             // [T][n] or null
+    uint4* states_a;            // [T][n] or null: plane-A word of the board BEFORE step t (the observation)
+    uint4* states_b;            // [T][n] or null
+};
+
+template <bool kAutoReset>
+__global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q) {
+    const StepArgs& p = q.s;
+    __shared__ uint4 s_image[kImageBytes / 16];
+    __shared__ ShapeWord s_shape[32];
+    __shared__ uint32_t s_stat[4];
+    if (threadIdx.x < 32) s_shape[threadIdx.x] = kShapeTable[threadIdx.x];
+    if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
+    load_image<512>(s_image, q.image);
+    const uint8_t* lds = (const uint8_t*)s_image;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t tiles = (p.n + 31) / 32;
+    Tally tally;
+    for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < tiles; tile += (int64_t)gridDim.x * 8) {
+        const int64_t b = tile * 32 + r;
+        const bool valid = b < p.n;
+        Board s;
+        if (valid) {
+            unpack_board(p.plane_a[b], p.plane_b[b], s);
+        } else {
+#pragma unroll
+            for (int c = 0; c < kCols; ++c) s.c[c] = 0;
+            s.window = 0x3FFFFFFFu; s.state = ST_LOST_LIMIT; s.lines = 0; s.moves = 0; s.episode = 0;   // frozen filler
+        }
+        for (uint32_t t = 0; t < q.T; ++t) {
+            if (q.states_a && valid && h == 0) {
+                uint4 A, B;
+                pack_board(s, A, B);
+                q.states_a[(size_t)t * p.n + b] = A;
+                q.states_b[(size_t)t * p.n + b] = B;
+            }
+            uint32_t cw[1][7], lm[1];
+            board_features(s, (int)p.L, (int)p.M, cw[0], lm[0]);
+            f32x16 c[1];
+            policy_logits<1>(lds, lane, h, r, cw, lm, c);
+            uint32_t action = pick_action(c[0], h);
+            action = explore(action, q.explore_seed, (uint64_t)(p.global_offset + b), q.step0 + t, q.eps_q24);
+            const uint32_t rot = action / 10u, loc = action - rot * 10u;
+            float reward;
+            Tally mine;                                  // only the h = 0 copy of a board counts its episodes
+            const bool done = advance_board<kAutoReset>(s, rot, loc, p, (uint32_t)b, s_shape, reward, mine);
+            if (valid && h == 0) {
+                tally.episodes += mine.episodes; tally.lines += mine.lines;
+                tally.wins += mine.wins; tally.topouts += mine.topouts;
+                if (q.actions) q.actions[(size_t)t * p.n + b] = (uint8_t)action;
+                if (q.rewards) q.rewards[(size_t)t * p.n + b] = reward;
+                if (q.dones) q.dones[(size_t)t * p.n + b] = done ? 1 : 0;
+            }
+        }
+        if (valid && h == 0) {
+            uint4 A, B;
+            pack_board(s, A, B);
+            p.plane_a[b] = A;
+            p.plane_b[b] = B;
+        }
+    }
+    flush_tally(tally, s_stat, p.stats);
 }
 
 }  // namespace tpl
@@ -361,6 +478,42 @@ extern "C" int tpl_policy_act(tpl_env* e, const void* image, uint8_t* action, fl
         const int64_t groups = ((e->n + 31) / 32 + 7) / 8;
         hipLaunchKernelGGL((policy_kernel<1, 512>), dim3((unsigned)(groups < 256 ? groups : 256)), dim3(512), 0, (hipStream_t)stream, p);
     }
+    TPL_HIP(hipGetLastError());
+    return TPL_OK;
+}
+
+extern "C" int tpl_explore_actions(tpl_env* e, uint8_t* action, float epsilon, uint64_t seed, uint32_t step, void* stream) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!action) return fail_msg(TPL_ERR_ARG, "action is null");
+    if (!(epsilon >= 0.0f && epsilon <= 1.0f)) return fail_msg(TPL_ERR_ARG, "epsilon must be in [0, 1]");
+    DeviceGuard guard(e->device);
+    const uint32_t eps_q24 = (uint32_t)(epsilon * 16777216.0f);
+    hipLaunchKernelGGL(explore_kernel, dim3((unsigned)((e->n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       action, e->n, seed, e->global_offset, step, eps_q24);
+    TPL_HIP(hipGetLastError());
+    return TPL_OK;
+}
+
+extern "C" int tpl_actor_rollout(tpl_env* e, const void* image, int32_t num_steps, float epsilon, uint64_t seed, uint32_t step0,
+                                 uint8_t* actions, float* rewards, uint8_t* dones, void* states_a, void* states_b,
+                                 void* stream) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!image) return fail_msg(TPL_ERR_ARG, "image is null");
+    if (((uintptr_t)image & 15u) != 0) return fail_msg(TPL_ERR_ARG, "image must be 16-byte aligned");
+    if (num_steps < 1) return fail_msg(TPL_ERR_ARG, "num_steps must be >= 1");
+    if (!(epsilon >= 0.0f && epsilon <= 1.0f)) return fail_msg(TPL_ERR_ARG, "epsilon must be in [0, 1]");
+    if ((states_a == nullptr) != (states_b == nullptr)) return fail_msg(TPL_ERR_ARG, "states_a and states_b go together");
+    if (e->auto_reset && e->pool.n_cfg == 0) return fail_msg(TPL_ERR_STATE, "auto_reset needs tpl_load_configs first");
+    DeviceGuard guard(e->device);
+    ActorArgs q{};
+    q.s = make_args(e);
+    q.image = (const uint4*)image; q.T = (uint32_t)num_steps; q.step0 = step0;
+    q.eps_q24 = (uint32_t)(epsilon * 16777216.0f); q.explore_seed = seed;
+    q.actions = actions; q.rewards = rewards; q.dones = dones; q.states_a = (uint4*)states_a; q.states_b = (uint4*)states_b;
+    const int64_t groups = ((e->n + 31) / 32 + 7) / 8;
+    const dim3 grid((unsigned)(groups < 256 ? groups : 256)), block(512);
+    if (e->auto_reset) hipLaunchKernelGGL(actor_rollout_kernel<true>, grid, block, 0, (hipStream_t)stream, q);
+    else hipLaunchKernelGGL(actor_rollout_kernel<false>, grid, block, 0, (hipStream_t)stream, q);
     TPL_HIP(hipGetLastError());
     return TPL_OK;
 }

@@ -2,6 +2,7 @@
 // gfx950 only.  The per-lane move lives in tpl_device.h; this file holds the kernels around it, the handle
 // and the extern "C" entry points.  Citations "(:NNN)" are lines of the reference's game/tetris.py.
 #include "tpl_internal.h"
+#include "tpl_step.h"
 
 #include <hip/hip_bf16.h>
 
@@ -29,45 +30,6 @@ static inline int piece_words(int M) { return (M + 2 + kWindowStride - 1) / kWin
 static inline size_t record_stride(int M) { return align_up(32 + 4 * (size_t)(piece_words(M) - 1), 64); }
 
 // ---------------------------------------------------------------------------------------------- kernels
-struct StepArgs {
-    uint4* plane_a;
-    uint4* plane_b;
-    int64_t n;
-    uint32_t L, M;
-    const void* act0;          // action, or rot
-    const void* act1;          // loc (move form) or null (action form)
-    int32_t dtype;
-    float* reward;
-    uint8_t* done;
-    uint8_t* cleared;
-    float r_line, r_win, r_lose;
-    // configuration pool (auto-reset, window refills)
-    const uint8_t* pool;
-    uint32_t stride;
-    uint32_t n_cfg;
-    int32_t assign_mode;
-    uint64_t seed;
-    int64_t global_offset;
-    uint32_t offset_mod;       // global_offset mod n_cfg
-    unsigned long long* stats;
-};
-
-__device__ __forceinline__ uint32_t load_int(const void* p, int32_t dtype, int64_t i) {
-    if (dtype == TPL_U8) return ((const uint8_t*)p)[i];
-    if (dtype == TPL_I32) return (uint32_t)((const int32_t*)p)[i];
-    return (uint32_t)((const long long*)p)[i];
-}
-
-// (re)initialise a board from pool entry `cfg`.  reset()/load_warm_reset() (:438-449), with the counters
-// zeroed; the record's two state words are one 32-B read.
-__device__ __forceinline__ void load_config(const uint8_t* pool, uint32_t stride, uint32_t cfg, uint32_t episode,
-                                            uint4& A, uint4& B) {
-    const uint4* rec = (const uint4*)(pool + (size_t)cfg * stride);
-    A = rec[0];
-    const uint4 pb = rec[1];
-    B = make_uint4(pb.x, pb.y | ((episode >> 4) << 28), pb.z | (episode << 28), pb.w);
-}
-
 // One Tetris.move per board (:354-422).  ACTION form: act0 = rot*10+loc; MOVE form: act0 = rot, act1 = loc.
 // Each lane owns kBpl boards (block-strided, so every load is still 1 KiB per wave); all their loads are
 // issued before the first move is computed.
@@ -201,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
     if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
     __syncthreads();
 
-    uint32_t t_eps = 0, t_lines = 0, t_wins = 0, t_tops = 0;
+    Tally tally;
     if (valid) {
         Board s;
         unpack_board(A, B, s);
@@ -211,37 +173,8 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
             uint32_t act_next = 0;
             if (k + 1 < q.K) act_next = q.actions[(size_t)(k + 1) * q.action_stride + i];
             const uint32_t rot = act / 10u, loc = act - rot * 10u;
-            float reward = 0.0f;
-            bool done = true;
-            if (s.state == ST_RUNNING) {
-                const uint32_t cursor = s.moves + 1u;
-                const bool refill = (cursor & (uint32_t)(kWindowStride - 1)) == 0u && p.n_cfg != 0u;
-                uint32_t word = 0;
-                if (refill) {
-                    const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, s.episode, p.seed, p.n_cfg, p.assign_mode);
-                    word = *(const uint32_t*)(p.pool + (size_t)cfg * p.stride + 32u + 4u * ((cursor >> 3) - 1u));
-                }
-                bool topout;
-                const uint32_t n_clear = move_board(s, s_shape, rot, loc, p.L, p.M, topout);
-                s.window = refill ? word : (s.window >> 3);
-                reward = p.r_line * (float)n_clear;
-                if (s.state == ST_WON) reward = reward + p.r_win;
-                if (s.state >= ST_LOST_LIMIT) reward = reward + p.r_lose;
-                done = s.state != ST_RUNNING;
-                if (done) {
-                    t_eps += 1u;
-                    t_lines += s.lines;
-                    t_wins += s.state == ST_WON ? 1u : 0u;
-                    t_tops += s.state == ST_LOST_TOPOUT ? 1u : 0u;
-                    if (kAutoReset) {
-                        const uint32_t ep = (s.episode + 1u) & 0xFFu;
-                        const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, ep, p.seed, p.n_cfg, p.assign_mode);
-                        uint4 A2, B2;
-                        load_config(p.pool, p.stride, cfg, ep, A2, B2);
-                        unpack_board(A2, B2, s);
-                    }
-                }
-            }
+            float reward;
+            const bool done = advance_board<kAutoReset>(s, rot, loc, p, (uint32_t)i, s_shape, reward, tally);
             rsum = rsum + reward;
             if (q.reward_steps) q.reward_steps[(size_t)k * p.n + i] = reward;
             if (q.done_steps) q.done_steps[(size_t)k * p.n + i] = done ? 1 : 0;
@@ -251,21 +184,9 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
         p.plane_a[i] = A;
         p.plane_b[i] = B;
         if (q.reward_sum) q.reward_sum[i] = rsum;
-        if (q.finished) q.finished[i] = t_eps;
+        if (q.finished) q.finished[i] = tally.episodes;
     }
-    if (t_eps) {
-        atomicAdd(&s_stat[0], t_eps);
-        if (t_lines) atomicAdd(&s_stat[1], t_lines);
-        if (t_wins) atomicAdd(&s_stat[2], t_wins);
-        if (t_tops) atomicAdd(&s_stat[3], t_tops);
-    }
-    if (__syncthreads_or(t_eps ? 1 : 0)) {
-        if (threadIdx.x < 4) {
-            const uint32_t v = s_stat[threadIdx.x];
-            if (v) atomicAdd(&p.stats[(size_t)(blockIdx.x % kStatShards) * kStatStride + threadIdx.x],
-                             (unsigned long long)v);
-        }
-    }
+    flush_tally(tally, s_stat, p.stats);
 }
 
 // Tetris.reset() (:438-443) for every board (mask == null, episode 0) or the masked ones (next episode).
@@ -475,18 +396,6 @@ __global__ __launch_bounds__(kBlock) void synth_actions_kernel(uint64_t seed, in
 }
 
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
-
-static StepArgs make_args(const tpl_env* e) {
-    StepArgs a{};
-    a.plane_a = e->plane_a; a.plane_b = e->plane_b;
-    a.n = e->n; a.L = (uint32_t)e->L; a.M = (uint32_t)e->M;
-    a.r_line = e->r_line; a.r_win = e->r_win; a.r_lose = e->r_lose;
-    a.pool = e->pool.rec; a.stride = e->pool.stride;
-    a.n_cfg = (uint32_t)e->pool.n_cfg; a.assign_mode = e->assign_mode; a.seed = e->seed;
-    a.global_offset = e->global_offset; a.stats = e->stats;
-    a.offset_mod = e->pool.n_cfg ? (uint32_t)((uint64_t)e->global_offset % (uint64_t)e->pool.n_cfg) : 0u;
-    return a;
-}
 
 template <int kBpl, int kThreads>
 static void launch_step_cfg(bool action_form, bool auto_reset, const StepArgs& a, hipStream_t stream) {

@@ -1,0 +1,119 @@
+// tpl_step.h -- device-side pieces shared by the kernels that advance boards (step, rollout, actor rollout).
+#pragma once
+
+#include "tpl_internal.h"
+
+namespace tpl {
+
+struct StepArgs {
+    uint4* plane_a;
+    uint4* plane_b;
+    int64_t n;
+    uint32_t L, M;
+    const void* act0;          // action, or rot
+    const void* act1;          // loc (move form) or null (action form)
+    int32_t dtype;
+    float* reward;
+    uint8_t* done;
+    uint8_t* cleared;
+    float r_line, r_win, r_lose;
+    // configuration pool (auto-reset, window refills)
+    const uint8_t* pool;
+    uint32_t stride;
+    uint32_t n_cfg;
+    int32_t assign_mode;
+    uint64_t seed;
+    int64_t global_offset;
+    uint32_t offset_mod;       // global_offset mod n_cfg
+    unsigned long long* stats;
+};
+
+// host: the arguments every board-advancing kernel takes from the handle
+inline StepArgs make_args(const tpl_env* e) {
+    StepArgs a{};
+    a.plane_a = e->plane_a; a.plane_b = e->plane_b;
+    a.n = e->n; a.L = (uint32_t)e->L; a.M = (uint32_t)e->M;
+    a.r_line = e->r_line; a.r_win = e->r_win; a.r_lose = e->r_lose;
+    a.pool = e->pool.rec; a.stride = e->pool.stride;
+    a.n_cfg = (uint32_t)e->pool.n_cfg; a.assign_mode = e->assign_mode; a.seed = e->seed;
+    a.global_offset = e->global_offset; a.stats = e->stats;
+    a.offset_mod = e->pool.n_cfg ? (uint32_t)((uint64_t)e->global_offset % (uint64_t)e->pool.n_cfg) : 0u;
+    return a;
+}
+
+__device__ __forceinline__ uint32_t load_int(const void* p, int32_t dtype, int64_t i) {
+    if (dtype == TPL_U8) return ((const uint8_t*)p)[i];
+    if (dtype == TPL_I32) return (uint32_t)((const int32_t*)p)[i];
+    return (uint32_t)((const long long*)p)[i];
+}
+
+// (re)initialise a board from pool entry `cfg`.  reset()/load_warm_reset() (:438-449), with the counters
+// zeroed; the record's two state words are one 32-B read.
+__device__ __forceinline__ void load_config(const uint8_t* pool, uint32_t stride, uint32_t cfg, uint32_t episode,
+                                            uint4& A, uint4& B) {
+    const uint4* rec = (const uint4*)(pool + (size_t)cfg * stride);
+    A = rec[0];
+    const uint4 pb = rec[1];
+    B = make_uint4(pb.x, pb.y | ((episode >> 4) << 28), pb.z | (episode << 28), pb.w);
+}
+
+// episodes a lane finished, accumulated in registers across the steps of one launch
+struct Tally { uint32_t episodes = 0, lines = 0, wins = 0, topouts = 0; };
+
+// One step of one unpacked board held in registers: Tetris.move (:354-422) + the window pop/refill + the
+// build's freeze / auto-reset rules + reward.  Returns done (state != running after the move, before a reset).
+template <bool kAutoReset>
+__device__ __forceinline__ bool advance_board(Board& s, uint32_t rot, uint32_t loc, const StepArgs& p, uint32_t i,
+                                              const ShapeWord* shape, float& reward, Tally& tally) {
+    reward = 0.0f;
+    if (s.state != ST_RUNNING) return true;      // frozen
+    // pieces.pop(0) (:356) moves the cursor to moves_used + 1 whatever the move does; at a multiple of eight the
+    // window is down to its last two entries and piece word cursor/8 replaces it (gather issued before the move)
+    const uint32_t cursor = s.moves + 1u;
+    const bool refill = (cursor & (uint32_t)(kWindowStride - 1)) == 0u && p.n_cfg != 0u;
+    uint32_t word = 0;
+    if (refill) {
+        const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, i, s.episode, p.seed, p.n_cfg, p.assign_mode);
+        word = *(const uint32_t*)(p.pool + (size_t)cfg * p.stride + 32u + 4u * ((cursor >> 3) - 1u));
+    }
+    bool topout;
+    const uint32_t n_clear = move_board(s, shape, rot, loc, p.L, p.M, topout);
+    s.window = refill ? word : (s.window >> 3);
+    reward = p.r_line * (float)n_clear;
+    if (s.state == ST_WON) reward = reward + p.r_win;
+    if (s.state >= ST_LOST_LIMIT) reward = reward + p.r_lose;
+    const bool done = s.state != ST_RUNNING;
+    if (done) {
+        tally.episodes += 1u;
+        tally.lines += s.lines;
+        tally.wins += s.state == ST_WON ? 1u : 0u;
+        tally.topouts += s.state == ST_LOST_TOPOUT ? 1u : 0u;
+        if (kAutoReset) {
+            const uint32_t ep = (s.episode + 1u) & 0xFFu;
+            const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, i, ep, p.seed, p.n_cfg, p.assign_mode);
+            uint4 A2, B2;
+            load_config(p.pool, p.stride, cfg, ep, A2, B2);
+            unpack_board(A2, B2, s);
+        }
+    }
+    return done;
+}
+
+// block-level flush of the lanes' tallies: LDS atomics, then one sharded 64-bit global atomic per counter.
+// Every thread of the block must call it (it contains a barrier); s_stat[4] must have been zeroed before.
+__device__ __forceinline__ void flush_tally(const Tally& t, uint32_t* s_stat, unsigned long long* stats) {
+    if (t.episodes) {
+        atomicAdd(&s_stat[0], t.episodes);
+        if (t.lines) atomicAdd(&s_stat[1], t.lines);
+        if (t.wins) atomicAdd(&s_stat[2], t.wins);
+        if (t.topouts) atomicAdd(&s_stat[3], t.topouts);
+    }
+    if (__syncthreads_or(t.episodes ? 1 : 0)) {
+        if (threadIdx.x < 4) {
+            const uint32_t v = s_stat[threadIdx.x];
+            if (v) atomicAdd(&stats[(size_t)(blockIdx.x % kStatShards) * kStatStride + threadIdx.x], (unsigned long long)v);
+        }
+    }
+}
+
+}  // namespace tpl

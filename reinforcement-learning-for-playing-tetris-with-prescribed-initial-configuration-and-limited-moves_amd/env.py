@@ -236,6 +236,40 @@ class BatchedTetris:
         check(self._lib.tpl_policy_act(self._h, _ptr(image), _ptr(out), _ptr(logits), self._stream()))
         return out
 
+    def explore_actions(self, action: torch.Tensor, epsilon: float, seed: int = 0, step: int = 0) -> torch.Tensor:
+        """Epsilon-greedy in place: action[i] becomes uniform in [0, 40) with probability epsilon."""
+        check(self._lib.tpl_explore_actions(self._h, _ptr(action), float(epsilon), int(seed), int(step), self._stream()))
+        return action
+
+    def actor_rollout(self, image: torch.Tensor, steps: int, epsilon: float = 0.0, seed: int = 0, step0: int = 0,
+                      record: bool = True, record_states: bool = False) -> dict:
+        """`steps` iterations of policy -> epsilon-greedy -> step in one kernel launch (weights in LDS, boards in
+        registers).  Returns the trajectory: actions/rewards/dones [steps, N] and, if asked, the 32-byte state of
+        every board before each step as two int32 [steps, N, 4] tensors."""
+        n, d = self.num_envs, self.device
+        out = {}
+        if record:
+            out["actions"] = torch.empty((steps, n), dtype=torch.uint8, device=d)
+            out["rewards"] = torch.empty((steps, n), dtype=torch.float32, device=d)
+            out["dones"] = torch.empty((steps, n), dtype=torch.uint8, device=d)
+        if record_states:
+            out["states_a"] = torch.empty((steps, n, 4), dtype=torch.int32, device=d)
+            out["states_b"] = torch.empty((steps, n, 4), dtype=torch.int32, device=d)
+        check(self._lib.tpl_actor_rollout(self._h, _ptr(image), int(steps), float(epsilon), int(seed), int(step0),
+                                          _ptr(out.get("actions")), _ptr(out.get("rewards")), _ptr(out.get("dones")),
+                                          _ptr(out.get("states_a")), _ptr(out.get("states_b")), self._stream()))
+        if record:
+            out["dones"] = out["dones"].view(torch.bool)
+        return out
+
+    def raw_planes(self):
+        """Copies of the two resident state planes, int32 [N, 4] each (layout in DESIGN.md section 2)."""
+        n = self.num_envs
+        stride = (n * 16 + 255) // 256 * 256
+        a = self._workspace[: n * 16].view(torch.int32).view(n, 4).clone()
+        b = self._workspace[stride: stride + n * 16].view(torch.int32).view(n, 4).clone()
+        return a, b
+
     def packed_state(self) -> dict:
         """Everything get_state() and the public attributes expose, in the interchange layout (device tensors)."""
         n, d = self.num_envs, self.device
