@@ -184,7 +184,21 @@ def main():
             torch.cuda.synchronize(dev)
             ms = a0.elapsed_time(a1) / iters
             actor[name] = {"value": na / (ms * 1e-3), "ms_per_step": ms}
-        actor["value"] = actor["fused_mfma_kernel"]["value"]
+        # T iterations per launch (tpl_actor_rollout): weights stay in LDS, boards in registers; trajectory written
+        image = T.actor.policy_image(T.PolicyMLP(), dev)
+        Tm = 50
+        aenv.actor_rollout(image, Tm)
+        torch.cuda.synchronize(dev)
+        m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        m0.record()
+        for _ in range(6):
+            aenv.actor_rollout(image, Tm)
+        m1.record()
+        torch.cuda.synchronize(dev)
+        ms = m0.elapsed_time(m1) / (6 * Tm)
+        actor["megakernel"] = {"value": na / (ms * 1e-3), "ms_per_step": ms, "steps_per_launch": Tm,
+                               "outputs": "per-step action u8 + reward f32 + done u8 written"}
+        actor["value"] = actor["megakernel"]["value"]
         # the policy kernel alone, priced against the dense bf16 MFMA peak: FLOPs it issues per board (K padded to
         # 224, the 14-row head run as one 32-row tile) over its own duration
         image = act.image if act.image is not None else T.actor.policy_image(T.PolicyMLP(), dev)

@@ -125,7 +125,7 @@ def lib() -> C.CDLL:
     L.tpl_policy_image_bytes.argtypes = []
     L.tpl_policy_pack.argtypes = [vp] * 11
     L.tpl_policy_act.argtypes = [vp, vp, vp, vp, vp]
-    L.tpl_set_policy_tuning.argtypes = [vp, i32]
+    L.tpl_set_policy_tuning.argtypes = [vp, i32, i32]
     L.tpl_explore_actions.argtypes = [vp, vp, f32, u64, C.c_uint32, vp]
     L.tpl_actor_rollout.argtypes = [vp, vp, i32, f32, u64, C.c_uint32, vp, vp, vp, vp, vp, vp]
     L.tpl_get_stats.argtypes = [vp, vp, vp]

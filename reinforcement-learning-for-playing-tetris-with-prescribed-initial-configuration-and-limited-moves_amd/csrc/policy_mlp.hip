@@ -136,19 +136,39 @@ struct PolicyArgs {
     const uint4* image;     // packed weights, kImageBytes
     uint8_t* action;        // [n]
     float* logits;          // [n][14] or null
+    uint32_t stagger;       // waves 4..7 of a 512-thread workgroup start this many x 1024 cycles late
 };
 
-// relu + convert an accumulator tile to the two B fragments it provides to the next layer
+// Two waves that share a SIMD and run the same program fall into lockstep: both in their MFMA loops, then both
+// in their VALU epilogues, and the two pipes never overlap.  Delaying the second wave of every SIMD (waves 4-7:
+// a workgroup's waves are dealt to the SIMDs round-robin) by a fraction of an iteration puts one wave's VALU
+// phases under the other's MFMA phases.
+__device__ __forceinline__ void stagger_second_wave(int wave, uint32_t units) {
+    if (wave >= 4)
+        for (uint32_t k = 0; k < units; ++k) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles
+}
+
+// ReLU on two packed bf16 values: as signed 16-bit integers a negative bf16 (sign bit set, -0 included) is a
+// negative number, so max(., 0) clears it and leaves non-negative values untouched -- one v_pk_max_i16 per pair,
+// where fmaxf on the f32 accumulators costs two v_max_f32 per VALUE (canonicalise + max).  Rounding to bf16 first
+// and clamping second gives the same result as the other order: rounding never changes the sign.
+typedef __attribute__((ext_vector_type(2))) short i16x2;
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
+    const i16x2 zero = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, v), zero));
+}
+
+// convert an accumulator tile to bf16, apply ReLU, and hand it on as the two B fragments of the next layer
 __device__ __forceinline__ void tile_to_frags(const f32x16& c, bf16x8& f0, bf16x8& f1) {
     uint4 lo, hi;
-    lo.x = pack_bf16(fmaxf(c[0], 0.f), fmaxf(c[1], 0.f));
-    lo.y = pack_bf16(fmaxf(c[2], 0.f), fmaxf(c[3], 0.f));
-    lo.z = pack_bf16(fmaxf(c[4], 0.f), fmaxf(c[5], 0.f));
-    lo.w = pack_bf16(fmaxf(c[6], 0.f), fmaxf(c[7], 0.f));
-    hi.x = pack_bf16(fmaxf(c[8], 0.f), fmaxf(c[9], 0.f));
-    hi.y = pack_bf16(fmaxf(c[10], 0.f), fmaxf(c[11], 0.f));
-    hi.z = pack_bf16(fmaxf(c[12], 0.f), fmaxf(c[13], 0.f));
-    hi.w = pack_bf16(fmaxf(c[14], 0.f), fmaxf(c[15], 0.f));
+    lo.x = relu_bf16x2(pack_bf16(c[0], c[1]));
+    lo.y = relu_bf16x2(pack_bf16(c[2], c[3]));
+    lo.z = relu_bf16x2(pack_bf16(c[4], c[5]));
+    lo.w = relu_bf16x2(pack_bf16(c[6], c[7]));
+    hi.x = relu_bf16x2(pack_bf16(c[8], c[9]));
+    hi.y = relu_bf16x2(pack_bf16(c[10], c[11]));
+    hi.z = relu_bf16x2(pack_bf16(c[12], c[13]));
+    hi.w = relu_bf16x2(pack_bf16(c[14], c[15]));
     f0 = __builtin_bit_cast(bf16x8, lo);
     f1 = __builtin_bit_cast(bf16x8, hi);
 }
@@ -164,31 +184,46 @@ __device__ __forceinline__ f32x16 bias_tile(const float* bias, int m, int h) {
     return c;
 }
 
-// one 128 -> 128 hidden layer on fragments held in registers
-template <int kNt>
-__device__ __forceinline__ void hidden_layer(const uint8_t* lds, int w_off, const float* bias, int lane, int h,
-                                             bf16x8 (&x)[kNt][kKsH]) {
-    f32x16 acc[kMt][kNt];
+// A fragment q of a layer = (output tile m = q / ks, k-step s = q % ks): consecutive fragments are 1 KiB apart
+__device__ __forceinline__ bf16x8 a_frag(const uint8_t* lds, int w_off, int q, int lane) {
+    return *(const bf16x8*)(lds + w_off + (q * 64 + lane) * 16);
+}
+
+// One layer with 128 outputs: xout^T[128 x boards] = relu(W . xin^T + b), both sides as MFMA fragments in registers.
+// Order: output tile m outermost, so that
+//   * tile m's epilogue (bf16 convert + ReLU: VALU) sits in program order BEHIND the MFMAs of tile m+1 and runs
+//     while the matrix pipe works on them (two accumulator tiles alternate);
+//   * the A fragments stream through a four-deep register window: the read of fragment q+4 is issued right behind
+//     the MFMA that consumes fragment q, so an LDS read has four MFMAs (128 pipe cycles) to land.
+// sched_barrier(0) pins that order; left alone the scheduler hoists every LDS read to the top and spills.
+template <int kNt, int kKs>
+__device__ __forceinline__ void dense128(const uint8_t* lds, int w_off, const float* bias, int lane, int h,
+                                         const bf16x8 (&xin)[kNt][kKs], bf16x8 (&xout)[kNt][kKsH]) {
+    f32x16 acc[2][kNt];
+    bf16x8 aq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) aq[q] = a_frag(lds, w_off, q, lane);
 #pragma unroll
     for (int m = 0; m < kMt; ++m) {
         const f32x16 b = bias_tile(bias, m, h);
 #pragma unroll
-        for (int t = 0; t < kNt; ++t) acc[m][t] = b;
-    }
+        for (int t = 0; t < kNt; ++t) acc[m & 1][t] = b;
 #pragma unroll
-    for (int s = 0; s < kKsH; ++s) {
+        for (int s = 0; s < kKs; ++s) {
+            const int q = m * kKs + s;
 #pragma unroll
-        for (int m = 0; m < kMt; ++m) {
-            const bf16x8 a = *(const bf16x8*)(lds + w_off + ((m * kKsH + s) * 64 + lane) * 16);
-#pragma unroll
-            for (int t = 0; t < kNt; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, x[t][s], acc[m][t], 0, 0, 0);
+            for (int t = 0; t < kNt; ++t) acc[m & 1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[q & 3], xin[t][s], acc[m & 1][t], 0, 0, 0);
+            if (q + 4 < kMt * kKs) aq[q & 3] = a_frag(lds, w_off, q + 4, lane);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every later A fragment up here (spills)
+        if (m > 0) {
+#pragma unroll
+            for (int t = 0; t < kNt; ++t) tile_to_frags(acc[(m - 1) & 1][t], xout[t][2 * (m - 1)], xout[t][2 * (m - 1) + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #pragma unroll
-    for (int m = 0; m < kMt; ++m)
-#pragma unroll
-        for (int t = 0; t < kNt; ++t) tile_to_frags(acc[m][t], x[t][2 * m], x[t][2 * m + 1]);
+    for (int t = 0; t < kNt; ++t) tile_to_frags(acc[(kMt - 1) & 1][t], xout[t][2 * (kMt - 1)], xout[t][2 * (kMt - 1) + 1]);
 }
 
 // weights -> LDS, eight 16-B loads in flight per thread (a load-store-load-store loop would pay the L2 latency
@@ -233,47 +268,28 @@ template <int kNt>
 __device__ __forceinline__ void policy_logits(const uint8_t* lds, int lane, int h, int r, const uint32_t (&cw)[kNt][7],
                                               const uint32_t (&lm)[kNt], f32x16 (&c)[kNt]) {
     const float* bias = (const float*)(lds + kOffB);
-    // ---- layer 1: 224 (217) -> 128, B fragments made from bits on the fly
-    bf16x8 x[kNt][kKsH];
-    {
-        f32x16 acc[kMt][kNt];
+    // ---- layer 1: 224 (217) -> 128; its B fragments are made from the cell bits, once, up front
+    bf16x8 x0[kNt][kKs1];
 #pragma unroll
-        for (int m = 0; m < kMt; ++m) {
-            const f32x16 b = bias_tile(bias, m, h);
-#pragma unroll
-            for (int t = 0; t < kNt; ++t) acc[m][t] = b;
-        }
+    for (int t = 0; t < kNt; ++t)
 #pragma unroll
         for (int s = 0; s < kKs1; ++s) {
-            bf16x8 bf[kNt];
-#pragma unroll
-            for (int t = 0; t < kNt; ++t) {
-                const uint32_t half16 = (cw[t][s >> 1] >> ((s & 1) * 16)) >> (4 * h);
-                uint4 q;
-                q.x = bits_to_bf16x2(half16);            // k = 16s + 4h + {0,1}
-                q.y = bits_to_bf16x2(half16 >> 2);       //                 {2,3}
-                q.z = bits_to_bf16x2(half16 >> 8);       // k = 16s + 8 + 4h + {0,1}
-                q.w = bits_to_bf16x2(half16 >> 10);
-                if (s == 13 && h == 1) q.y = lm[t];      // k = 214, 215: L_rem, M_rem
-                bf[t] = __builtin_bit_cast(bf16x8, q);
-            }
-#pragma unroll
-            for (int m = 0; m < kMt; ++m) {
-                const bf16x8 a = *(const bf16x8*)(lds + kOffW1 + ((m * kKs1 + s) * 64 + lane) * 16);
-#pragma unroll
-                for (int t = 0; t < kNt; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf[t], acc[m][t], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t half16 = (cw[t][s >> 1] >> ((s & 1) * 16)) >> (4 * h);
+            uint4 q;
+            q.x = bits_to_bf16x2(half16);            // k = 16s + 4h + {0,1}
+            q.y = bits_to_bf16x2(half16 >> 2);       //                 {2,3}
+            q.z = bits_to_bf16x2(half16 >> 8);       // k = 16s + 8 + 4h + {0,1}
+            q.w = bits_to_bf16x2(half16 >> 10);
+            if (s == 13 && h == 1) q.y = lm[t];      // k = 214, 215: L_rem, M_rem
+            x0[t][s] = __builtin_bit_cast(bf16x8, q);
         }
-#pragma unroll
-        for (int m = 0; m < kMt; ++m)
-#pragma unroll
-            for (int t = 0; t < kNt; ++t) tile_to_frags(acc[m][t], x[t][2 * m], x[t][2 * m + 1]);
-    }
+    bf16x8 xa[kNt][kKsH], xb[kNt][kKsH];
+    dense128<kNt, kKs1>(lds, kOffW1, bias, lane, h, x0, xa);
     // ---- layers 2-4
-    hidden_layer<kNt>(lds, kOffW2, bias + 1 * kHidden, lane, h, x);
-    hidden_layer<kNt>(lds, kOffW3, bias + 2 * kHidden, lane, h, x);
-    hidden_layer<kNt>(lds, kOffW4, bias + 3 * kHidden, lane, h, x);
+    dense128<kNt, kKsH>(lds, kOffW2, bias + 1 * kHidden, lane, h, xa, xb);
+    dense128<kNt, kKsH>(lds, kOffW3, bias + 2 * kHidden, lane, h, xb, xa);
+    dense128<kNt, kKsH>(lds, kOffW4, bias + 3 * kHidden, lane, h, xa, xb);
+    const bf16x8 (&x)[kNt][kKsH] = xb;
     // ---- layer 5: 128 -> 14 (rows 0..13 of one tile; lanes of rows 16..31 re-read rows 0..15, unused)
 #pragma unroll
     for (int t = 0; t < kNt; ++t) {
@@ -330,6 +346,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void policy_kernel(const 
     const int r = lane & 31, h = lane >> 5;
     constexpr int kWaves = kThreads / 64;
     const int64_t tiles = (p.n + 32 * kNt - 1) / (32 * kNt);
+    stagger_second_wave(wave, p.stagger);
     for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += (int64_t)gridDim.x * kWaves) {
         uint32_t cw[kNt][7];
         uint32_t lm[kNt];
@@ -388,7 +405,7 @@ __global__ __launch_bounds__(kBlock) void explore_kernel(uint8_t* action, int64_
 struct ActorArgs {
     StepArgs s;
     const uint4* image;
-    uint32_t T, step0, eps_q24;
+    uint32_t T, step0, eps_q24, stagger;
     uint64_t explore_seed;
     uint8_t* actions;           // [T][n] or null
     float* rewards;             // [T][n] or null
@@ -412,6 +429,7 @@ __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q
     const int r = lane & 31, h = lane >> 5;
     const int64_t tiles = (p.n + 31) / 32;
     Tally tally;
+    stagger_second_wave(wave, q.stagger);
     for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < tiles; tile += (int64_t)gridDim.x * 8) {
         const int64_t b = tile * 32 + r;
         const bool valid = b < p.n;
@@ -467,7 +485,7 @@ extern "C" int tpl_policy_act(tpl_env* e, const void* image, uint8_t* action, fl
     DeviceGuard guard(e->device);
     PolicyArgs p{};
     p.plane_a = e->plane_a; p.plane_b = e->plane_b; p.n = e->n; p.L = e->L; p.M = e->M;
-    p.image = (const uint4*)image; p.action = action; p.logits = logits;
+    p.image = (const uint4*)image; p.action = action; p.logits = logits; p.stagger = (uint32_t)e->policy_stagger;
     // one resident workgroup per CU (the weights fill its LDS), looping over board tiles.
     // variant 0: 4 waves x 64 boards (one wave per SIMD); variant 1: 8 waves x 32 boards (two per SIMD, so one
     // wave's epilogue overlaps the other's MFMAs)
@@ -508,7 +526,7 @@ extern "C" int tpl_actor_rollout(tpl_env* e, const void* image, int32_t num_step
     ActorArgs q{};
     q.s = make_args(e);
     q.image = (const uint4*)image; q.T = (uint32_t)num_steps; q.step0 = step0;
-    q.eps_q24 = (uint32_t)(epsilon * 16777216.0f); q.explore_seed = seed;
+    q.eps_q24 = (uint32_t)(epsilon * 16777216.0f); q.explore_seed = seed; q.stagger = (uint32_t)e->policy_stagger;
     q.actions = actions; q.rewards = rewards; q.dones = dones; q.states_a = (uint4*)states_a; q.states_b = (uint4*)states_b;
     const int64_t groups = ((e->n + 31) / 32 + 7) / 8;
     const dim3 grid((unsigned)(groups < 256 ? groups : 256)), block(512);
