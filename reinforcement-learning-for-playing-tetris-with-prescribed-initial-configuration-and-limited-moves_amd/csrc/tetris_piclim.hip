@@ -491,7 +491,10 @@ int tpl_create(tpl_env** out, int64_t num_envs, int32_t L, int32_t M, int32_t de
     e->plane_a = (uint4*)base; base += align_up(n * sizeof(uint4), 256);
     e->plane_b = (uint4*)base; base += align_up(n * sizeof(uint4), 256);
     e->stats = (unsigned long long*)base;
-    hipError_t err = hipMemset(e->plane_a, 0, need);   // every board: empty, running, no pieces
+    // every board: empty, running, no pieces.  Synchronised, because the caller's later work may run on a stream
+    // that does not order itself against the null stream.
+    hipError_t err = hipMemset(e->plane_a, 0, need);
+    if (err == hipSuccess) err = hipStreamSynchronize(nullptr);
     if (err != hipSuccess) {
         if (e->owned) (void)hipFree(e->owned);
         delete e;
