@@ -486,6 +486,43 @@ def _popcount(rows):
     return np.unpackbits(r.view(np.uint8), axis=-1).reshape(r.shape[0], -1).sum(1).astype(np.int64)
 
 
+def test_step_is_graph_capturable_and_replays_exactly(T, oracle):
+    """The ABI promises no host synchronisation inside tpl_step: capture 8 steps into one HIP graph, replay it."""
+    import torch
+    L, M, n, seed = 5, 20, 20000, 31
+    gpu = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True)
+    rows, pieces = gpu.synthetic_configs(2048)
+    gpu.load_configs(rows, pieces)
+    gpu.reset()
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
+    cpu.set_options(auto_reset=True, assign_mode=0)
+    cpu.reset()
+    actions = torch.stack([gpu.synthetic_actions(t) for t in range(8)])
+    rewards = torch.zeros((8, n), dtype=torch.float32, device=gpu.device)
+    dones = torch.zeros((8, n), dtype=torch.uint8, device=gpu.device)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        saved = gpu.snapshot()
+        gpu.step_into(actions[0], rewards[0], dones[0])         # warm-up outside the capture
+        gpu.restore(saved)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            for t in range(8):
+                gpu.step_into(actions[t], rewards[t], dones[t])
+    torch.cuda.current_stream().wait_stream(side)
+    for rep in range(3):                                         # the same 8 actions again each replay
+        graph.replay()
+        torch.cuda.synchronize()
+        for t in range(8):
+            r_c, d_c = cpu.step(_np(actions[t]))
+            assert np.array_equal(_np(rewards[t]), r_c) and np.array_equal(_np(dones[t]), d_c), (rep, t)
+    _assert_state_equal(_state(gpu), cpu.get_state(), "graph")
+    gpu.terminate()
+
+
 def test_ragged_sizes_and_errors(T):
     for n in (1, 63, 65, 257):
         env = T.BatchedTetris(4, 9, n, assign="sequential")
