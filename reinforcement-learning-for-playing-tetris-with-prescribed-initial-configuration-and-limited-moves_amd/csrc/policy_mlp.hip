@@ -441,6 +441,7 @@ __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q
             for (int c = 0; c < kCols; ++c) s.c[c] = 0;
             s.window = 0x3FFFFFFFu; s.state = ST_LOST_LIMIT; s.lines = 0; s.moves = 0; s.episode = 0;   // frozen filler
         }
+        uint32_t cfg = current_config(s, p, (uint32_t)b);
         for (uint32_t t = 0; t < q.T; ++t) {
             if (q.states_a && valid && h == 0) {
                 uint4 A, B;
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q
             const uint32_t rot = action / 10u, loc = action - rot * 10u;
             float reward;
             Tally mine;                                  // only the h = 0 copy of a board counts its episodes
-            const bool done = advance_board<kAutoReset>(s, rot, loc, p, (uint32_t)b, s_shape, reward, mine);
+            const bool done = advance_board<kAutoReset>(s, cfg, rot, loc, p, (uint32_t)b, s_shape, reward, mine);
             if (valid && h == 0) {
                 tally.episodes += mine.episodes; tally.lines += mine.lines;
                 tally.wins += mine.wins; tally.topouts += mine.topouts;

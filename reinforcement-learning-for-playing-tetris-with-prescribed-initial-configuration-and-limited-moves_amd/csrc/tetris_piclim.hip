@@ -167,6 +167,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
     if (valid) {
         Board s;
         unpack_board(A, B, s);
+        uint32_t cfg = current_config(s, p, (uint32_t)i);
         float rsum = 0.0f;
         for (uint32_t k = 0; k < q.K; ++k) {
             // next step's action is independent of the board: fetch it under this step's move
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
             if (k + 1 < q.K) act_next = q.actions[(size_t)(k + 1) * q.action_stride + i];
             const uint32_t rot = act / 10u, loc = act - rot * 10u;
             float reward;
-            const bool done = advance_board<kAutoReset>(s, rot, loc, p, (uint32_t)i, s_shape, reward, tally);
+            const bool done = advance_board<kAutoReset>(s, cfg, rot, loc, p, (uint32_t)i, s_shape, reward, tally);
             rsum = rsum + reward;
             if (q.reward_steps) q.reward_steps[(size_t)k * p.n + i] = reward;
             if (q.done_steps) q.done_steps[(size_t)k * p.n + i] = done ? 1 : 0;

@@ -60,11 +60,18 @@ __device__ __forceinline__ void load_config(const uint8_t* pool, uint32_t stride
 // episodes a lane finished, accumulated in registers across the steps of one launch
 struct Tally { uint32_t episodes = 0, lines = 0, wins = 0, topouts = 0; };
 
+// pool entry of the board's current episode (kept in a register by the multi-step kernels: the window refill needs
+// it every eighth move, and hashing it again each time costs more than the refill itself)
+__device__ __forceinline__ uint32_t current_config(const Board& s, const StepArgs& p, uint32_t i) {
+    return p.n_cfg ? assign_config(p.global_offset, p.offset_mod, i, s.episode, p.seed, p.n_cfg, p.assign_mode) : 0u;
+}
+
 // One step of one unpacked board held in registers: Tetris.move (:354-422) + the window pop/refill + the
-// build's freeze / auto-reset rules + reward.  Returns done (state != running after the move, before a reset).
+// build's freeze / auto-reset rules + reward.  `cfg` = current_config() of the board, updated on a reset.
+// Returns done (state != running after the move, before a reset).
 template <bool kAutoReset>
-__device__ __forceinline__ bool advance_board(Board& s, uint32_t rot, uint32_t loc, const StepArgs& p, uint32_t i,
-                                              const ShapeWord* shape, float& reward, Tally& tally) {
+__device__ __forceinline__ bool advance_board(Board& s, uint32_t& cfg, uint32_t rot, uint32_t loc, const StepArgs& p,
+                                              uint32_t i, const ShapeWord* shape, float& reward, Tally& tally) {
     reward = 0.0f;
     if (s.state != ST_RUNNING) return true;      // frozen
     // pieces.pop(0) (:356) moves the cursor to moves_used + 1 whatever the move does; at a multiple of eight the
@@ -72,10 +79,7 @@ __device__ __forceinline__ bool advance_board(Board& s, uint32_t rot, uint32_t l
     const uint32_t cursor = s.moves + 1u;
     const bool refill = (cursor & (uint32_t)(kWindowStride - 1)) == 0u && p.n_cfg != 0u;
     uint32_t word = 0;
-    if (refill) {
-        const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, i, s.episode, p.seed, p.n_cfg, p.assign_mode);
-        word = *(const uint32_t*)(p.pool + (size_t)cfg * p.stride + 32u + 4u * ((cursor >> 3) - 1u));
-    }
+    if (refill) word = *(const uint32_t*)(p.pool + (size_t)cfg * p.stride + 32u + 4u * ((cursor >> 3) - 1u));
     bool topout;
     const uint32_t n_clear = move_board(s, shape, rot, loc, p.L, p.M, topout);
     s.window = refill ? word : (s.window >> 3);
@@ -90,7 +94,7 @@ __device__ __forceinline__ bool advance_board(Board& s, uint32_t rot, uint32_t l
         tally.topouts += s.state == ST_LOST_TOPOUT ? 1u : 0u;
         if (kAutoReset) {
             const uint32_t ep = (s.episode + 1u) & 0xFFu;
-            const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, i, ep, p.seed, p.n_cfg, p.assign_mode);
+            cfg = assign_config(p.global_offset, p.offset_mod, i, ep, p.seed, p.n_cfg, p.assign_mode);
             uint4 A2, B2;
             load_config(p.pool, p.stride, cfg, ep, A2, B2);
             unpack_board(A2, B2, s);
