@@ -144,10 +144,6 @@ int tpl_explore_actions(tpl_env* env, uint8_t* action, float epsilon, uint64_t s
  * resident state of every board BEFORE step t (a 32-byte observation for a replay buffer; layout in DESIGN.md). */
 int tpl_actor_rollout(tpl_env* env, const void* image, int32_t num_steps, float epsilon, uint64_t seed, uint32_t step0,
                       uint8_t* actions, float* rewards, uint8_t* dones, void* states_a, void* states_b, void* stream);
-/* Tuning of the policy kernels: geometry (0: 4 waves x 64 boards per workgroup, 1: 8 waves x 32 boards; default 1)
- * and the start delay of the second wave of each SIMD in units of 1024 cycles (0..64).  Results do not depend
- * on them. */
-int tpl_set_policy_tuning(tpl_env* env, int32_t variant, int32_t stagger);
 
 /* Statistics over episodes finished since the last full reset, reduced on the device into
  * out[4] (device pointer, uint64): {episodes, sum of lines_cleared at finish, wins, top-outs}. */

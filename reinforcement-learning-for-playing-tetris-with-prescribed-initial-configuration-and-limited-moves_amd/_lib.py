@@ -13,7 +13,9 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 _ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_CSRC, "libtetris_piclim.so")
+# development switch: TPL_DIAG_CLOCK=1 builds a diagnostic library whose policy kernel stamps its clocks (tools/policy_clock.py)
+_DIAG = os.environ.get("TPL_DIAG_CLOCK") == "1"
+LIB_PATH = os.path.join(_CSRC, "libtetris_piclim_diag.so" if _DIAG else "libtetris_piclim.so")
 _UNITS = [os.path.join(_CSRC, f) for f in ("tetris_piclim.hip", "carve_generator.hip", "policy_mlp.hip")]
 _SOURCES = _UNITS + [os.path.join(_CSRC, "tpl_device.h"), os.path.join(_CSRC, "tpl_internal.h"),
                      os.path.join(_CSRC, "tpl_step.h"),
@@ -25,7 +27,7 @@ SYMBOLS = [
     "tpl_set_options", "tpl_load_configs", "tpl_reset", "tpl_move", "tpl_step", "tpl_get_state",
     "tpl_expand_obs", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
     "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_decode_actions", "tpl_generate_configs",
-    "tpl_policy_image_bytes", "tpl_policy_pack", "tpl_policy_act", "tpl_set_policy_tuning",
+    "tpl_policy_image_bytes", "tpl_policy_pack", "tpl_policy_act",
     "tpl_explore_actions", "tpl_actor_rollout",
 ]
 
@@ -75,6 +77,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             if force or not fresh():
                 tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
                 cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", tmp] + _UNITS
+                if _DIAG:
+                    cmd.insert(1, "-DTPL_DIAG_CLOCK")
                 res = subprocess.run(cmd, capture_output=True, text=True)
                 if res.returncode != 0:
                     raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
@@ -125,7 +129,6 @@ def lib() -> C.CDLL:
     L.tpl_policy_image_bytes.argtypes = []
     L.tpl_policy_pack.argtypes = [vp] * 11
     L.tpl_policy_act.argtypes = [vp, vp, vp, vp, vp]
-    L.tpl_set_policy_tuning.argtypes = [vp, i32, i32]
     L.tpl_explore_actions.argtypes = [vp, vp, f32, u64, C.c_uint32, vp]
     L.tpl_actor_rollout.argtypes = [vp, vp, i32, f32, u64, C.c_uint32, vp, vp, vp, vp, vp, vp]
     L.tpl_get_stats.argtypes = [vp, vp, vp]

@@ -1,26 +1,33 @@
-// policy_mlp.hip -- obs -> MLP -> action in ONE kernel (BASELINE configs[4]).
+// policy_mlp.hip -- obs -> MLP -> action in ONE kernel, and T x (policy, explore, step) in one launch
+// (BASELINE configs[4]).
 //
 // Policy: Model(217, 14) of the reference (model/model.py:9-20, model/train.py:26): Linear 217-128, 128-128,
-// 128-128, 128-128, 128-14 with ReLU between them.  This is the only GEMM-shaped work on the path, so it runs
-// on the matrix cores: v_mfma_f32_32x32x16_bf16, bf16 operands, f32 accumulation, activations rounded to bf16
+// 128-128, 128-128, 128-14 with ReLU between them.  This is the only GEMM-shaped work on the path, so it runs on
+// the matrix cores: v_mfma_f32_16x16x32_bf16, bf16 operands, f32 accumulation, activations rounded to bf16
 // between layers (what a bf16 torch module does).
 //
-// Everything is computed TRANSPOSED: boards run along the MFMA's N dimension (the lane), features along M/K.
+// Everything is computed TRANSPOSED: boards run along the MFMA's N dimension (the lane), features along M/K:
 //   H_{l+1}^T [out x boards] = W_{l+1} [out x in] . H_l^T [in x boards]
-// With that orientation the 32x32 accumulator tile of one layer IS the B operand of the next (its column is on
-// the lane, its rows are the next product's k): registers 8s..8s+7 of a tile, converted pairwise to bf16, are the
-// fragment of k-step s -- no LDS round trip, no lane movement.  The k order inside such a fragment is permuted
-// (element j of lane half h is row 16s + 8(j>>2) + 4h + (j&3)); the weights are pre-packed on the host in the
-// same permuted order, lane-major, so an A fragment is one conflict-free ds_read_b128.
+// so that the accumulator tiles of one layer ARE the B operand of the next (their column is on the lane, their
+// rows are the next product's k) -- no LDS round trip, no lane movement.  All weights (158 KB of bf16 + 2 KB of
+// f32 biases) stay resident in the CU's 160 KB LDS, pre-packed on the host lane-major in the permuted k order the
+// hand-off produces, so an A fragment is one conflict-free ds_read_b128; a 512-thread workgroup loads them once
+// and loops over board tiles.  The observation is never materialised: each lane turns its board's 32-B state into
+// the layer-1 B fragments directly (cells are 0/1: a nibble becomes two packed bf16 registers with two multiplies).
+// Internal feature order of layer 1 (the packer permutes W1's columns, callers keep tpl_expand_obs' order):
+// k = 20x + y for the cell in row y, column x -- how the state stores the board -- then the 17 extras at 200..216.
 //
-// All weights (158 KB of bf16 + 2 KB of f32 biases) stay resident in the CU's 160 KB LDS; a 256-thread workgroup
-// (one wave per SIMD) loads them once and then loops over board tiles.  The observation is never materialised:
-// each lane turns its board's 32-B state into the layer-1 B fragments directly (cells are 0/1, so a 4-bit
-// nibble becomes two packed bf16 registers with two multiplies).
+// (The same kernels were also built on v_mfma_f32_32x32x16_bf16; both shapes take 33-34 us per 262,144 boards.
+// This one is kept because the 14-row head is one 16-row tile and the file has a single geometry.)
 //
-// Internal feature order of layer 1 (the packer permutes W1's columns, so callers keep the standard order of
-// tpl_expand_obs): k = 20*x + y for the cell in row y, column x (that is how the state stores the board), then
-// the 17 extras in their standard positions 200..216, then 7 zero pads.
+// Geometry of a wave: 32 boards = two N tiles of 16.  Lane l = (c = l & 15, g = l >> 4) owns board (t = g >> 1, c);
+// lanes g and g ^ 1 carry identical copies of it.  For the matrix products every lane needs the features of BOTH
+// boards of its column c (one per N tile); the other one comes from lane l ^ 32 with eight cross-lane moves.
+//
+// Fragment maps (cdna_hip_programming.md section 3): A: lane holds A[row c][k = 8g + j]; B: B[k = 8g + j][col c];
+// C/D: D[row = 4g + reg][col c], reg 0..3.  A layer's output tile m (16 rows) therefore leaves rows 16m + 4g + reg
+// on lane (c, g); two consecutive tiles give the eight values a B fragment of the next layer needs, in the
+// permuted order k = 32s + 16(j >> 2) + 4g + (j & 3) -- which is the order the weights are pre-packed in.
 #include "tpl_internal.h"
 #include "tpl_step.h"
 
@@ -28,50 +35,47 @@
 #include <vector>
 
 namespace tpl {
+namespace p16 {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) short i16x2;
 
-constexpr int kHidden = 128;
-constexpr int kObs = 217;
-constexpr int kOut = 14;
-constexpr int kKs1 = 14;                         // k-steps of layer 1: 224 = 217 padded to a multiple of 16
-constexpr int kKsH = 8;                          // k-steps of a hidden layer: 128 / 16
-constexpr int kMt = 4;                           // 32-row output tiles of a 128-wide layer
+constexpr int kHidden = 128, kObs = 217, kOut = 14;
+constexpr int kKs1 = 7;        // k-steps of 32 in layer 1: 224 = 217 padded
+constexpr int kKsH = 4;        // k-steps of a hidden layer
+constexpr int kMt = 8;         // 16-row output tiles of a 128-wide layer
 
-// byte offsets inside the packed image
 constexpr int kOffW1 = 0;
 constexpr int kOffW2 = kOffW1 + kMt * kKs1 * 1024;             // 57344
 constexpr int kOffW3 = kOffW2 + kMt * kKsH * 1024;
 constexpr int kOffW4 = kOffW3 + kMt * kKsH * 1024;
 constexpr int kOffW5 = kOffW4 + kMt * kKsH * 1024;             // 155648
-constexpr int kOffB = kOffW5 + kKsH * 512;                     // 159744: biases f32: 4 x 128, then 16
-constexpr int kImageBytes = kOffB + (4 * kHidden + 16) * 4;    // 161856 <= 163840
-static_assert(kImageBytes <= 160 * 1024, "policy image must fit the CU's LDS");
-static_assert(kImageBytes % 16 == 0, "image is copied in 16-byte pieces");
+constexpr int kOffB = kOffW5 + kKsH * 1024;                    // 159744
+constexpr int kImageBytes = kOffB + (4 * kHidden + 16) * 4;    // 161856
+static_assert(kImageBytes <= 160 * 1024 - 512, "policy image + shape table must fit the CU's LDS");
 
-// ---- host side: packing ----------------------------------------------------------------------------------
 static inline uint16_t bf16_rne(float f) {
     uint32_t u;
     std::memcpy(&u, &f, 4);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);   // NaN stays NaN
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
     return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
-// k inside a fragment: element j of lane half h in k-step s
-static inline int frag_k(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+static inline int frag_k(int s, int g, int j) { return 32 * s + 16 * (j >> 2) + 4 * g + (j & 3); }
 
-// internal layer-1 feature index -> standard observation index (tpl_expand_obs order), or -1 for a pad
-static inline int std_feature(int k) {
+static inline int std_feature(int k) {     // internal layer-1 feature -> tpl_expand_obs index, -1 for a pad
     if (k < 200) return (k % 20) * 10 + (k / 20);
     return k < kObs ? k : -1;
 }
 
+}  // namespace p16
 }  // namespace tpl
 
 using namespace tpl;
+using namespace tpl::p16;
 
 extern "C" size_t tpl_policy_image_bytes(void) { return (size_t)kImageBytes; }
 
@@ -82,29 +86,24 @@ extern "C" int tpl_policy_pack(const float* w1, const float* b1, const float* w2
         return fail_msg(TPL_ERR_ARG, "tpl_policy_pack: null pointer");
     std::vector<uint8_t> img((size_t)kImageBytes, 0);
     uint16_t* p = (uint16_t*)img.data();
-    auto pack_layer = [&](int off, const float* w, int in, int ks, bool first) {
-        for (int m = 0; m < kMt; ++m)
+    auto pack_layer = [&](int off, const float* w, int rows, int in, int mt, int ks, bool first) {
+        for (int m = 0; m < mt; ++m)
             for (int s = 0; s < ks; ++s)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
-                        const int r = lane & 31, h = lane >> 5;
-                        int k = frag_k(s, h, j);
+                        const int c = lane & 15, g = lane >> 4;
+                        int k = frag_k(s, g, j);
                         if (first) k = std_feature(k);
-                        const float v = (k >= 0 && k < in) ? w[(size_t)(32 * m + r) * in + k] : 0.0f;
+                        const int row = 16 * m + c;
+                        const float v = (k >= 0 && k < in && row < rows) ? w[(size_t)row * in + k] : 0.0f;
                         p[off / 2 + (((m * ks + s) * 64 + lane) * 8 + j)] = bf16_rne(v);
                     }
     };
-    pack_layer(kOffW1, w1, kObs, kKs1, true);
-    pack_layer(kOffW2, w2, kHidden, kKsH, false);
-    pack_layer(kOffW3, w3, kHidden, kKsH, false);
-    pack_layer(kOffW4, w4, kHidden, kKsH, false);
-    for (int s = 0; s < kKsH; ++s)                          // last layer: 14 rows, stored as 16, two lane halves
-        for (int h = 0; h < 2; ++h)
-            for (int r = 0; r < 16; ++r)
-                for (int j = 0; j < 8; ++j) {
-                    const float v = r < kOut ? w5[(size_t)r * kHidden + frag_k(s, h, j)] : 0.0f;
-                    p[kOffW5 / 2 + (((s * 2 + h) * 16 + r) * 8 + j)] = bf16_rne(v);
-                }
+    pack_layer(kOffW1, w1, kHidden, kObs, kMt, kKs1, true);
+    pack_layer(kOffW2, w2, kHidden, kHidden, kMt, kKsH, false);
+    pack_layer(kOffW3, w3, kHidden, kHidden, kMt, kKsH, false);
+    pack_layer(kOffW4, w4, kHidden, kHidden, kMt, kKsH, false);
+    pack_layer(kOffW5, w5, kOut, kHidden, 1, kKsH, false);
     float* bias = (float*)(img.data() + kOffB);
     const float* bs[4] = {b1, b2, b3, b4};
     for (int l = 0; l < 4; ++l)
@@ -115,12 +114,11 @@ extern "C" int tpl_policy_pack(const float* w1, const float* b1, const float* w2
 }
 
 namespace tpl {
+namespace p16 {
 
-// ---- device side -----------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     f32x2 v = {a, b};
-    bf16x2 r = __builtin_convertvector(v, bf16x2);
-    return __builtin_bit_cast(uint32_t, r);
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
 // two cell bits -> two packed bf16 values (1.0 = 0x3F80)
@@ -128,106 +126,12 @@ __device__ __forceinline__ uint32_t bits_to_bf16x2(uint32_t two_bits) {
     return ((two_bits & 1u) | ((two_bits & 2u) << 15)) * 0x3F80u;
 }
 
-struct PolicyArgs {
-    const uint4* plane_a;
-    const uint4* plane_b;
-    int64_t n;
-    int32_t L, M;
-    const uint4* image;     // packed weights, kImageBytes
-    uint8_t* action;        // [n]
-    float* logits;          // [n][14] or null
-    uint32_t stagger;       // waves 4..7 of a 512-thread workgroup start this many x 1024 cycles late
-};
-
-// Two waves that share a SIMD and run the same program fall into lockstep: both in their MFMA loops, then both
-// in their VALU epilogues, and the two pipes never overlap.  Delaying the second wave of every SIMD (waves 4-7:
-// a workgroup's waves are dealt to the SIMDs round-robin) by a fraction of an iteration puts one wave's VALU
-// phases under the other's MFMA phases.
-__device__ __forceinline__ void stagger_second_wave(int wave, uint32_t units) {
-    if (wave >= 4)
-        for (uint32_t k = 0; k < units; ++k) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles
-}
-
-// ReLU on two packed bf16 values: as signed 16-bit integers a negative bf16 (sign bit set, -0 included) is a
-// negative number, so max(., 0) clears it and leaves non-negative values untouched -- one v_pk_max_i16 per pair,
-// where fmaxf on the f32 accumulators costs two v_max_f32 per VALUE (canonicalise + max).  Rounding to bf16 first
-// and clamping second gives the same result as the other order: rounding never changes the sign.
-typedef __attribute__((ext_vector_type(2))) short i16x2;
+// ReLU on two packed bf16 values: a negative bf16 is a negative int16, so one v_pk_max_i16 clears it
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
     const i16x2 zero = {0, 0};
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, v), zero));
 }
 
-// convert an accumulator tile to bf16, apply ReLU, and hand it on as the two B fragments of the next layer
-__device__ __forceinline__ void tile_to_frags(const f32x16& c, bf16x8& f0, bf16x8& f1) {
-    uint4 lo, hi;
-    lo.x = relu_bf16x2(pack_bf16(c[0], c[1]));
-    lo.y = relu_bf16x2(pack_bf16(c[2], c[3]));
-    lo.z = relu_bf16x2(pack_bf16(c[4], c[5]));
-    lo.w = relu_bf16x2(pack_bf16(c[6], c[7]));
-    hi.x = relu_bf16x2(pack_bf16(c[8], c[9]));
-    hi.y = relu_bf16x2(pack_bf16(c[10], c[11]));
-    hi.z = relu_bf16x2(pack_bf16(c[12], c[13]));
-    hi.w = relu_bf16x2(pack_bf16(c[14], c[15]));
-    f0 = __builtin_bit_cast(bf16x8, lo);
-    f1 = __builtin_bit_cast(bf16x8, hi);
-}
-
-// accumulator tile m of a layer starts as the bias of its rows: row = (reg&3) + 8(reg>>2) + 4h
-__device__ __forceinline__ f32x16 bias_tile(const float* bias, int m, int h) {
-    f32x16 c;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const float4 b = *(const float4*)(bias + 32 * m + 8 * g + 4 * h);
-        c[4 * g + 0] = b.x; c[4 * g + 1] = b.y; c[4 * g + 2] = b.z; c[4 * g + 3] = b.w;
-    }
-    return c;
-}
-
-// A fragment q of a layer = (output tile m = q / ks, k-step s = q % ks): consecutive fragments are 1 KiB apart
-__device__ __forceinline__ bf16x8 a_frag(const uint8_t* lds, int w_off, int q, int lane) {
-    return *(const bf16x8*)(lds + w_off + (q * 64 + lane) * 16);
-}
-
-// One layer with 128 outputs: xout^T[128 x boards] = relu(W . xin^T + b), both sides as MFMA fragments in registers.
-// Order: output tile m outermost, so that
-//   * tile m's epilogue (bf16 convert + ReLU: VALU) sits in program order BEHIND the MFMAs of tile m+1 and runs
-//     while the matrix pipe works on them (two accumulator tiles alternate);
-//   * the A fragments stream through a four-deep register window: the read of fragment q+4 is issued right behind
-//     the MFMA that consumes fragment q, so an LDS read has four MFMAs (128 pipe cycles) to land.
-// sched_barrier(0) pins that order; left alone the scheduler hoists every LDS read to the top and spills.
-template <int kNt, int kKs>
-__device__ __forceinline__ void dense128(const uint8_t* lds, int w_off, const float* bias, int lane, int h,
-                                         const bf16x8 (&xin)[kNt][kKs], bf16x8 (&xout)[kNt][kKsH]) {
-    f32x16 acc[2][kNt];
-    bf16x8 aq[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) aq[q] = a_frag(lds, w_off, q, lane);
-#pragma unroll
-    for (int m = 0; m < kMt; ++m) {
-        const f32x16 b = bias_tile(bias, m, h);
-#pragma unroll
-        for (int t = 0; t < kNt; ++t) acc[m & 1][t] = b;
-#pragma unroll
-        for (int s = 0; s < kKs; ++s) {
-            const int q = m * kKs + s;
-#pragma unroll
-            for (int t = 0; t < kNt; ++t) acc[m & 1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[q & 3], xin[t][s], acc[m & 1][t], 0, 0, 0);
-            if (q + 4 < kMt * kKs) aq[q & 3] = a_frag(lds, w_off, q + 4, lane);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (m > 0) {
-#pragma unroll
-            for (int t = 0; t < kNt; ++t) tile_to_frags(acc[(m - 1) & 1][t], xout[t][2 * (m - 1)], xout[t][2 * (m - 1) + 1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < kNt; ++t) tile_to_frags(acc[(kMt - 1) & 1][t], xout[t][2 * (kMt - 1)], xout[t][2 * (kMt - 1) + 1]);
-}
-
-// weights -> LDS, eight 16-B loads in flight per thread (a load-store-load-store loop would pay the L2 latency
-// forty times over).  Ends with a barrier.
 template <int kThreads>
 __device__ __forceinline__ void load_image(uint4* s_image, const uint4* image) {
     constexpr int kPieces = kImageBytes / 16;
@@ -247,147 +151,214 @@ __device__ __forceinline__ void load_image(uint4* s_image, const uint4* image) {
     __syncthreads();
 }
 
-// a board -> its cell bit vector in the internal order (bit 20x + y; extras as bits 200..213 and 216) and the
-// two numeric features (L_rem, M_rem) as a packed bf16 pair
-__device__ __forceinline__ void board_features(const Board& s, int L, int M, uint32_t (&cw)[7], uint32_t& lm) {
-    cw[0] = s.c[0] | (s.c[1] << 20);
-    cw[1] = (s.c[1] >> 12) | (s.c[2] << 8) | (s.c[3] << 28);
-    cw[2] = (s.c[3] >> 4) | (s.c[4] << 16);
-    cw[3] = (s.c[4] >> 16) | (s.c[5] << 4) | (s.c[6] << 24);
-    cw[4] = (s.c[6] >> 8) | (s.c[7] << 12);
-    cw[5] = s.c[8] | (s.c[9] << 20);
+// a board -> its cell bit vector in the internal order (bit 20x + y; extras as bits 200..213 and 216) and the two
+// numeric features (L_rem, M_rem) as a packed bf16 pair; f[7] = that pair
+__device__ __forceinline__ void board_features(const Board& s, int L, int M, uint32_t (&f)[8]) {
+    f[0] = s.c[0] | (s.c[1] << 20);
+    f[1] = (s.c[1] >> 12) | (s.c[2] << 8) | (s.c[3] << 28);
+    f[2] = (s.c[3] >> 4) | (s.c[4] << 16);
+    f[3] = (s.c[4] >> 16) | (s.c[5] << 4) | (s.c[6] << 24);
+    f[4] = (s.c[6] >> 8) | (s.c[7] << 12);
+    f[5] = s.c[8] | (s.c[9] << 20);
     const uint32_t cur = s.window & 7u, nxt = (s.window >> 3) & 7u;
-    cw[6] = (s.c[9] >> 12) | ((1u << (8 + cur)) & 0x7F00u) | ((1u << (15 + nxt)) & 0x3F8000u) |
-            (s.state != ST_RUNNING ? 1u << 24 : 0u);
-    lm = pack_bf16((float)(L - (int)s.lines), (float)(M - (int)s.moves));   // features 214, 215
+    f[6] = (s.c[9] >> 12) | ((1u << (8 + cur)) & 0x7F00u) | ((1u << (15 + nxt)) & 0x3F8000u) |
+           (s.state != ST_RUNNING ? 1u << 24 : 0u);
+    f[7] = pack_bf16((float)(L - (int)s.lines), (float)(M - (int)s.moves));   // features 214, 215
 }
 
-// the five layers for kNt tiles of 32 boards; c[t] ends up holding the 14 logits of board (t, r): outputs
-// 4h + {0..3} in c[t][0..3] and 8 + 4h + {0..3} in c[t][4..7]
-template <int kNt>
-__device__ __forceinline__ void policy_logits(const uint8_t* lds, int lane, int h, int r, const uint32_t (&cw)[kNt][7],
-                                              const uint32_t (&lm)[kNt], f32x16 (&c)[kNt]) {
-    const float* bias = (const float*)(lds + kOffB);
-    // ---- layer 1: 224 (217) -> 128; its B fragments are made from the cell bits, once, up front
-    bf16x8 x0[kNt][kKs1];
+__device__ __forceinline__ bf16x8 a_frag(const uint8_t* lds, int w_off, int q, int lane) {
+    return *(const bf16x8*)(lds + w_off + (q * 64 + lane) * 16);
+}
+
+// One layer with 16*kTiles outputs on two N tiles of 16 boards.  Output tile m outermost; the A fragments stream
+// through a four-deep register window (the read of fragment q+4 is issued right behind the MFMAs that consume
+// fragment q); tile m's epilogue sits behind the MFMAs of tile m+1.  xout[t][s] collects tiles 2s and 2s+1.
+template <int kTiles, int kKs, bool kRelu>
+__device__ __forceinline__ void dense(const uint8_t* lds, int w_off, const float* bias, int lane, int g,
+                                      const uint4 (&xin)[2][kKs], uint4 (&xout)[2][kTiles / 2 > 0 ? kTiles / 2 : 1],
+                                      f32x4 (&last)[2]) {
+    f32x4 acc[2][2];
+    bf16x8 aq[4];
 #pragma unroll
-    for (int t = 0; t < kNt; ++t)
+    for (int q = 0; q < 4 && q < kTiles * kKs; ++q) aq[q] = a_frag(lds, w_off, q, lane);
+    // the bias of tile m+1 is read while tile m is being multiplied: read just in time, the accumulator's initial
+    // value would stall the first MFMA of every tile for one LDS latency
+    float4 bnext = *(const float4*)(bias + 4 * g);
 #pragma unroll
-        for (int s = 0; s < kKs1; ++s) {
-            const uint32_t half16 = (cw[t][s >> 1] >> ((s & 1) * 16)) >> (4 * h);
-            uint4 q;
-            q.x = bits_to_bf16x2(half16);            // k = 16s + 4h + {0,1}
-            q.y = bits_to_bf16x2(half16 >> 2);       //                 {2,3}
-            q.z = bits_to_bf16x2(half16 >> 8);       // k = 16s + 8 + 4h + {0,1}
-            q.w = bits_to_bf16x2(half16 >> 10);
-            if (s == 13 && h == 1) q.y = lm[t];      // k = 214, 215: L_rem, M_rem
-            x0[t][s] = __builtin_bit_cast(bf16x8, q);
+    for (int m = 0; m < kTiles; ++m) {
+        const float4 b = bnext;
+        if (m + 1 < kTiles) bnext = *(const float4*)(bias + 16 * (m + 1) + 4 * g);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { acc[m & 1][t][0] = b.x; acc[m & 1][t][1] = b.y; acc[m & 1][t][2] = b.z; acc[m & 1][t][3] = b.w; }
+#pragma unroll
+        for (int s = 0; s < kKs; ++s) {
+            const int q = m * kKs + s;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                acc[m & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[q & 3], __builtin_bit_cast(bf16x8, xin[t][s]), acc[m & 1][t], 0, 0, 0);
+            if (q + 4 < kTiles * kKs) aq[q & 3] = a_frag(lds, w_off, q + 4, lane);
+            __builtin_amdgcn_sched_barrier(0);
         }
-    bf16x8 xa[kNt][kKsH], xb[kNt][kKsH];
-    dense128<kNt, kKs1>(lds, kOffW1, bias, lane, h, x0, xa);
-    // ---- layers 2-4
-    dense128<kNt, kKsH>(lds, kOffW2, bias + 1 * kHidden, lane, h, xa, xb);
-    dense128<kNt, kKsH>(lds, kOffW3, bias + 2 * kHidden, lane, h, xb, xa);
-    dense128<kNt, kKsH>(lds, kOffW4, bias + 3 * kHidden, lane, h, xa, xb);
-    const bf16x8 (&x)[kNt][kKsH] = xb;
-    // ---- layer 5: 128 -> 14 (rows 0..13 of one tile; lanes of rows 16..31 re-read rows 0..15, unused)
+        if (kRelu && m > 0) {
+            const int pm = m - 1;
 #pragma unroll
-    for (int t = 0; t < kNt; ++t) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g < 2) b = *(const float4*)(bias + 4 * kHidden + 8 * g + 4 * h);
-            c[t][4 * g + 0] = b.x; c[t][4 * g + 1] = b.y; c[t][4 * g + 2] = b.z; c[t][4 * g + 3] = b.w;
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t lo = relu_bf16x2(pack_bf16(acc[pm & 1][t][0], acc[pm & 1][t][1]));
+                const uint32_t hi = relu_bf16x2(pack_bf16(acc[pm & 1][t][2], acc[pm & 1][t][3]));
+                if (pm & 1) { xout[t][pm >> 1].z = lo; xout[t][pm >> 1].w = hi; }
+                else { xout[t][pm >> 1].x = lo; xout[t][pm >> 1].y = hi; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if (kRelu) {
+        const int pm = kTiles - 1;
 #pragma unroll
-        for (int s = 0; s < kKsH; ++s) {
-            const bf16x8 a = *(const bf16x8*)(lds + kOffW5 + ((s * 2 + h) * 16 + (r & 15)) * 16);
-            c[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, x[t][s], c[t], 0, 0, 0);
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t lo = relu_bf16x2(pack_bf16(acc[pm & 1][t][0], acc[pm & 1][t][1]));
+            const uint32_t hi = relu_bf16x2(pack_bf16(acc[pm & 1][t][2], acc[pm & 1][t][3]));
+            if (pm & 1) { xout[t][pm >> 1].z = lo; xout[t][pm >> 1].w = hi; }
+            else { xout[t][pm >> 1].x = lo; xout[t][pm >> 1].y = hi; }
         }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) last[t] = acc[(kTiles - 1) & 1][t];
     }
 }
 
-// argmax of outputs 0..3 (rotation) and of outputs 4..13 (location), lowest index on ties, NaN never wins; the two
-// lane halves of a board exchange their location candidates.  Every lane of the pair returns the action.
-__device__ __forceinline__ uint32_t pick_action(const f32x16& c, int h) {
-    float rv = -INFINITY; int ri = 0;                    // rotation: all four live on the h = 0 lane
+// five layers for the wave's two N tiles; fb[t] = features of board (t, c).  Returns the logits tile: lane (c, g)
+// holds outputs 4g + reg of board (t, c) in logits[t][reg].
+__device__ __forceinline__ void policy_logits(const uint8_t* lds, int lane, int g, const uint32_t (&fb)[2][8],
+                                              f32x4 (&logits)[2]) {
+    const float* bias = (const float*)(lds + kOffB);
+    uint4 x0[2][kKs1];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < kKs1; ++s) {
+            // k = 32s + 4g + {0..3} and 32s + 16 + 4g + {0..3}: two nibbles of cell word s
+            const uint32_t w = fb[t][s] >> (4 * g);
+            uint4 q;
+            q.x = bits_to_bf16x2(w);
+            q.y = bits_to_bf16x2(w >> 2);
+            q.z = bits_to_bf16x2(w >> 16);
+            q.w = bits_to_bf16x2(w >> 18);
+            if (s == 6 && g == 1) q.w = fb[t][7];        // k = 192 + 16 + 4 + {2, 3} = 214, 215: L_rem, M_rem
+            x0[t][s] = q;
+        }
+    uint4 xa[2][kKsH], xb[2][kKsH];
+    f32x4 unused[2];
+    dense<kMt, kKs1, true>(lds, kOffW1, bias, lane, g, x0, xa, unused);
+    dense<kMt, kKsH, true>(lds, kOffW2, bias + 1 * kHidden, lane, g, xa, xb, unused);
+    dense<kMt, kKsH, true>(lds, kOffW3, bias + 2 * kHidden, lane, g, xb, xa, unused);
+    dense<kMt, kKsH, true>(lds, kOffW4, bias + 3 * kHidden, lane, g, xa, xb, unused);
+    uint4 none[2][1];
+    dense<1, kKsH, false>(lds, kOffW5, bias + 4 * kHidden, lane, g, xb, none, logits);
+}
+
+// argmax of outputs 0..3 (rotation, on the g = 0 lane) and of outputs 4..13 (location, spread over g = 1, 2, 3),
+// lowest index on ties, NaN never wins.  All four lanes of a board return its action.
+__device__ __forceinline__ uint32_t pick_action(const f32x4& c, int g, int lane) {
+    float rv = -INFINITY; int ri = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (c[k] > rv) { rv = c[k]; ri = k; }
-    float lv = -INFINITY; int li = 99;                   // location candidates of this lane, ascending index
-    if (h == 1) {                                        // outputs 4..7 -> loc 0..3, outputs 12, 13 -> loc 8, 9
+    float lv = -INFINITY; int li = 99;
+    const int first = 4 * g - 4;                         // location index of c[0] on this lane (g >= 1)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (c[k] > lv) { lv = c[k]; li = k; }
+    for (int k = 0; k < 4; ++k)
+        if (g >= 1 && first + k < 10 && c[k] > lv) { lv = c[k]; li = first + k; }
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-            if (c[4 + k] > lv) { lv = c[4 + k]; li = 8 + k; }
-    } else {                                             // outputs 8..11 -> loc 4..7
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (c[4 + k] > lv) { lv = c[4 + k]; li = 4 + k; }
+    for (int step = 16; step <= 32; step <<= 1) {
+        const float ov = __shfl_xor(lv, step);
+        const int oi = __shfl_xor(li, step);
+        if (ov > lv || (ov == lv && oi < li)) { lv = ov; li = oi; }
     }
-    const float ov = __shfl_xor(lv, 32);
-    const int oi = __shfl_xor(li, 32);
-    if (ov > lv || (ov == lv && oi < li)) { lv = ov; li = oi; }
     if (li == 99) li = 0;
-    const int partner_ri = __shfl_xor(ri, 32);           // (shuffles stay outside any lane-dependent branch)
-    const int rot = h == 0 ? ri : partner_ri;            // the h = 1 lane takes the rotation from its partner
+    const int rot = __shfl(ri, lane & 15);               // the g = 0 lane of this column
     return (uint32_t)(rot * 10 + li);
 }
 
-template <int kNt, int kThreads>
-__global__ __launch_bounds__(kThreads, kThreads / 256) void policy_kernel(const PolicyArgs p) {
-    __shared__ uint4 s_image[kImageBytes / 16];
-    load_image<kThreads>(s_image, p.image);
-    const uint8_t* lds = (const uint8_t*)s_image;
+struct PolicyArgs {
+    const uint4* plane_a;
+    const uint4* plane_b;
+    int64_t n;
+    int32_t L, M;
+    const uint4* image;
+    uint8_t* action;
+    float* logits;
+    unsigned long long* diag;   // diagnostic build only
+};
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    constexpr int kWaves = kThreads / 64;
-    const int64_t tiles = (p.n + 32 * kNt - 1) / (32 * kNt);
-    stagger_second_wave(wave, p.stagger);
-    for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += (int64_t)gridDim.x * kWaves) {
-        uint32_t cw[kNt][7];
-        uint32_t lm[kNt];
-        bool valid[kNt];
+// features of both boards of column c: the lane's own board (t = g >> 1) and the one held by lane ^ 32
+__device__ __forceinline__ void both_features(const uint32_t (&own)[8], int g, uint32_t (&fb)[2][8]) {
 #pragma unroll
-        for (int t = 0; t < kNt; ++t) {
-            const int64_t b = tile * (32 * kNt) + t * 32 + r;
-            valid[t] = b < p.n;
-            Board s;
-            if (valid[t]) {
-                unpack_board(p.plane_a[b], p.plane_b[b], s);
-            } else {
-#pragma unroll
-                for (int c = 0; c < kCols; ++c) s.c[c] = 0;
-                s.window = 0x3FFFFFFFu; s.state = 0; s.lines = 0; s.moves = 0; s.episode = 0;
-            }
-            board_features(s, p.L, p.M, cw[t], lm[t]);
-        }
-        f32x16 c[kNt];
-        policy_logits<kNt>(lds, lane, h, r, cw, lm, c);
-#pragma unroll
-        for (int t = 0; t < kNt; ++t) {
-            const int64_t b = tile * (32 * kNt) + t * 32 + r;
-            if (p.logits && valid[t]) {
-                float* o = p.logits + b * kOut;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) o[4 * h + k] = c[t][k];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (8 + 4 * h + k < kOut) o[8 + 4 * h + k] = c[t][4 + k];
-            }
-            const uint32_t action = pick_action(c[t], h);
-            if (h == 0 && valid[t]) p.action[b] = (uint8_t)action;
-        }
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t other = __shfl_xor(own[k], 32);
+        fb[0][k] = (g >> 1) == 0 ? own[k] : other;
+        fb[1][k] = (g >> 1) == 1 ? own[k] : other;
     }
 }
 
-// epsilon-greedy exploration, keyed by (seed, global board, global step): with probability eps_q24 / 2^24 the
-// action is replaced by a uniform one in [0, 40)
-__device__ __forceinline__ uint32_t explore(uint32_t action, uint64_t seed, uint64_t g, uint32_t step, uint32_t eps_q24) {
-    uint32_t u = fmix32((uint32_t)g ^ ((uint32_t)(g >> 32) * 0x9E3779B9u) ^ (uint32_t)seed ^ 0x51ED270Bu);
+__global__ __launch_bounds__(512, 2) void policy_kernel(const PolicyArgs p) {
+    __shared__ uint4 s_image[kImageBytes / 16];
+    load_image<512>(s_image, p.image);
+    const uint8_t* lds = (const uint8_t*)s_image;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int64_t tiles = (p.n + 31) / 32;
+#ifdef TPL_DIAG_CLOCK
+    // diagnostic build only (tools/policy_clock.py): shader-clock and 100 MHz real-time stamps around the tile loop
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < tiles; tile += (int64_t)gridDim.x * 8) {
+        const int64_t b = tile * 32 + (g >> 1) * 16 + c;
+        const bool valid = b < p.n;
+        Board s;
+        if (valid) {
+            unpack_board(p.plane_a[b], p.plane_b[b], s);
+        } else {
+#pragma unroll
+            for (int k = 0; k < kCols; ++k) s.c[k] = 0;
+            s.window = 0x3FFFFFFFu; s.state = 0; s.lines = 0; s.moves = 0; s.episode = 0;
+        }
+        uint32_t own[8], fb[2][8];
+        board_features(s, p.L, p.M, own);
+        both_features(own, g, fb);
+        f32x4 lg[2];
+        policy_logits(lds, lane, g, fb, lg);
+        const uint32_t act0 = pick_action(lg[0], g, lane), act1 = pick_action(lg[1], g, lane);
+        const uint32_t action = (g >> 1) ? act1 : act0;
+        const f32x4 mine = (g >> 1) ? lg[1] : lg[0];     // the tile of this lane's own board (t = g >> 1)
+        // rows 4g + reg of board (t, c) live on lane (c, g) for BOTH t; a lane writes the rows of its own board's
+        // tile and fetches nothing: lanes (c, 0..3) of tile t are four different lanes, two of which own board t
+        if (p.logits) {
+            // every (t, c, g) triple must be written once: lane (c, g) holds lg[t] for both t
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int64_t bt = tile * 32 + t * 16 + c;
+                if (bt < p.n) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (4 * g + k < kOut) p.logits[bt * kOut + 4 * g + k] = lg[t][k];
+                }
+            }
+        }
+        (void)mine;
+        if (valid && (g & 1) == 0) p.action[b] = (uint8_t)action;
+    }
+#ifdef TPL_DIAG_CLOCK
+    if (lane == 0 && p.diag) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* d = p.diag + 2 * ((size_t)blockIdx.x * 8 + wave);
+        d[0] = t1 - t0;
+        d[1] = r1 - r0;
+    }
+#endif
+}
+
+__device__ __forceinline__ uint32_t explore(uint32_t action, uint64_t seed, uint64_t gidx, uint32_t step, uint32_t eps_q24) {
+    uint32_t u = fmix32((uint32_t)gidx ^ ((uint32_t)(gidx >> 32) * 0x9E3779B9u) ^ (uint32_t)seed ^ 0x51ED270Bu);
     u = fmix32(u + step * 0x9E3779B1u + (uint32_t)(seed >> 32));
     return (u >> 8) < eps_q24 ? ((u & 0xFFu) * 40u) >> 8 : action;
 }
@@ -398,22 +369,21 @@ __global__ __launch_bounds__(kBlock) void explore_kernel(uint8_t* action, int64_
     if (i < n) action[i] = (uint8_t)explore(action[i], seed, (uint64_t)(global_offset + i), step, eps_q24);
 }
 
-// T iterations of (policy -> epsilon-greedy -> step) in ONE launch: weights stay in LDS, boards stay in
-// registers, nothing but the trajectory leaves the chip.  Exactly T x (tpl_policy_act, tpl_explore_actions,
-// tpl_step).  One wave owns 32 boards; the two lane halves of a board carry identical copies of its state and
-// advance it identically, the h = 0 half writes.
 struct ActorArgs {
     StepArgs s;
     const uint4* image;
-    uint32_t T, step0, eps_q24, stagger;
+    uint32_t T, step0, eps_q24;
     uint64_t explore_seed;
-    uint8_t* actions;           // [T][n] or null
-    float* rewards;             // [T][n] or null
-    uint8_t* dones;             // [T][n] or null
-    uint4* states_a;            // [T][n] or null: plane-A word of the board BEFORE step t (the observation)
-    uint4* states_b;            // [T][n] or null
+    uint8_t* actions;
+    float* rewards;
+    uint8_t* dones;
+    uint4* states_a;
+    uint4* states_b;
 };
 
+// T iterations of (policy -> epsilon-greedy -> step) in ONE launch: weights stay in LDS, boards stay in
+// registers, nothing but the trajectory leaves the chip.  Exactly T x (tpl_policy_act, tpl_explore_actions,
+// tpl_step).  Lanes g and g ^ 1 advance identical copies of board (g >> 1, c); the even one writes.
 template <bool kAutoReset>
 __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q) {
     const StepArgs& p = q.s;
@@ -424,42 +394,43 @@ __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q
     if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
     load_image<512>(s_image, q.image);
     const uint8_t* lds = (const uint8_t*)s_image;
-
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
+    const int c = lane & 15, g = lane >> 4;
+    const bool writer = (g & 1) == 0;
     const int64_t tiles = (p.n + 31) / 32;
     Tally tally;
-    stagger_second_wave(wave, q.stagger);
     for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < tiles; tile += (int64_t)gridDim.x * 8) {
-        const int64_t b = tile * 32 + r;
+        const int64_t b = tile * 32 + (g >> 1) * 16 + c;
         const bool valid = b < p.n;
         Board s;
         if (valid) {
             unpack_board(p.plane_a[b], p.plane_b[b], s);
         } else {
 #pragma unroll
-            for (int c = 0; c < kCols; ++c) s.c[c] = 0;
+            for (int k = 0; k < kCols; ++k) s.c[k] = 0;
             s.window = 0x3FFFFFFFu; s.state = ST_LOST_LIMIT; s.lines = 0; s.moves = 0; s.episode = 0;   // frozen filler
         }
         uint32_t cfg = current_config(s, p, (uint32_t)b);
         for (uint32_t t = 0; t < q.T; ++t) {
-            if (q.states_a && valid && h == 0) {
+            if (q.states_a && valid && writer) {
                 uint4 A, B;
                 pack_board(s, A, B);
                 q.states_a[(size_t)t * p.n + b] = A;
                 q.states_b[(size_t)t * p.n + b] = B;
             }
-            uint32_t cw[1][7], lm[1];
-            board_features(s, (int)p.L, (int)p.M, cw[0], lm[0]);
-            f32x16 c[1];
-            policy_logits<1>(lds, lane, h, r, cw, lm, c);
-            uint32_t action = pick_action(c[0], h);
+            uint32_t own[8], fb[2][8];
+            board_features(s, (int)p.L, (int)p.M, own);
+            both_features(own, g, fb);
+            f32x4 lg[2];
+            policy_logits(lds, lane, g, fb, lg);
+            const uint32_t act0 = pick_action(lg[0], g, lane), act1 = pick_action(lg[1], g, lane);
+            uint32_t action = (g >> 1) ? act1 : act0;
             action = explore(action, q.explore_seed, (uint64_t)(p.global_offset + b), q.step0 + t, q.eps_q24);
             const uint32_t rot = action / 10u, loc = action - rot * 10u;
             float reward;
-            Tally mine;                                  // only the h = 0 copy of a board counts its episodes
+            Tally mine;
             const bool done = advance_board<kAutoReset>(s, cfg, rot, loc, p, (uint32_t)b, s_shape, reward, mine);
-            if (valid && h == 0) {
+            if (valid && writer) {
                 tally.episodes += mine.episodes; tally.lines += mine.lines;
                 tally.wins += mine.wins; tally.topouts += mine.topouts;
                 if (q.actions) q.actions[(size_t)t * p.n + b] = (uint8_t)action;
@@ -467,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q
                 if (q.dones) q.dones[(size_t)t * p.n + b] = done ? 1 : 0;
             }
         }
-        if (valid && h == 0) {
+        if (valid && writer) {
             uint4 A, B;
             pack_board(s, A, B);
             p.plane_a[b] = A;
@@ -477,6 +448,7 @@ __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q
     flush_tally(tally, s_stat, p.stats);
 }
 
+}  // namespace p16
 }  // namespace tpl
 
 extern "C" int tpl_policy_act(tpl_env* e, const void* image, uint8_t* action, float* logits, void* stream) {
@@ -486,17 +458,14 @@ extern "C" int tpl_policy_act(tpl_env* e, const void* image, uint8_t* action, fl
     DeviceGuard guard(e->device);
     PolicyArgs p{};
     p.plane_a = e->plane_a; p.plane_b = e->plane_b; p.n = e->n; p.L = e->L; p.M = e->M;
-    p.image = (const uint4*)image; p.action = action; p.logits = logits; p.stagger = (uint32_t)e->policy_stagger;
-    // one resident workgroup per CU (the weights fill its LDS), looping over board tiles.
-    // variant 0: 4 waves x 64 boards (one wave per SIMD); variant 1: 8 waves x 32 boards (two per SIMD, so one
-    // wave's epilogue overlaps the other's MFMAs)
-    if (e->policy_variant == 0) {
-        const int64_t groups = ((e->n + 63) / 64 + 3) / 4;
-        hipLaunchKernelGGL((policy_kernel<2, 256>), dim3((unsigned)(groups < 256 ? groups : 256)), dim3(256), 0, (hipStream_t)stream, p);
-    } else {
-        const int64_t groups = ((e->n + 31) / 32 + 7) / 8;
-        hipLaunchKernelGGL((policy_kernel<1, 512>), dim3((unsigned)(groups < 256 ? groups : 256)), dim3(512), 0, (hipStream_t)stream, p);
-    }
+    p.image = (const uint4*)image; p.action = action; p.logits = logits;
+#ifdef TPL_DIAG_CLOCK
+    p.diag = (unsigned long long*)logits;    // the diagnostic build writes its stamps where the logits would go
+    p.logits = nullptr;
+#endif
+    // one resident workgroup per CU (the weights fill its LDS), eight waves of 32 boards, looping over board tiles
+    const int64_t groups = ((e->n + 31) / 32 + 7) / 8;
+    hipLaunchKernelGGL(policy_kernel, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(512), 0, (hipStream_t)stream, p);
     TPL_HIP(hipGetLastError());
     return TPL_OK;
 }
@@ -527,7 +496,7 @@ extern "C" int tpl_actor_rollout(tpl_env* e, const void* image, int32_t num_step
     ActorArgs q{};
     q.s = make_args(e);
     q.image = (const uint4*)image; q.T = (uint32_t)num_steps; q.step0 = step0;
-    q.eps_q24 = (uint32_t)(epsilon * 16777216.0f); q.explore_seed = seed; q.stagger = (uint32_t)e->policy_stagger;
+    q.eps_q24 = (uint32_t)(epsilon * 16777216.0f); q.explore_seed = seed;
     q.actions = actions; q.rewards = rewards; q.dones = dones; q.states_a = (uint4*)states_a; q.states_b = (uint4*)states_b;
     const int64_t groups = ((e->n + 31) / 32 + 7) / 8;
     const dim3 grid((unsigned)(groups < 256 ? groups : 256)), block(512);

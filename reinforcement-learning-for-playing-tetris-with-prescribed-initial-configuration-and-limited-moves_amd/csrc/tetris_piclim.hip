@@ -686,14 +686,6 @@ int tpl_set_tuning(tpl_env* e, int32_t boards_per_lane, int32_t block_threads) {
     return TPL_OK;
 }
 
-int tpl_set_policy_tuning(tpl_env* e, int32_t variant, int32_t stagger) {
-    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
-    if (variant != 0 && variant != 1) return fail_msg(TPL_ERR_ARG, "policy variant must be 0 or 1");
-    if (stagger < 0 || stagger > 64) return fail_msg(TPL_ERR_ARG, "stagger must be in [0, 64]");
-    e->policy_variant = variant;
-    e->policy_stagger = stagger;
-    return TPL_OK;
-}
 
 int tpl_synth_configs(tpl_env* e, uint64_t seed, int64_t first, int64_t count, uint16_t* rows, uint8_t* pieces,
                       void* stream) {

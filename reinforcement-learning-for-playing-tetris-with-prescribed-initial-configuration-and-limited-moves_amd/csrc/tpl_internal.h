@@ -28,8 +28,6 @@ struct tpl_env {
     float r_line = 1.0f, r_win = 0.0f, r_lose = 0.0f;
     int32_t boards_per_lane = 2;        // tuning knobs of the step kernel: boards per lane (1, 2 or 4)
     int32_t block_threads = 256;        //   and threads per block (64, 128, 256 or 512)
-    int32_t policy_variant = 1;         // fused policy kernel geometry (0: 4 waves x 64 boards, 1: 8 waves x 32 boards)
-    int32_t policy_stagger = 0;         // start delay of waves 4-7 in units of 1024 cycles
     uint4* plane_a = nullptr;
     uint4* plane_b = nullptr;
     unsigned long long* stats = nullptr;// [kStatShards][kStatStride]

@@ -80,11 +80,6 @@ class BatchedTetris:
         """Step-kernel geometry (boards per lane 1/2/4, threads per block 64..512); results do not depend on it."""
         check(self._lib.tpl_set_tuning(self._h, int(boards_per_lane), int(block_threads)))
 
-    def set_policy_tuning(self, variant: int = 1, stagger: int = 0) -> None:
-        """Policy kernel geometry (0: 4 waves x 64 boards, 1: 8 waves x 32 boards) and the start delay of each
-        SIMD's second wave (units of 1024 cycles); results do not depend on them."""
-        check(self._lib.tpl_set_policy_tuning(self._h, int(variant), int(stagger)))
-
     def set_options(self, auto_reset=None, assign=None, reward=None):
         if auto_reset is not None:
             self.auto_reset = bool(auto_reset)

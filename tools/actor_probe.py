@@ -13,8 +13,7 @@ rows, pieces = env.synthetic_configs(n)
 env.load_configs(rows, pieces)
 env.reset()
 torch.manual_seed(0)
-for use_graph, variant in ((False, 0), (False, 1), (True, 1)):
-    env.set_policy_tuning(variant)
+for use_graph, variant in ((False, 1), (True, 1)):
     act = T.Actor(env, T.PolicyMLP(), use_graph=use_graph, fused=True)
     act.run(20)
     torch.cuda.synchronize()
