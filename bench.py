@@ -202,7 +202,7 @@ def main():
                                "outputs": "per-step action u8 + reward f32 + done u8 written"}
         actor["value"] = actor["megakernel"]["value"]
         # the policy kernel alone, priced against the dense bf16 MFMA peak: FLOPs it issues per board (K padded to
-        # 224, the 14-row head run as one 32-row tile) over its own duration
+        # 224, the 14-row head run as one 16-row tile) over its own duration
         image = act.image if act.image is not None else T.actor.policy_image(T.PolicyMLP(), dev)
         out = torch.empty(na, dtype=torch.uint8, device=dev)
         for _ in range(5):
@@ -214,7 +214,7 @@ def main():
         p1.record()
         torch.cuda.synchronize(dev)
         pol_ms = p0.elapsed_time(p1) / 100
-        flop = 2.0 * (224 * 128 + 3 * 128 * 128 + 128 * 32) * na
+        flop = 2.0 * (224 * 128 + 3 * 128 * 128 + 128 * 16) * na
         actor["policy_kernel"] = {"ms": pol_ms, "roofline": {"bound": "mfma", "achieved": flop / (pol_ms * 1e-3) / 1e12,
                                                               "peak": 2500.0, "unit": "TFLOP/s",
                                                               "frac": flop / (pol_ms * 1e-3) / 1e12 / 2500.0}}

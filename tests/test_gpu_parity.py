@@ -486,6 +486,31 @@ def _popcount(rows):
     return np.unpackbits(r.view(np.uint8), axis=-1).reshape(r.shape[0], -1).sum(1).astype(np.int64)
 
 
+@pytest.mark.parametrize("assign", ["hash", "sequential"])
+def test_global_offsets_beyond_32_bits(T, oracle, assign):
+    """A shard far into a (hypothetical) huge global batch: board indices above 2^32 key the generator and the
+    configuration assignment exactly as on the CPU."""
+    L, M, n, pool, seed, off = 5, 20, 3000, 1237, 41, (1 << 33) + 12345
+    gpu = T.BatchedTetris(L, M, n, seed=seed, global_offset=off, auto_reset=True, assign=assign)
+    rows, pieces = gpu.synthetic_configs(pool, first=off)
+    assert np.array_equal(_np(rows).view(np.uint16), oracle.synth_boards(seed, off, pool, L))
+    gpu.load_configs(rows, pieces)
+    gpu.reset()
+    cpu = oracle.Env(n, L, M, off, seed)
+    cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
+    cpu.set_options(auto_reset=True, assign_mode=0 if assign == "hash" else 1)
+    cpu.reset()
+    for t in range(50):
+        a = gpu.synthetic_actions(t)
+        assert np.array_equal(_np(a), oracle.synth_actions(seed, off, n, t))
+        _, r, d, _ = gpu.step(a, observe=False)
+        r_c, d_c = cpu.step(_np(a))
+        assert np.array_equal(_np(r), r_c) and np.array_equal(_np(d).astype(np.uint8), d_c), t
+    _assert_state_equal(_state(gpu), cpu.get_state(), "offset")
+    assert gpu.stats() == cpu.stats()
+    gpu.terminate()
+
+
 def test_step_is_graph_capturable_and_replays_exactly(T, oracle):
     """The ABI promises no host synchronisation inside tpl_step: capture 8 steps into one HIP graph, replay it."""
     import torch
