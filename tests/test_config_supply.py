@@ -71,6 +71,19 @@ def test_native_generator_statistics_match_the_reference_generator():
         assert abs(sol_len.mean() - ref.mean()) < 4 * se + 0.5, (name, sol_len.mean(), ref.mean())
 
 
+def test_pool_file_round_trip(tmp_path):
+    import tetris_piclim as T
+    rows, pieces, sol, sol_len = T.generate_configs(5, 20, 64, seed=9, with_solutions=True)
+    path = str(tmp_path / "pool.npz")
+    T.save_pool(path, 5, 20, rows, pieces, sol, sol_len)
+    back = T.load_pool(path)
+    assert (back["L"], back["M"]) == (5, 20)
+    assert np.array_equal(back["rows"], rows) and np.array_equal(back["pieces"], pieces)
+    assert np.array_equal(back["solution"], sol) and np.array_equal(back["solution_len"], sol_len)
+    with pytest.raises(ValueError):
+        T.save_pool(path, 5, 21, rows, pieces)
+
+
 def test_native_generator_argument_errors():
     import tetris_piclim as T
     with pytest.raises(T.TplError):
