@@ -171,6 +171,13 @@ int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t first, int
                          int64_t max_iters, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
                          int32_t* solution_len);
 
+/* The same generator driven by CPython's `random` stream: configuration i is what the reference produces after
+ * `random.seed(seeds[i]); Tetris(L, M, warm_reset=False)` (game/tetris.py:226-284 drawing through :85,93,250,253)
+ * -- MT19937 seeded as random.seed(int) seeds it, randint/shuffle on _randbelow_with_getrandbits.  HOST pointers. */
+int tpl_generate_configs_pyseed(int32_t L, int32_t M, const uint64_t* seeds, int64_t count, int32_t threads,
+                                int64_t max_iters, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
+                                int32_t* solution_len);
+
 /* Synthetic workload of SURVEY 8(d), generated on the device from a counter-based hash
  * keyed by (seed, stream, global board index, counter); DESIGN.md states the function. */
 int tpl_synth_configs(tpl_env* env, uint64_t seed, int64_t first, int64_t count,

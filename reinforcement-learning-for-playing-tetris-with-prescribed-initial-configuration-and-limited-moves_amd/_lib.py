@@ -26,7 +26,7 @@ SYMBOLS = [
     "tpl_last_error", "tpl_version", "tpl_workspace_bytes", "tpl_pool_bytes", "tpl_create", "tpl_destroy",
     "tpl_set_options", "tpl_load_configs", "tpl_reset", "tpl_move", "tpl_step", "tpl_get_state",
     "tpl_expand_obs", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
-    "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_decode_actions", "tpl_generate_configs",
+    "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_decode_actions", "tpl_generate_configs", "tpl_generate_configs_pyseed",
     "tpl_policy_image_bytes", "tpl_policy_pack", "tpl_policy_act",
     "tpl_explore_actions", "tpl_actor_rollout",
 ]
@@ -136,6 +136,7 @@ def lib() -> C.CDLL:
     L.tpl_state_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.tpl_set_tuning.argtypes = [vp, i32, i32]
     L.tpl_generate_configs.argtypes = [i32, i32, u64, i64, i64, i32, i64, vp, vp, vp, vp]
+    L.tpl_generate_configs_pyseed.argtypes = [i32, i32, vp, i64, i32, i64, vp, vp, vp, vp]
     L.tpl_synth_configs.argtypes = [vp, u64, i64, i64, vp, vp, vp]
     L.tpl_synth_actions.argtypes = [vp, u64, i64, i64, u64, vp, vp]
     for name in SYMBOLS:
@@ -151,19 +152,26 @@ def check(status: int) -> None:
         raise TplError(f"tetris_piclim status {status}: {lib().tpl_last_error().decode()}")
 
 
-def generate_configs(L: int, M: int, count: int, seed: int = 0, first: int = 0, threads: int = 0,
-                     max_iters: int = 0, with_solutions: bool = False):
+def generate_configs(L: int, M: int, count: int = 0, seed: int = 0, first: int = 0, threads: int = 0,
+                     max_iters: int = 0, with_solutions: bool = False, python_seeds=None):
     """Carved (solvable) prescribed configurations, produced on the host cores (game/tetris.py:226-352).
 
     Returns (rows uint16 [count, 20], pieces uint8 [count, M+1]) and, with_solutions, also
-    (solution uint8 [count, M, 2], solution_len int32 [count])."""
+    (solution uint8 [count, M, 2], solution_len int32 [count]).  With python_seeds=[s0, s1, ...] configuration i is
+    exactly what the reference builds after random.seed(s_i) (CPython's random stream is reproduced)."""
     import numpy as np
+    if python_seeds is not None:
+        seeds = np.ascontiguousarray(python_seeds, dtype=np.uint64)
+        count = len(seeds)
     rows = np.empty((count, 20), np.uint16)
     pieces = np.empty((count, M + 1), np.uint8)
     sol = np.zeros((count, M, 2), np.uint8) if with_solutions else None
     sol_len = np.zeros(count, np.int32) if with_solutions else None
     ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
-    check(lib().tpl_generate_configs(L, M, seed, first, count, threads, max_iters, ptr(rows), ptr(pieces), ptr(sol), ptr(sol_len)))
+    if python_seeds is not None:
+        check(lib().tpl_generate_configs_pyseed(L, M, ptr(seeds), count, threads, max_iters, ptr(rows), ptr(pieces), ptr(sol), ptr(sol_len)))
+    else:
+        check(lib().tpl_generate_configs(L, M, seed, first, count, threads, max_iters, ptr(rows), ptr(pieces), ptr(sol), ptr(sol_len)))
     return (rows, pieces, sol, sol_len) if with_solutions else (rows, pieces)
 
 

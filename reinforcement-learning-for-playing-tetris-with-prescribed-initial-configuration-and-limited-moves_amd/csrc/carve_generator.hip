@@ -24,6 +24,56 @@ struct Decisions {
     int randint(int lo, int hi) { return lo + (int)(rng(seed, 4, index, counter++) % (uint64_t)(hi - lo + 1)); }
 };
 
+// The reference draws from Python's `random` module (game/tetris.py:85,93,250,253).  This is that generator:
+// MT19937 seeded the way CPython's random.seed(int) seeds it (init_by_array over the 32-bit digits of the seed),
+// and randint / shuffle built on _randbelow_with_getrandbits (k = n.bit_length(); draw k bits until < n) -- so a
+// configuration can be regenerated from the same integer seed the reference was given.
+struct PyRandom {
+    uint32_t mt[624];
+    int idx = 625;
+
+    void init_genrand(uint32_t s) {
+        mt[0] = s;
+        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        idx = 624;
+    }
+    explicit PyRandom(uint64_t seed) {
+        uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+        const int len = key[1] ? 2 : 1;
+        init_genrand(19650218u);
+        int i = 1, j = 0;
+        for (int k = 624 > len ? 624 : len; k; --k) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+            if (++i >= 624) { mt[0] = mt[623]; i = 1; }
+            if (++j >= len) j = 0;
+        }
+        for (int k = 623; k; --k) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+            if (++i >= 624) { mt[0] = mt[623]; i = 1; }
+        }
+        mt[0] = 0x80000000u;
+    }
+    uint32_t next() {
+        if (idx >= 624) {
+            for (int k = 0; k < 624; ++k) {
+                const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7FFFFFFFu);
+                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11; y ^= (y << 7) & 0x9D2C5680u; y ^= (y << 15) & 0xEFC60000u; y ^= y >> 18;
+        return y;
+    }
+    uint32_t randbelow(uint32_t n) {                     // n >= 1
+        const int k = 32 - __builtin_clz(n);             // n.bit_length()
+        uint32_t r;
+        do r = next() >> (32 - k); while (r >= n);
+        return r;
+    }
+    int randint(int lo, int hi) { return lo + (int)randbelow((uint32_t)(hi - lo + 1)); }
+};
+
 struct Shape {
     int h, w;
     uint32_t col[4];   // column c of the piece as a bit-per-row pattern
@@ -92,9 +142,9 @@ inline bool carve(uint32_t* col, int piece, int rotations, int loc, bool allow_p
 }
 
 // _generate_initial_config (:226-284) for one configuration.  Returns false if max_iters (> 0) was reached.
-bool generate_one(int L, int M, uint64_t seed, uint64_t index, int64_t max_iters, uint16_t* rows_out,
-                  uint8_t* pieces_out, uint8_t* sol_out, int32_t* sol_len) {
-    Decisions rnd{seed, index};
+template <typename Random>
+bool generate_one(int L, int M, Random& rnd, int64_t max_iters, uint16_t* rows_out, uint8_t* pieces_out,
+                  uint8_t* sol_out, int32_t* sol_len) {
     Game g;
     const uint32_t filled = L >= kRows ? kColMask : (((1u << L) - 1u) << (kRows - L));
     for (int c = 0; c < kCols; ++c) g.col[c] = filled;                      // :228 L full rows
@@ -161,13 +211,13 @@ bool generate_one(int L, int M, uint64_t seed, uint64_t index, int64_t max_iters
 }  // namespace
 }  // namespace tpl
 
-extern "C" int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count, int32_t threads,
-                                    int64_t max_iters, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
-                                    int32_t* solution_len) {
+template <typename MakeRandom>
+static int run_generator(int32_t L, int32_t M, int64_t count, int32_t threads, int64_t max_iters, uint16_t* rows,
+                         uint8_t* pieces, uint8_t* solution, int32_t* solution_len, MakeRandom make_random) {
     using namespace tpl;
     if (L < 1 || L > 16) return fail_msg(TPL_ERR_ARG, "carving needs 1 <= L <= 16 (got %d)", L);
     if (M < 1 || M > 254) return fail_msg(TPL_ERR_ARG, "M=%d out of range [1, 254]", M);
-    if (count < 1 || first < 0 || !rows || !pieces) return fail_msg(TPL_ERR_ARG, "bad count/first/output pointers");
+    if (count < 1 || !rows || !pieces) return fail_msg(TPL_ERR_ARG, "bad count / output pointers");
     if (threads < 1) threads = (int32_t)std::thread::hardware_concurrency();
     if (threads < 1) threads = 1;
     if ((int64_t)threads > count) threads = (int32_t)count;
@@ -177,8 +227,9 @@ extern "C" int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t
         for (;;) {
             const int64_t k = next.fetch_add(1, std::memory_order_relaxed);
             if (k >= count) return;
-            const bool ok = generate_one(L, M, seed, (uint64_t)(first + k), max_iters, rows + k * kRows,
-                                         pieces + k * (M + 1), solution ? solution + k * (int64_t)M * 2 : nullptr,
+            auto rnd = make_random(k);
+            const bool ok = generate_one(L, M, rnd, max_iters, rows + k * kRows, pieces + k * (M + 1),
+                                         solution ? solution + k * (int64_t)M * 2 : nullptr,
                                          solution_len ? solution_len + k : nullptr);
             if (!ok) failed.store(k, std::memory_order_relaxed);
         }
@@ -189,6 +240,22 @@ extern "C" int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t
     for (auto& th : pool) th.join();
     if (failed.load() >= 0)
         return fail_msg(TPL_ERR_STATE, "configuration %lld did not finish within %lld iterations",
-                        (long long)(first + failed.load()), (long long)max_iters);
+                        (long long)failed.load(), (long long)max_iters);
     return TPL_OK;
+}
+
+extern "C" int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count, int32_t threads,
+                                    int64_t max_iters, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
+                                    int32_t* solution_len) {
+    if (first < 0) return tpl::fail_msg(TPL_ERR_ARG, "first is negative");
+    return run_generator(L, M, count, threads, max_iters, rows, pieces, solution, solution_len,
+                         [=](int64_t k) { return tpl::Decisions{seed, (uint64_t)(first + k)}; });
+}
+
+extern "C" int tpl_generate_configs_pyseed(int32_t L, int32_t M, const uint64_t* seeds, int64_t count, int32_t threads,
+                                           int64_t max_iters, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
+                                           int32_t* solution_len) {
+    if (!seeds) return tpl::fail_msg(TPL_ERR_ARG, "seeds is null");
+    return run_generator(L, M, count, threads, max_iters, rows, pieces, solution, solution_len,
+                         [=](int64_t k) { return tpl::PyRandom(seeds[k]); });
 }

@@ -58,6 +58,23 @@ def test_native_generator_equals_oracle_and_configs_are_solvable(oracle, L, M, n
         assert np.all(pieces[k, : sol_len[k]] < 7) and 1 <= sol_len[k] <= M
 
 
+@pytest.mark.parametrize("name", ["carved_L5_M20.npz", "carved_L10_M40.npz"])
+def test_native_generator_reproduces_the_reference_from_the_same_python_seed(name):
+    """The F2 fixtures were made by `random.seed(1000*L + k); Tetris(L, M, warm_reset=False, debug=True)` in the
+    reference.  Given the same integer seeds (and its own MT19937 + CPython randint/shuffle) the native generator
+    must produce the same boards, piece lists and solutions."""
+    import tetris_piclim as T
+    f = load_golden(name)
+    L, M = int(f["L"]), int(f["M"])
+    n = f["rows"].shape[0]
+    seeds = [1000 * L + k for k in range(n)]
+    rows, pieces, sol, sol_len = T.generate_configs(L, M, python_seeds=seeds, with_solutions=True, threads=4)
+    assert np.array_equal(rows, f["rows"]) and np.array_equal(pieces, f["pieces"])
+    assert np.array_equal(sol_len, f["sol_len"])
+    for k in range(n):
+        assert np.array_equal(sol[k, : sol_len[k]], f["sol"][k, : sol_len[k]]), k
+
+
 def test_native_generator_statistics_match_the_reference_generator():
     """Same algorithm, different random stream: the distribution of solution lengths must look like the
     reference's (fixtures: 64 games at L=5, 32 at L=10)."""
