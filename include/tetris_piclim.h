@@ -178,6 +178,20 @@ int tpl_generate_configs_pyseed(int32_t L, int32_t M, const uint64_t* seeds, int
                                 int64_t max_iters, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
                                 int32_t* solution_len);
 
+/* Replaces the forward generator + solver behind Tetris.reset() (game/tetris_algo_main/: TetrisGameGenerator.py
+ * :15-29,72-106, TetrisSolver.py:112-163, main.py generate_batch :29-74; its worker game/tetris.py:482-488):
+ * for each seed, random-fill the board to `initial_height_max`, draw a 7-bag sequence of M pieces, and run the greedy
+ * depth-first solver with `max_attempts`.  Game i equals the reference's TetrisGameGenerator(seed=seeds[i], goal=L,
+ * tetrominoes=M, initial_height_max) and its TetrisSolver verdict.  HOST pointers; outputs for EVERY seed:
+ * rows [count][20], sequence [count][M] (piece ids of Tetris.move, game/tetris.py:8-16), winnable [count],
+ * failed_attempts [count] (optional), solution [count][M][2] as (rotations, location) of Tetris.move (optional),
+ * solver_stack [count][M][3] as the solver's own (letter index in IJLOSTZ, rotation, column) (optional),
+ * solution_len [count] (optional; 0 when not winnable).  The reference defaults are initial_height_max 4,
+ * max_attempts 1000, seeds 0..99 (main.py:35-42). */
+int tpl_forward_generate(int32_t L, int32_t M, int32_t initial_height_max, int32_t max_attempts, const uint64_t* seeds,
+                         int64_t count, int32_t threads, uint16_t* rows, uint8_t* sequence, uint8_t* winnable,
+                         int32_t* failed_attempts, uint8_t* solution, uint8_t* solver_stack, int32_t* solution_len);
+
 /* Synthetic workload of SURVEY 8(d), generated on the device from a counter-based hash
  * keyed by (seed, stream, global board index, counter); DESIGN.md states the function. */
 int tpl_synth_configs(tpl_env* env, uint64_t seed, int64_t first, int64_t count,

@@ -16,9 +16,10 @@ _ROOT = os.path.dirname(_PKG)
 # development switch: TPL_DIAG_CLOCK=1 builds a diagnostic library whose policy kernel stamps its clocks (tools/policy_clock.py)
 _DIAG = os.environ.get("TPL_DIAG_CLOCK") == "1"
 LIB_PATH = os.path.join(_CSRC, "libtetris_piclim_diag.so" if _DIAG else "libtetris_piclim.so")
-_UNITS = [os.path.join(_CSRC, f) for f in ("tetris_piclim.hip", "carve_generator.hip", "policy_mlp.hip")]
+_UNITS = [os.path.join(_CSRC, f) for f in ("tetris_piclim.hip", "carve_generator.hip", "forward_generator.hip",
+                                           "policy_mlp.hip")]
 _SOURCES = _UNITS + [os.path.join(_CSRC, "tpl_device.h"), os.path.join(_CSRC, "tpl_internal.h"),
-                     os.path.join(_CSRC, "tpl_step.h"),
+                     os.path.join(_CSRC, "tpl_step.h"), os.path.join(_CSRC, "py_random.h"),
                      os.path.join(_ROOT, "include", "tetris_piclim.h")]
 
 # entry points declared in include/tetris_piclim.h (tests check that the .so exports every one of them)
@@ -26,7 +27,7 @@ SYMBOLS = [
     "tpl_last_error", "tpl_version", "tpl_workspace_bytes", "tpl_pool_bytes", "tpl_create", "tpl_destroy",
     "tpl_set_options", "tpl_load_configs", "tpl_reset", "tpl_move", "tpl_step", "tpl_get_state",
     "tpl_expand_obs", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
-    "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_decode_actions", "tpl_generate_configs", "tpl_generate_configs_pyseed",
+    "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_decode_actions", "tpl_generate_configs", "tpl_generate_configs_pyseed", "tpl_forward_generate",
     "tpl_policy_image_bytes", "tpl_policy_pack", "tpl_policy_act",
     "tpl_explore_actions", "tpl_actor_rollout",
 ]
@@ -137,6 +138,7 @@ def lib() -> C.CDLL:
     L.tpl_set_tuning.argtypes = [vp, i32, i32]
     L.tpl_generate_configs.argtypes = [i32, i32, u64, i64, i64, i32, i64, vp, vp, vp, vp]
     L.tpl_generate_configs_pyseed.argtypes = [i32, i32, vp, i64, i32, i64, vp, vp, vp, vp]
+    L.tpl_forward_generate.argtypes = [i32, i32, i32, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp]
     L.tpl_synth_configs.argtypes = [vp, u64, i64, i64, vp, vp, vp]
     L.tpl_synth_actions.argtypes = [vp, u64, i64, i64, u64, vp, vp]
     for name in SYMBOLS:
@@ -173,6 +175,26 @@ def generate_configs(L: int, M: int, count: int = 0, seed: int = 0, first: int =
     else:
         check(lib().tpl_generate_configs(L, M, seed, first, count, threads, max_iters, ptr(rows), ptr(pieces), ptr(sol), ptr(sol_len)))
     return (rows, pieces, sol, sol_len) if with_solutions else (rows, pieces)
+
+
+def forward_generate(L: int, M: int, seeds, initial_height_max: int = 4, max_attempts: int = 1000, threads: int = 0):
+    """The reference's forward generator + solver (game/tetris_algo_main/) for the given integer seeds.
+
+    Returns a dict of numpy arrays over ALL seeds: rows [n, 20], sequence [n, M] (piece ids of Tetris.move),
+    winnable [n] bool, failed_attempts [n], solution [n, M, 2] (rotations, location), solver_stack [n, M, 3],
+    solution_len [n].  Game i equals TetrisGameGenerator(seed=seeds[i], ...) and its TetrisSolver verdict."""
+    import numpy as np
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+    n = len(seeds)
+    out = dict(rows=np.zeros((n, 20), np.uint16), sequence=np.zeros((n, M), np.uint8), winnable=np.zeros(n, np.uint8),
+               failed_attempts=np.zeros(n, np.int32), solution=np.zeros((n, M, 2), np.uint8),
+               solver_stack=np.zeros((n, M, 3), np.uint8), solution_len=np.zeros(n, np.int32))
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    check(lib().tpl_forward_generate(L, M, initial_height_max, max_attempts, ptr(seeds), n, threads, ptr(out["rows"]),
+                                     ptr(out["sequence"]), ptr(out["winnable"]), ptr(out["failed_attempts"]),
+                                     ptr(out["solution"]), ptr(out["solver_stack"]), ptr(out["solution_len"])))
+    out["winnable"] = out["winnable"].astype(bool)
+    return out
 
 
 def pack_policy(params):

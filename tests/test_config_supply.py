@@ -88,6 +88,45 @@ def test_native_generator_statistics_match_the_reference_generator():
         assert abs(sol_len.mean() - ref.mean()) < 4 * se + 0.5, (name, sol_len.mean(), ref.mean())
 
 
+LETTER_TO_ID = np.array([0, 2, 1, 6, 4, 3, 5], np.uint8)        # I J L O S T Z -> ids of Tetris.move (game/tetris.py:8-16)
+
+
+@pytest.mark.parametrize("name", ["forward_L5_M20.npz", "forward_L3_M20.npz", "forward_L10_M40.npz"])
+def test_forward_generator_and_solver_reproduce_the_reference_seed_for_seed(oracle, name):
+    """tests/golden/forward_*.npz hold what the reference's TetrisGameGenerator + TetrisSolver produce for each
+    seed (make_golden_forward.py).  The native restatement must give the same board, sequence, verdict, failed-
+    attempt count and solver stack; and every game it calls winnable is won by its solution under Tetris.move."""
+    import tetris_piclim as T
+    f = load_golden(name)
+    L, M = int(f["L"]), int(f["M"])
+    out = T.forward_generate(L, M, f["seeds"], threads=3)
+    assert np.array_equal(out["rows"], f["rows"])
+    assert np.array_equal(out["sequence"], LETTER_TO_ID[f["sequence"]])
+    assert np.array_equal(out["winnable"], f["winnable"].astype(bool))
+    assert np.array_equal(out["failed_attempts"], f["failed_attempts"])
+    assert np.array_equal(out["solution_len"], f["stack_len"])
+    for k in range(len(f["seeds"])):
+        n = int(f["stack_len"][k])
+        assert np.array_equal(out["solver_stack"][k, :n], f["stack"][k, :n]), k
+        if out["winnable"][k]:
+            pieces = np.concatenate([out["sequence"][k], [0]]).astype(np.uint8)      # M+1 entries, pad at the END
+            g = oracle.Game(L, M, out["rows"][k], pieces)
+            for rot, loc in out["solution"][k, :n]:
+                assert g.state == 0
+                g.move(int(rot), int(loc))
+            assert g.state == 1 and g.lines_cleared >= L, k
+    one = T.forward_generate(L, M, f["seeds"][:7], threads=1)
+    assert np.array_equal(one["rows"], out["rows"][:7]) and np.array_equal(one["winnable"], out["winnable"][:7])
+
+
+def test_forward_generator_argument_errors():
+    import tetris_piclim as T
+    with pytest.raises(T.TplError):
+        T.forward_generate(5, 20, [0], initial_height_max=0)
+    with pytest.raises(T.TplError):
+        T.forward_generate(5, 0, [0])
+
+
 def test_pool_file_round_trip(tmp_path):
     import tetris_piclim as T
     rows, pieces, sol, sol_len = T.generate_configs(5, 20, 64, seed=9, with_solutions=True)
@@ -109,6 +148,28 @@ def test_native_generator_argument_errors():
         T.generate_configs(5, 0, 1)
     with pytest.raises(T.TplError):
         T.generate_configs(10, 40, 2, max_iters=3)        # cannot finish in three iterations
+
+
+@pytest.mark.gpu
+def test_forward_pool_replays_to_a_win_on_the_gpu():
+    import torch
+    import tetris_piclim as T
+    L, M = 3, 20
+    out = T.forward_generate(L, M, np.arange(400))
+    keep = out["winnable"]
+    assert keep.mean() > 0.5
+    rows = out["rows"][keep]
+    pieces = np.concatenate([out["sequence"][keep], np.zeros((keep.sum(), 1), np.uint8)], axis=1)
+    sol, sol_len = out["solution"][keep], out["solution_len"][keep]
+    n = rows.shape[0]
+    env = T.BatchedTetris(L, M, n, assign="sequential", config_pool=(rows, pieces))
+    env.reset()
+    for t in range(int(sol_len.max())):
+        active = t < sol_len
+        env.move(np.where(active, sol[:, t, 0], 0).astype(np.uint8), np.where(active, sol[:, t, 1], 0).astype(np.uint8))
+    s = env.packed_state()
+    assert bool((s["state"] == T.WON).all()) and bool((s["lines"] >= L).all())
+    env.terminate()
 
 
 @pytest.mark.gpu
