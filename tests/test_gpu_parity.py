@@ -511,6 +511,47 @@ def test_global_offsets_beyond_32_bits(T, oracle, assign):
     gpu.terminate()
 
 
+@pytest.mark.parametrize("L,M", [(2, 7), (4, 33), (10, 40)])
+def test_long_soak_against_the_oracle(T, oracle, L, M):
+    """Two thousand lockstep steps with auto-reset from carved (solvable) configurations mixed with synthetic
+    ones, alternating single steps and fused rollouts; compared with the oracle at the end and on the way."""
+    import torch
+    n, seed, steps = 16384, 1000 + L, 2000
+    gen = min(L, 16)
+    c_rows, c_pieces = T.generate_configs(gen, M, 1500, seed=seed) if M >= 2 * gen else (np.zeros((0, 20), np.uint16), np.zeros((0, M + 1), np.uint8))
+    gpu = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True, reward=(0.5, 4.0, -0.25))
+    s_rows, s_pieces = gpu.synthetic_configs(1500)
+    rows = np.concatenate([c_rows, _np(s_rows).view(np.uint16)])
+    pieces = np.concatenate([c_pieces, _np(s_pieces)])
+    gpu.load_configs(rows, pieces)
+    gpu.reset()
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_pool(rows, pieces)
+    cpu.set_options(auto_reset=True, assign_mode=0, per_line=0.5, win=4.0, lose=-0.25)
+    cpu.reset()
+    t = 0
+    while t < steps:
+        if (t // 100) % 2 == 0:                                  # a block of single steps
+            for _ in range(100):
+                a = gpu.synthetic_actions(t)
+                _, r, d, _ = gpu.step(a, observe=False)
+                r_c, d_c = cpu.step(_np(a))
+                t += 1
+            assert np.array_equal(_np(r), r_c) and np.array_equal(_np(d).astype(np.uint8), d_c), t
+        else:                                                    # a fused rollout of 100 steps
+            acts = torch.stack([gpu.synthetic_actions(t + k) for k in range(100)])
+            rsum, fin = gpu.rollout(acts)
+            acc = np.zeros(n, np.float32)
+            for k in range(100):
+                r_c, d_c = cpu.step(_np(acts[k]))
+                acc += r_c
+            t += 100
+            assert np.array_equal(_np(rsum), acc), t
+        _assert_state_equal(_state(gpu), cpu.get_state(), f"L={L} M={M} step {t}")
+    assert gpu.stats() == cpu.stats() and gpu.stats()["wins"] > 0 or L > 4
+    gpu.terminate()
+
+
 def test_step_is_graph_capturable_and_replays_exactly(T, oracle):
     """The ABI promises no host synchronisation inside tpl_step: capture 8 steps into one HIP graph, replay it."""
     import torch
