@@ -13,9 +13,12 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 _ROOT = os.path.dirname(_PKG)
-# development switch: TPL_DIAG_CLOCK=1 builds a diagnostic library whose policy kernel stamps its clocks (tools/policy_clock.py)
+# development switches: TPL_DIAG_CLOCK=1 builds a diagnostic library whose policy kernel stamps its clocks
+# (tools/policy_clock.py); TPL_EXTRA_DEFINE=NAME builds libtetris_piclim_NAME.so with -DNAME for A/B runs on one box
 _DIAG = os.environ.get("TPL_DIAG_CLOCK") == "1"
-LIB_PATH = os.path.join(_CSRC, "libtetris_piclim_diag.so" if _DIAG else "libtetris_piclim.so")
+_EXTRA = os.environ.get("TPL_EXTRA_DEFINE", "")
+LIB_PATH = os.path.join(_CSRC, "libtetris_piclim_diag.so" if _DIAG else
+                        f"libtetris_piclim_{_EXTRA}.so" if _EXTRA else "libtetris_piclim.so")
 _UNITS = [os.path.join(_CSRC, f) for f in ("tetris_piclim.hip", "carve_generator.hip", "forward_generator.hip",
                                            "policy_mlp.hip")]
 _SOURCES = _UNITS + [os.path.join(_CSRC, "tpl_device.h"), os.path.join(_CSRC, "tpl_internal.h"),
@@ -80,6 +83,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
                 cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", tmp] + _UNITS
                 if _DIAG:
                     cmd.insert(1, "-DTPL_DIAG_CLOCK")
+                if _EXTRA:
+                    cmd.insert(1, "-D" + _EXTRA)
                 res = subprocess.run(cmd, capture_output=True, text=True)
                 if res.returncode != 0:
                     raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)

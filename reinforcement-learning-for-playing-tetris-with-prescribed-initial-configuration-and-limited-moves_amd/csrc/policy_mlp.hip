@@ -13,7 +13,8 @@
 // f32 biases) stay resident in the CU's 160 KB LDS, pre-packed on the host lane-major in the permuted k order the
 // hand-off produces, so an A fragment is one conflict-free ds_read_b128; a 512-thread workgroup loads them once
 // and loops over board tiles.  The observation is never materialised: each lane turns its board's 32-B state into
-// the layer-1 B fragments directly (cells are 0/1: a nibble becomes two packed bf16 registers with two multiplies).
+// the layer-1 B fragments directly (a 0/1 feature is the single bf16 bit 0x4000 = 2.0 with halved weights, so a
+// fragment register is one shift and one mask of the feature word).
 // Internal feature order of layer 1 (the packer permutes W1's columns, callers keep tpl_expand_obs' order):
 // k = 20x + y for the cell in row y, column x -- how the state stores the board -- then the 17 extras at 200..216.
 //
@@ -64,7 +65,11 @@ static inline uint16_t bf16_rne(float f) {
     return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
+// k of element j of lane group g in k-step s.  Hidden layers: dictated by the accumulator hand-off.
 static inline int frag_k(int s, int g, int j) { return 32 * s + 16 * (j >> 2) + 4 * g + (j & 3); }
+// Layer 1 is free to choose, because its B fragments are made from bits: the two elements of register i come from
+// bits 4g + i and 16 + 4g + i of feature word s, so that one shift and one mask turn the word into the register.
+static inline int frag_k1(int s, int g, int j) { return 32 * s + 4 * g + (j >> 1) + 16 * (j & 1); }
 
 static inline int std_feature(int k) {     // internal layer-1 feature -> tpl_expand_obs index, -1 for a pad
     if (k < 200) return (k % 20) * 10 + (k / 20);
@@ -92,10 +97,13 @@ extern "C" int tpl_policy_pack(const float* w1, const float* b1, const float* w2
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
                         const int c = lane & 15, g = lane >> 4;
-                        int k = frag_k(s, g, j);
+                        int k = first ? frag_k1(s, g, j) : frag_k(s, g, j);
+                        // a 0/1 feature enters layer 1 as the single bf16 bit 0x4000 = 2.0, so its weights are halved
+                        // (exact: a power of two); the two counters 214, 215 enter as numbers
+                        const float scale = (first && k != 214 && k != 215) ? 0.5f : 1.0f;
                         if (first) k = std_feature(k);
                         const int row = 16 * m + c;
-                        const float v = (k >= 0 && k < in && row < rows) ? w[(size_t)row * in + k] : 0.0f;
+                        const float v = (k >= 0 && k < in && row < rows) ? scale * w[(size_t)row * in + k] : 0.0f;
                         p[off / 2 + (((m * ks + s) * 64 + lane) * 8 + j)] = bf16_rne(v);
                     }
     };
@@ -119,11 +127,6 @@ namespace p16 {
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     f32x2 v = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-
-// two cell bits -> two packed bf16 values (1.0 = 0x3F80)
-__device__ __forceinline__ uint32_t bits_to_bf16x2(uint32_t two_bits) {
-    return ((two_bits & 1u) | ((two_bits & 2u) << 15)) * 0x3F80u;
 }
 
 // ReLU on two packed bf16 values: a negative bf16 is a negative int16, so one v_pk_max_i16 clears it
@@ -231,19 +234,23 @@ __device__ __forceinline__ void dense(const uint8_t* lds, int w_off, const float
 __device__ __forceinline__ void policy_logits(const uint8_t* lds, int lane, int g, const uint32_t (&fb)[2][8],
                                               f32x4 (&logits)[2]) {
     const float* bias = (const float*)(lds + kOffB);
+    // layer-1 B fragments straight from the feature bits: register i of lane group g holds bits 4g + i and
+    // 16 + 4g + i of word s as the bf16 pattern 0x4000 (= 2.0; the packer halves the weights) -- one shift, one mask
     uint4 x0[2][kKs1];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int s = 0; s < kKs1; ++s) {
-            // k = 32s + 4g + {0..3} and 32s + 16 + 4g + {0..3}: two nibbles of cell word s
-            const uint32_t w = fb[t][s] >> (4 * g);
+            const uint32_t u = fb[t][s] >> (4 * g);
             uint4 q;
-            q.x = bits_to_bf16x2(w);
-            q.y = bits_to_bf16x2(w >> 2);
-            q.z = bits_to_bf16x2(w >> 16);
-            q.w = bits_to_bf16x2(w >> 18);
-            if (s == 6 && g == 1) q.w = fb[t][7];        // k = 192 + 16 + 4 + {2, 3} = 214, 215: L_rem, M_rem
+            q.x = (u << 14) & 0x40004000u;
+            q.y = (u << 13) & 0x40004000u;
+            q.z = (u << 12) & 0x40004000u;
+            q.w = (u << 11) & 0x40004000u;
+            if (s == 6 && g == 1) {                      // bits 22, 23 of word 6 = features 214, 215: L_rem, M_rem
+                q.z |= fb[t][7] << 16;
+                q.w |= fb[t][7] & 0xFFFF0000u;
+            }
             x0[t][s] = q;
         }
     uint4 xa[2][kKsH], xb[2][kKsH];
