@@ -328,22 +328,44 @@ class BatchedTetris:
 
 
 class Tetris:
-    """One board with the reference's own surface and attribute types (game/tetris.py:140-214, 354-449).
+    """One board with the reference's own constructor, surface and attribute types (game/tetris.py:140-214,
+    354-449): `Tetris(L, M, warm_reset=True, render=False, framerate=30, debug=False)`.
 
-    `board` is a 20x10 numpy bool array, `pieces` a Python list, `state` None / True / False.  The prescribed
-    configuration comes from `configs=(rows, pieces)` (one or more; reset() walks through them in order)
-    instead of the reference's carving workers.
-    """
+    `board` is a 20x10 numpy bool array, `pieces` a Python list, `state` None / True / False, and with debug=True
+    `solution` is the list of (rotations, location) that wins the current configuration (:155-156).  Like the
+    reference's constructor it carves its own prescribed configurations -- with the native generator, a pool of
+    `pool_size` at a time instead of two worker processes; `configs=(rows, pieces)` supplies them instead.
+    reset() moves on to the next configuration of the pool.  render=True (the pygame window, :158-182) is out of
+    scope and raises."""
 
     _STATE = {RUNNING: None, WON: True, LOST: False}
 
-    def __init__(self, L: int, M: int, configs, device="cuda:0"):
-        rows, pieces = configs
+    def __init__(self, L: int, M: int, warm_reset: bool = True, render: bool = False, framerate: int = 30,
+                 debug: bool = False, configs=None, device="cuda:0", seed: Optional[int] = None, pool_size: int = 64):
+        if render:
+            raise NotImplementedError("the pygame window of the reference is not part of this build")
+        del warm_reset, framerate                      # the warm-reset workers are replaced by the configuration pool
+        self.L, self.M, self.debug = L, M, debug
+        self._solutions = None
+        if configs is None:
+            seed = int.from_bytes(__import__("os").urandom(4), "little") if seed is None else seed
+            rows, pieces, sol, sol_len = _lib.generate_configs(L, M, pool_size, seed=seed, with_solutions=True)
+            self._solutions = [[(int(r), int(c)) for r, c in sol[k, : sol_len[k]]] for k in range(pool_size)]
+        else:
+            rows, pieces = configs
         self._pieces_host = np.asarray(pieces, dtype=np.uint8).reshape(-1, M + 1)
         self._env = BatchedTetris(L, M, 1, device=device, assign="sequential", config_pool=(rows, self._pieces_host))
-        self.L, self.M = L, M
         self._episode = 0
         self._env.reset()
+
+    def _config(self) -> int:
+        return (self._episode & 0xFF) % self._pieces_host.shape[0]        # the device keeps 8 episode bits
+
+    @property
+    def solution(self) -> list:
+        if not self.debug or self._solutions is None:
+            raise AttributeError("solution is recorded only with debug=True and self-generated configurations")
+        return self._solutions[self._config()]
 
     def move(self, rotations: int, location: int) -> None:
         self._env.move(torch.tensor([rotations], dtype=torch.int64), torch.tensor([location], dtype=torch.int64))
@@ -363,8 +385,7 @@ class Tetris:
     @property
     def pieces(self) -> list:
         left = int(self._s()["pieces_left"][0])
-        cfg = (self._episode & 0xFF) % self._pieces_host.shape[0]     # the device keeps 8 episode bits
-        return self._pieces_host[cfg][self.M + 1 - left:].tolist()
+        return self._pieces_host[self._config()][self.M + 1 - left:].tolist()
 
     lines_cleared = property(lambda self: int(self._s()["lines"][0]))
     moves_used = property(lambda self: int(self._s()["moves"][0]))

@@ -57,6 +57,29 @@ def test_f1_plumbing_with_reference_style_object(T, prefix):
     game.terminate()
 
 
+def test_reference_test_carving_invertability_verbatim(T):
+    """The reference's own TestTetris.test_carving_invertability (game/main.py:49-57), with `tetris.Tetris` swapped
+    for this build's class and nothing else changed."""
+    tetris = T
+    L, M = 15, 40
+
+    game = tetris.Tetris(L, M, warm_reset=False, debug=True)
+
+    for i in range(0, len(game.solution)):
+        rotations, location = game.solution[i]
+        game.move(rotations, location)
+    assert game.state, 'Carving inversion failed'
+    # and again after reset(): the next prescribed configuration, counters zeroed
+    game.reset()
+    assert game.state is None and game.lines_cleared == 0 and game.moves_used == 0 and len(game.pieces) == M + 1
+    for rotations, location in game.solution:
+        game.move(rotations, location)
+    assert game.state is True and game.lines_cleared >= L
+    board, cur, nxt, l_rem, m_rem, state = game.get_state()
+    assert board.shape == (20, 10) and board.dtype == bool and l_rem <= 0 and state is True
+    game.terminate()
+
+
 # ------------------------------------------------------------------------------------------------- F2
 @pytest.mark.parametrize("name", ["carved_L5_M20.npz", "carved_L10_M40.npz"])
 def test_f2_carved_solutions_win(T, name):
