@@ -122,6 +122,12 @@ int tpl_expand_obs(tpl_env* env, void* out, int32_t dtype, void* stream);
  * lowest index on ties. */
 int tpl_decode_actions(tpl_env* env, const void* logits, int32_t dtype, uint8_t* action, void* stream);
 
+/* The same observation for `count` recorded 32-byte states (the states_a / states_b outputs of tpl_actor_rollout,
+ * e.g. a minibatch gathered from a replay buffer) instead of the environment's resident boards.  L and M come
+ * from `env`.  out: [count][217] of `dtype`. */
+int tpl_expand_states(tpl_env* env, const void* states_a, const void* states_b, int64_t count, void* out,
+                      int32_t dtype, void* stream);
+
 /* ---- fused policy: observation -> Model(217, 14) -> action in one kernel (model/model.py:9-20, train.py:26) ----
  * tpl_policy_pack (host): the ten parameter arrays of the five Linear layers, float32, torch layout
  * (weight [out][in] row-major, bias [out]; sizes 128x217, 128x128 x3, 14x128) -> an image of

@@ -29,7 +29,7 @@ _SOURCES = _UNITS + [os.path.join(_CSRC, "tpl_device.h"), os.path.join(_CSRC, "t
 SYMBOLS = [
     "tpl_last_error", "tpl_version", "tpl_workspace_bytes", "tpl_pool_bytes", "tpl_create", "tpl_destroy",
     "tpl_set_options", "tpl_load_configs", "tpl_reset", "tpl_move", "tpl_step", "tpl_get_state",
-    "tpl_expand_obs", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
+    "tpl_expand_obs", "tpl_expand_states", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
     "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_decode_actions", "tpl_generate_configs", "tpl_generate_configs_pyseed", "tpl_forward_generate",
     "tpl_policy_image_bytes", "tpl_policy_pack", "tpl_policy_act",
     "tpl_explore_actions", "tpl_actor_rollout",
@@ -130,6 +130,7 @@ def lib() -> C.CDLL:
     L.tpl_rollout.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, vp]
     L.tpl_get_state.argtypes = [vp] * 9
     L.tpl_expand_obs.argtypes = [vp, vp, i32, vp]
+    L.tpl_expand_states.argtypes = [vp, vp, vp, i64, vp, i32, vp]
     L.tpl_decode_actions.argtypes = [vp, vp, i32, vp, vp]
     L.tpl_policy_image_bytes.restype = sz
     L.tpl_policy_image_bytes.argtypes = []

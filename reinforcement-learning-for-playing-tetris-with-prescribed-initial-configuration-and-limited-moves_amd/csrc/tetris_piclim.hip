@@ -610,21 +610,35 @@ int tpl_get_state(tpl_env* e, uint16_t* rows, uint8_t* cur, uint8_t* nxt, uint8_
     return TPL_OK;
 }
 
-int tpl_expand_obs(tpl_env* e, void* out, int32_t dtype, void* stream) {
-    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
-    if (!out) return fail_msg(TPL_ERR_ARG, "out is null");
-    DeviceGuard guard(e->device);
-    const dim3 grid(blocks_for(e->n)), block(kBlock);
+static int launch_expand(tpl_env* e, const uint4* plane_a, const uint4* plane_b, int64_t n, void* out, int32_t dtype,
+                         hipStream_t stream) {
+    const dim3 grid(blocks_for(n)), block(kBlock);
     if (dtype == TPL_F32)
-        hipLaunchKernelGGL(expand_obs_kernel<float>, grid, block, 0, (hipStream_t)stream, e->plane_a, e->plane_b, e->n,
-                           (uint32_t)e->L, (uint32_t)e->M, (float*)out);
+        hipLaunchKernelGGL(expand_obs_kernel<float>, grid, block, 0, stream, plane_a, plane_b, n, (uint32_t)e->L,
+                           (uint32_t)e->M, (float*)out);
     else if (dtype == TPL_BF16)
-        hipLaunchKernelGGL(expand_obs_kernel<__hip_bfloat16>, grid, block, 0, (hipStream_t)stream, e->plane_a, e->plane_b,
-                           e->n, (uint32_t)e->L, (uint32_t)e->M, (__hip_bfloat16*)out);
+        hipLaunchKernelGGL(expand_obs_kernel<__hip_bfloat16>, grid, block, 0, stream, plane_a, plane_b, n, (uint32_t)e->L,
+                           (uint32_t)e->M, (__hip_bfloat16*)out);
     else
         return fail_msg(TPL_ERR_ARG, "unknown observation dtype %d", dtype);
     TPL_HIP(hipGetLastError());
     return TPL_OK;
+}
+
+int tpl_expand_obs(tpl_env* e, void* out, int32_t dtype, void* stream) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!out) return fail_msg(TPL_ERR_ARG, "out is null");
+    DeviceGuard guard(e->device);
+    return launch_expand(e, e->plane_a, e->plane_b, e->n, out, dtype, (hipStream_t)stream);
+}
+
+int tpl_expand_states(tpl_env* e, const void* states_a, const void* states_b, int64_t count, void* out, int32_t dtype,
+                      void* stream) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!states_a || !states_b || !out) return fail_msg(TPL_ERR_ARG, "states/out is null");
+    if (count < 1) return fail_msg(TPL_ERR_ARG, "count must be positive");
+    DeviceGuard guard(e->device);
+    return launch_expand(e, (const uint4*)states_a, (const uint4*)states_b, count, out, dtype, (hipStream_t)stream);
 }
 
 int tpl_decode_actions(tpl_env* e, const void* logits, int32_t dtype, uint8_t* action, void* stream) {

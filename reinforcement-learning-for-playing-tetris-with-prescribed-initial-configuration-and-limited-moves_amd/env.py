@@ -266,6 +266,17 @@ class BatchedTetris:
         b = self._workspace[stride: stride + n * 16].view(torch.int32).view(n, 4).clone()
         return a, b
 
+    def expand_states(self, states_a: torch.Tensor, states_b: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+        """[K, 217] observations of K recorded 32-byte states (int32 [K, 4] pairs as actor_rollout(record_states=True)
+        returns them, e.g. a replay-buffer minibatch)."""
+        a = states_a.reshape(-1, 4).contiguous()
+        b = states_b.reshape(-1, 4).contiguous()
+        if a.shape != b.shape or a.dtype != torch.int32 or b.dtype != torch.int32:
+            raise ValueError("states_a / states_b must be int32 [..., 4] tensors of equal shape")
+        out = torch.empty((a.shape[0], OBS_DIM), dtype=dtype, device=self.device)
+        check(self._lib.tpl_expand_states(self._h, _ptr(a), _ptr(b), a.shape[0], _ptr(out), _OBS_CODES[dtype], self._stream()))
+        return out
+
     def packed_state(self) -> dict:
         """Everything get_state() and the public attributes expose, in the interchange layout (device tensors)."""
         n, d = self.num_envs, self.device

@@ -192,6 +192,9 @@ def test_actor_rollout_megakernel_equals_the_step_by_step_loop(T, oracle, auto, 
     for t in range(steps):
         a_planes, b_planes = ref.raw_planes()
         assert torch.equal(out["states_a"][t], a_planes) and torch.equal(out["states_b"][t], b_planes), t
+        if t % 8 == 0:      # a recorded state expands to the observation the environment showed at that moment
+            idx = torch.arange(0, n, 7, device=ref.device)
+            assert torch.equal(ref.expand_states(out["states_a"][t][idx], out["states_b"][t][idx]), ref.observe()[idx]), t
         greedy = ref.policy_act(image).clone()
         action = ref.explore_actions(greedy.clone(), eps, seed=5, step=100 + t)
         explored += int((action != greedy).sum())
