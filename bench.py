@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--actor-boards", type=int, default=262144, help="boards of the config-5 actor-loop side measurement (0 = skip)")
+    ap.add_argument("--carved-pool", type=int, default=65536, help="size of the carved pool of the realism run (0 = skip)")
     ap.add_argument("--chunk", type=int, default=50, help="steps per launch of the fused-rollout side measurement (0 = skip)")
     args = ap.parse_args()
 
@@ -161,6 +162,29 @@ def main():
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
     elapsed = float(t_all.item())
 
+    # secondary figure (SURVEY 8d "realism run"): the same step loop on a pool of CARVED (solvable) configurations from
+    # the native generator instead of the synthetic half-filled boards
+    carved = None
+    if args.carved_pool > 0 and world == 1:
+        c_rows, c_pieces = T.generate_configs(L, M, args.carved_pool, seed=args.seed)
+        env.load_configs(c_rows, c_pieces)
+        env.reset()
+        for t in range(W):
+            env.step_into(actions[t % S], reward, done)
+        torch.cuda.synchronize(dev)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        kc = min(K, 500)
+        c0.record()
+        for t in range(W, W + kc):
+            env.step_into(actions[t % S], reward, done)
+        c1.record()
+        torch.cuda.synchronize(dev)
+        ms = c0.elapsed_time(c1) / kc
+        st = env.stats()
+        carved = {"value": float(n) / (ms * 1e-3), "unit": "env-steps/s", "ms_per_step": ms, "pool": args.carved_pool,
+                  "mean_moves_per_episode": (W + kc) * float(n) / max(st["episodes"], 1),
+                  "win_rate": st["wins"] / max(st["episodes"], 1)}
+
     # secondary figure: BASELINE configs[4] -- 262,144 boards driven by the policy MLP, obs -> action -> step on device
     actor = None
     if args.actor_boards > 0 and world == 1:
@@ -172,10 +196,10 @@ def main():
         aenv.load_configs(rows, pieces)
         aenv.reset()
         actor = {"boards": na, "unit": "env-steps/s", "policy": "MLP 217-128-128-128-128-14, bf16 operands, greedy, random init"}
-        for name, fused in (("fused_mfma_kernel", True), ("torch_linear_layers", False)):
+        for name, use_fused in (("fused_mfma_kernel", True), ("torch_linear_layers", False)):
             torch.manual_seed(0)
             # two launches per iteration when fused: a graph replay costs more than it saves there
-            act = T.Actor(aenv, T.PolicyMLP(), dtype=torch.bfloat16, use_graph=not fused, fused=fused)
+            act = T.Actor(aenv, T.PolicyMLP(), dtype=torch.bfloat16, use_graph=not use_fused, fused=use_fused)
             act.run(20)
             torch.cuda.synchronize(dev)
             a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -254,6 +278,7 @@ def main():
                          "kernel": "step_kernel<action, auto_reset>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BOARD_STEP * n},
             "fused_rollout": fused,
+            "carved_pool_run": carved,
             "actor_loop": actor,
             "mean_episodic_return": mean_return if episodes else None,
             "episodes": episodes,
