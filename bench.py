@@ -12,9 +12,12 @@ data-path collective; one RCCL all-reduce of the episodic-return counters closes
 
 Prints ONE JSON line (rank 0).  `roofline` prices the step kernel against HBM with the canonical
 96 B/board-step of SURVEY 8(d); `cpu_baseline` is the CPU oracle (a scalar C port of the reference's move)
-timed on this box's host cores over a bounded sample of the same workload.
+timed on this box's host cores over a bounded sample of the same workload.  Side figures that never enter
+`value`: `fused_rollout` (tpl_rollout), `carved_pool_run` (the step loop on carved configurations),
+`actor_loop` (BASELINE configs[4]: 262,144 boards driven by the 217-128-128-128-128-14 policy).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -25,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_BOARD_STEP = 96          # 46 B read + 49 B write, rounded
 HBM_PEAK_GBS = 8000.0                   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 (MI355X_MICROARCH.md)
 
 
 def cpu_baseline(L, M, seed):
@@ -34,7 +38,6 @@ def cpu_baseline(L, M, seed):
     boards, steps = 262144, 40
     O.bench_run(seed, 4096, L, M, 8, cores)                      # warm the thread pool / page in
     done, sec = O.bench_run(seed, boards, L, M, steps, cores)
-    rate = done / sec
     # bounded sample: grow the step count until the timed part is a few seconds of wall time on all cores
     for _ in range(3):
         if sec >= 3.0 or steps >= 20000:
@@ -43,6 +46,93 @@ def cpu_baseline(L, M, seed):
         done, sec = O.bench_run(seed, boards, L, M, steps, cores)
     return {"value": done / sec, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{boards} boards x {steps} lockstep steps, L={L} M={M}, auto-reset, {cores} threads, {sec:.1f}s"}
+
+
+def timed(torch, dev, fn, reps):
+    """Average milliseconds of fn() over `reps` calls, by HIP events on the current stream."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / reps
+
+
+def measure_fused_rollout(torch, T, env, actions, first, K, chunk):
+    """tpl_rollout over the same pre-staged actions, `chunk` steps per launch, writing the same
+    per-step reward/done outputs as the step loop."""
+    n, dev = env.num_envs, env.device
+    rs = torch.empty((chunk, n), dtype=torch.float32, device=dev)
+    ds = torch.empty((chunk, n), dtype=torch.uint8, device=dev)
+    launches = K // chunk
+
+    def run():
+        for c in range(launches):
+            a = actions[first + c * chunk: first + (c + 1) * chunk]
+            T._lib.check(env._lib.tpl_rollout(env._h, ctypes.c_void_p(a.data_ptr()), a.stride(0), chunk,
+                                              ctypes.c_void_p(rs.data_ptr()), ctypes.c_void_p(ds.data_ptr()), None, None,
+                                              env._stream()))
+    run()
+    torch.cuda.synchronize(dev)
+    return timed(torch, dev, run, 1) / (launches * chunk)
+
+
+def measure_carved_pool(torch, T, env, actions, reward, done, W, K, pool, seed):
+    """SURVEY 8(d) "realism run": the same step loop on a pool of CARVED (solvable) configurations."""
+    n, dev, S = env.num_envs, env.device, actions.shape[0]
+    rows, pieces = T.generate_configs(env.L, env.M, pool, seed=seed)
+    env.load_configs(rows, pieces)
+    env.reset()
+    for t in range(W):
+        env.step_into(actions[t % S], reward, done)
+    torch.cuda.synchronize(dev)
+    kc = min(K, 500)
+    step = iter(range(W, W + kc))
+    ms = timed(torch, dev, lambda: env.step_into(actions[next(step) % S], reward, done), kc)
+    st = env.stats()
+    return {"value": float(n) / (ms * 1e-3), "unit": "env-steps/s", "ms_per_step": ms, "pool": pool,
+            "mean_moves_per_episode": (W + kc) * float(n) / max(st["episodes"], 1),
+            "win_rate": st["wins"] / max(st["episodes"], 1)}
+
+
+def measure_actor_loop(torch, T, dev, L, M, boards, seed):
+    """BASELINE configs[4]: boards driven by the policy MLP, obs -> action -> step on the device, three ways."""
+    env = T.BatchedTetris(L, M, boards, device=dev, seed=seed, auto_reset=True, assign="hash")
+    rows, pieces = env.synthetic_configs(boards)
+    env.load_configs(rows, pieces)
+    env.reset()
+    out = {"boards": boards, "unit": "env-steps/s",
+           "policy": "MLP 217-128-128-128-128-14, bf16 operands, greedy, random init"}
+    for name, use_fused in (("fused_mfma_kernel", True), ("torch_linear_layers", False)):
+        torch.manual_seed(0)
+        # two launches per iteration when fused: a graph replay costs more than it saves there
+        actor = T.Actor(env, T.PolicyMLP(), dtype=torch.bfloat16, use_graph=not use_fused, fused=use_fused)
+        actor.run(20)
+        torch.cuda.synchronize(dev)
+        ms = timed(torch, dev, actor.step, 300)
+        out[name] = {"value": boards / (ms * 1e-3), "ms_per_step": ms}
+    # T iterations per launch (tpl_actor_rollout): weights stay in LDS, boards in registers; trajectory written
+    torch.manual_seed(0)
+    image = T.actor.policy_image(T.PolicyMLP(), dev)
+    iters = 50
+    env.actor_rollout(image, iters)
+    torch.cuda.synchronize(dev)
+    ms = timed(torch, dev, lambda: env.actor_rollout(image, iters), 6) / iters
+    out["megakernel"] = {"value": boards / (ms * 1e-3), "ms_per_step": ms, "steps_per_launch": iters,
+                         "outputs": "per-step action u8 + reward f32 + done u8 written"}
+    out["value"] = out["megakernel"]["value"]
+    # the policy kernel alone against the dense bf16 MFMA peak: FLOPs it issues per board (K padded to 224, the
+    # 14-row head run as one 16-row tile) over its own duration
+    act = torch.empty(boards, dtype=torch.uint8, device=dev)
+    for _ in range(5):
+        env.policy_act(image, out=act)
+    ms = timed(torch, dev, lambda: env.policy_act(image, out=act), 100)
+    tflops = 2.0 * (224 * 128 + 3 * 128 * 128 + 128 * 16) * boards / (ms * 1e-3) / 1e12
+    out["policy_kernel"] = {"ms": ms, "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_PEAK_TFLOPS,
+                                                   "unit": "TFLOP/s", "frac": tflops / MFMA_BF16_PEAK_TFLOPS}}
+    env.terminate()
+    return out
 
 
 def main():
@@ -83,12 +173,22 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     n, L, M, K, W = args.boards, args.L, args.M, args.steps, args.warmup
     pool = args.pool or n
     shard = T.sharding.weak_shard(rank, world, n)               # batch-index sharding: contiguous blocks
-    offset = shard.global_offset
-    env = T.BatchedTetris(L, M, n, device=dev, seed=args.seed, global_offset=offset, auto_reset=True, assign="hash")
-    rows, pieces = env.synthetic_configs(pool, first=offset)
+    env = T.BatchedTetris(L, M, n, device=dev, seed=args.seed, global_offset=shard.global_offset, auto_reset=True,
+                          assign="hash")
+    rows, pieces = env.synthetic_configs(pool, first=shard.global_offset)
     env.load_configs(rows, pieces)
     del rows, pieces
     env.reset()
@@ -102,10 +202,7 @@ def main():
     done = torch.empty(n, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize(dev)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
+    # ---- the timed region: W untimed + exactly K timed steps, barrier + synchronize on both sides
     for t in range(W):
         env.step_into(actions[t % S], reward, done)
     T.sharding.mean_episodic_return(env.stats_tensor(), env.reward_params)   # load the reduction kernels / RCCL rings
@@ -124,129 +221,26 @@ def main():
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     kernel_ms = ev0.elapsed_time(ev1) / K                         # average launch-to-launch duration of the step kernel
 
-    # secondary figure: the fused rollout (tpl_rollout) over the same pre-staged actions, writing the
-    # same per-step reward/done outputs; chunks of `args.chunk` steps per launch.  Not part of `value`.
+    # ---- side figures (not part of `value`)
     fused = None
     if args.chunk > 0 and K >= args.chunk and W + K <= S:
-        C_ = args.chunk
-        rs = torch.empty((C_, n), dtype=torch.float32, device=dev)
-        ds = torch.empty((C_, n), dtype=torch.uint8, device=dev)
-        lib, h, stream = env._lib, env._h, env._stream()
-        import ctypes
-        def run_chunks():
-            for t0_ in range(W, W + (K // C_) * C_, C_):
-                a = actions[t0_:t0_ + C_]
-                T._lib.check(lib.tpl_rollout(h, ctypes.c_void_p(a.data_ptr()), a.stride(0), C_, ctypes.c_void_p(rs.data_ptr()),
-                                             ctypes.c_void_p(ds.data_ptr()), None, None, stream))
-        run_chunks()
-        torch.cuda.synchronize(dev)
         barrier()
-        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        f0.record()
-        run_chunks()
-        f1.record()
-        torch.cuda.synchronize(dev)
-        fused_ms = f0.elapsed_time(f1) / ((K // C_) * C_)
-        ft = torch.tensor([fused_ms], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(ft, op=dist.ReduceOp.MAX)
-        fused = {"value": float(n) * world / (float(ft.item()) * 1e-3), "unit": "env-steps/s", "steps_per_launch": C_,
-                 "ms_per_step": float(ft.item()), "outputs": "per-step reward f32 + done u8 written",
-                 "kernel": "rollout_kernel<auto_reset>"}
-    t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-    elapsed = float(t_all.item())
-
-    # secondary figure (SURVEY 8d "realism run"): the same step loop on a pool of CARVED (solvable) configurations from
-    # the native generator instead of the synthetic half-filled boards
+        ms = max_over_ranks(measure_fused_rollout(torch, T, env, actions, W, K, args.chunk))
+        fused = {"value": float(n) * world / (ms * 1e-3), "unit": "env-steps/s", "steps_per_launch": args.chunk,
+                 "ms_per_step": ms, "outputs": "per-step reward f32 + done u8 written", "kernel": "rollout_kernel<auto_reset>"}
     carved = None
     if args.carved_pool > 0 and world == 1:
-        c_rows, c_pieces = T.generate_configs(L, M, args.carved_pool, seed=args.seed)
-        env.load_configs(c_rows, c_pieces)
-        env.reset()
-        for t in range(W):
-            env.step_into(actions[t % S], reward, done)
-        torch.cuda.synchronize(dev)
-        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        kc = min(K, 500)
-        c0.record()
-        for t in range(W, W + kc):
-            env.step_into(actions[t % S], reward, done)
-        c1.record()
-        torch.cuda.synchronize(dev)
-        ms = c0.elapsed_time(c1) / kc
-        st = env.stats()
-        carved = {"value": float(n) / (ms * 1e-3), "unit": "env-steps/s", "ms_per_step": ms, "pool": args.carved_pool,
-                  "mean_moves_per_episode": (W + kc) * float(n) / max(st["episodes"], 1),
-                  "win_rate": st["wins"] / max(st["episodes"], 1)}
-
-    # secondary figure: BASELINE configs[4] -- 262,144 boards driven by the policy MLP, obs -> action -> step on device
+        carved = measure_carved_pool(torch, T, env, actions, reward, done, W, K, args.carved_pool, args.seed)
+    env.terminate()
+    del actions
     actor = None
     if args.actor_boards > 0 and world == 1:
-        na = args.actor_boards
-        env.terminate()
-        del actions
-        aenv = T.BatchedTetris(L, M, na, device=dev, seed=args.seed, auto_reset=True, assign="hash")
-        rows, pieces = aenv.synthetic_configs(na)
-        aenv.load_configs(rows, pieces)
-        aenv.reset()
-        actor = {"boards": na, "unit": "env-steps/s", "policy": "MLP 217-128-128-128-128-14, bf16 operands, greedy, random init"}
-        for name, use_fused in (("fused_mfma_kernel", True), ("torch_linear_layers", False)):
-            torch.manual_seed(0)
-            # two launches per iteration when fused: a graph replay costs more than it saves there
-            act = T.Actor(aenv, T.PolicyMLP(), dtype=torch.bfloat16, use_graph=not use_fused, fused=use_fused)
-            act.run(20)
-            torch.cuda.synchronize(dev)
-            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            iters = 300
-            a0.record()
-            act.run(iters)
-            a1.record()
-            torch.cuda.synchronize(dev)
-            ms = a0.elapsed_time(a1) / iters
-            actor[name] = {"value": na / (ms * 1e-3), "ms_per_step": ms}
-        # T iterations per launch (tpl_actor_rollout): weights stay in LDS, boards in registers; trajectory written
-        image = T.actor.policy_image(T.PolicyMLP(), dev)
-        Tm = 50
-        aenv.actor_rollout(image, Tm)
-        torch.cuda.synchronize(dev)
-        m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        m0.record()
-        for _ in range(6):
-            aenv.actor_rollout(image, Tm)
-        m1.record()
-        torch.cuda.synchronize(dev)
-        ms = m0.elapsed_time(m1) / (6 * Tm)
-        actor["megakernel"] = {"value": na / (ms * 1e-3), "ms_per_step": ms, "steps_per_launch": Tm,
-                               "outputs": "per-step action u8 + reward f32 + done u8 written"}
-        actor["value"] = actor["megakernel"]["value"]
-        # the policy kernel alone, priced against the dense bf16 MFMA peak: FLOPs it issues per board (K padded to
-        # 224, the 14-row head run as one 16-row tile) over its own duration
-        image = act.image if act.image is not None else T.actor.policy_image(T.PolicyMLP(), dev)
-        out = torch.empty(na, dtype=torch.uint8, device=dev)
-        for _ in range(5):
-            aenv.policy_act(image, out=out)
-        p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        p0.record()
-        for _ in range(100):
-            aenv.policy_act(image, out=out)
-        p1.record()
-        torch.cuda.synchronize(dev)
-        pol_ms = p0.elapsed_time(p1) / 100
-        flop = 2.0 * (224 * 128 + 3 * 128 * 128 + 128 * 16) * na
-        actor["policy_kernel"] = {"ms": pol_ms, "roofline": {"bound": "mfma", "achieved": flop / (pol_ms * 1e-3) / 1e12,
-                                                              "peak": 2500.0, "unit": "TFLOP/s",
-                                                              "frac": flop / (pol_ms * 1e-3) / 1e12 / 2500.0}}
-        aenv.terminate()
-        env = None
+        actor = measure_actor_loop(torch, T, dev, L, M, args.actor_boards, args.seed)
 
     if rank == 0:
-        total_steps = float(n) * world * K
         achieved = ALGO_BYTES_PER_BOARD_STEP * n / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -258,7 +252,7 @@ def main():
                 traffic = None
         out = {
             "metric": "env-steps/sec (whole node) at 1M parallel 20x10 boards",
-            "value": total_steps / elapsed,
+            "value": float(n) * world * K / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": K,
@@ -286,8 +280,6 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(L, M, args.seed)
         print(json.dumps(out), flush=True)
-    if env is not None:
-        env.terminate()
     if world > 1:
         dist.destroy_process_group()
 
