@@ -34,7 +34,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 (MI355X_MICROARCH.md)
 def cpu_baseline(L, M, seed):
     """The oracle's loop (game/performance_test.py:13-17 shape: move, reset when finished) on the host cores."""
     from oracle import oracle as O
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    import tetris_piclim as T
+    cores = T._lib.cpu_budget()                                  # affinity mask capped by the cgroup CPU quota
     boards, steps = 262144, 40
     O.bench_run(seed, 4096, L, M, 8, cores)                      # warm the thread pool / page in
     done, sec = O.bench_run(seed, boards, L, M, steps, cores)

@@ -160,6 +160,19 @@ def check(status: int) -> None:
         raise TplError(f"tetris_piclim status {status}: {lib().tpl_last_error().decode()}")
 
 
+def cpu_budget() -> int:
+    """Host threads worth starting: the affinity mask, capped by the cgroup CPU quota when there is one (a
+    container that sees 256 CPUs but may use 16 of them runs slower with 256 threads than with 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def generate_configs(L: int, M: int, count: int = 0, seed: int = 0, first: int = 0, threads: int = 0,
                      max_iters: int = 0, with_solutions: bool = False, python_seeds=None):
     """Carved (solvable) prescribed configurations, produced on the host cores (game/tetris.py:226-352).
@@ -168,6 +181,7 @@ def generate_configs(L: int, M: int, count: int = 0, seed: int = 0, first: int =
     (solution uint8 [count, M, 2], solution_len int32 [count]).  With python_seeds=[s0, s1, ...] configuration i is
     exactly what the reference builds after random.seed(s_i) (CPython's random stream is reproduced)."""
     import numpy as np
+    threads = threads or cpu_budget()
     if python_seeds is not None:
         seeds = np.ascontiguousarray(python_seeds, dtype=np.uint64)
         count = len(seeds)
@@ -190,6 +204,7 @@ def forward_generate(L: int, M: int, seeds, initial_height_max: int = 4, max_att
     winnable [n] bool, failed_attempts [n], solution [n, M, 2] (rotations, location), solver_stack [n, M, 3],
     solution_len [n].  Game i equals TetrisGameGenerator(seed=seeds[i], ...) and its TetrisSolver verdict."""
     import numpy as np
+    threads = threads or cpu_budget()
     seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
     n = len(seeds)
     out = dict(rows=np.zeros((n, 20), np.uint16), sequence=np.zeros((n, M), np.uint8), winnable=np.zeros(n, np.uint8),

@@ -102,9 +102,11 @@ bool generate_one(int L, int M, Random& rnd, int64_t max_iters, uint16_t* rows_o
     uint8_t bag[7];
     int n_bag = 0;
     // CheckpointManager (:111-137).  A checkpoint is added only when a fresh bag is opened, i.e. after at least
-    // seven successful carves on top of the previous one (or a reload), so M/7 + 2 entries always suffice.
-    std::vector<Game> checkpoints;
-    checkpoints.reserve((size_t)M / 7 + 3);
+    // seven successful carves on top of the previous one (or a reload), so M/7 + 2 entries always suffice; kept on
+    // the stack so that hundreds of generator threads do not meet in the allocator.
+    constexpr int kMaxCheckpoints = 254 / 7 + 3;
+    Game checkpoints[kMaxCheckpoints];
+    int n_cp = 0;
     int attempts = 0, uses = 0;
     int64_t iters = 0;
 
@@ -115,7 +117,7 @@ bool generate_one(int L, int M, Random& rnd, int64_t max_iters, uint16_t* rows_o
         if (n_bag == 0) { for (int k = 0; k < 7; ++k) bag[k] = (uint8_t)k; n_bag = 7; fresh_bag = true; }
         const int idx = rnd.randint(0, n_bag - 1);                          // :85
         const int piece = bag[idx];
-        if (fresh_bag) checkpoints.push_back(g);                            // :239-247
+        if (fresh_bag && n_cp < kMaxCheckpoints) checkpoints[n_cp++] = g;   // :239-247
         const int rotations = rnd.randint(0, 3);                            // :250
         const int width = shape_of(piece, rotations).w;
         const int loc = rnd.randint(0, kCols - width);                      // :253
@@ -129,9 +131,9 @@ bool generate_one(int L, int M, Random& rnd, int64_t max_iters, uint16_t* rows_o
             --n_bag;
         } else if (g.n >= M || ++attempts > 40) {                           // :268, add_attempt (:121-123)
             attempts = 0;                                                   // load_checkpoint (:128-137)
-            if (checkpoints.size() > 1 && uses > 10) { checkpoints.pop_back(); uses = 0; }
+            if (n_cp > 1 && uses > 10) { --n_cp; uses = 0; }
             else ++uses;
-            g = checkpoints.back();                                         // :275-276
+            g = checkpoints[n_cp - 1];                                      // :275-276
             for (int k = 0; k < 7; ++k) bag[k] = (uint8_t)k;                // :278
             n_bag = 7;
         }
