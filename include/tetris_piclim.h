@@ -171,11 +171,21 @@ int tpl_set_tuning(tpl_env* env, int32_t boards_per_lane, int32_t block_threads)
  * configurations on `threads` host threads (0 = all cores).  HOST pointers: rows [count][20] uint16,
  * pieces [count][M+1] uint8, and optionally the carved solution [count][M][2] (rotations, location) with
  * solution_len [count] (the reference's debug `solution`, :155-156).  Decision k of configuration first+i is
- * lo + hash(seed, 4, first+i, k) % (hi-lo+1), so the output does not depend on `threads`.  max_iters > 0 bounds
+ * the draw hash(seed, 4, first+i, k) reduced to [lo, hi] by multiply-high, so the output does not depend on
+ * `threads`.  max_iters > 0 bounds
  * the search loop of one configuration (the reference has no bound); 1 <= L <= 16. */
 int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count, int32_t threads,
                          int64_t max_iters, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
                          int32_t* solution_len);
+
+/* The same generator on the GPU, one configuration per lane: same decisions, same output as tpl_generate_configs, for
+ * refreshing a device pool without the host (whose container may own only a few CPUs).  DEVICE pointers; `status`
+ * [count] (optional) is 1 for a configuration that hit the iteration cap (max_iters, or 2^22 when 0) and whose
+ * outputs are then not a finished configuration.  `work`: tpl_generate_configs_device_work_bytes(M, count) bytes. */
+size_t tpl_generate_configs_device_work_bytes(int32_t M, int64_t count);
+int tpl_generate_configs_device(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count, int64_t max_iters,
+                                uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* solution_len,
+                                int32_t* status, void* work, size_t work_bytes, void* stream);
 
 /* The same generator driven by CPython's `random` stream: configuration i is what the reference produces after
  * `random.seed(seeds[i]); Tetris(L, M, warm_reset=False)` (game/tetris.py:226-284 drawing through :85,93,250,253)

@@ -532,7 +532,7 @@ typedef struct { uint64_t seed, index, counter; } seeded_ctx;
 static int32_t seeded_randint(void* vctx, int32_t lo, int32_t hi) {
     seeded_ctx* c = (seeded_ctx*)vctx;
     uint64_t h = to_rng(c->seed, 4, c->index, c->counter++);
-    return lo + (int32_t)(h % (uint64_t)(hi - lo + 1));
+    return lo + (int32_t)(((h >> 32) * (uint64_t)(hi - lo + 1)) >> 32);   /* multiply-high range reduction */
 }
 
 int64_t to_generate_config_seeded(int L, int M, uint64_t seed, uint64_t index, int64_t max_iters,

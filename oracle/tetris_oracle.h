@@ -118,7 +118,8 @@ int64_t to_generate_config(int L, int M, to_randint_fn randint, void* ctx, int64
  * *consumed = decisions used. */
 int64_t to_generate_config_tape(int L, int M, const int32_t* tape, int64_t n, int64_t* consumed,
                                 uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* sol_len);
-/* (b) counter-driven: decision k of configuration `index` is lo + to_rng(seed, 4, index, k) % (hi - lo + 1). */
+/* (b) counter-driven: decision k of configuration `index` is to_rng(seed, 4, index, k), reduced to [lo, hi] by
+ * lo + ((draw >> 32) * (hi - lo + 1) >> 32). */
 int64_t to_generate_config_seeded(int L, int M, uint64_t seed, uint64_t index, int64_t max_iters,
                                   uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* sol_len);
 

@@ -19,8 +19,8 @@ _DIAG = os.environ.get("TPL_DIAG_CLOCK") == "1"
 _EXTRA = os.environ.get("TPL_EXTRA_DEFINE", "")
 LIB_PATH = os.path.join(_CSRC, "libtetris_piclim_diag.so" if _DIAG else
                         f"libtetris_piclim_{_EXTRA}.so" if _EXTRA else "libtetris_piclim.so")
-_UNITS = [os.path.join(_CSRC, f) for f in ("tetris_piclim.hip", "carve_generator.hip", "forward_generator.hip",
-                                           "policy_mlp.hip")]
+_UNITS = [os.path.join(_CSRC, f) for f in ("tetris_piclim.hip", "carve_generator.hip", "carve_device.hip",
+                                           "forward_generator.hip", "policy_mlp.hip")]
 _SOURCES = _UNITS + [os.path.join(_CSRC, "tpl_device.h"), os.path.join(_CSRC, "tpl_internal.h"),
                      os.path.join(_CSRC, "tpl_step.h"), os.path.join(_CSRC, "py_random.h"),
                      os.path.join(_ROOT, "include", "tetris_piclim.h")]
@@ -31,6 +31,7 @@ SYMBOLS = [
     "tpl_set_options", "tpl_load_configs", "tpl_reset", "tpl_move", "tpl_step", "tpl_get_state",
     "tpl_expand_obs", "tpl_expand_states", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
     "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_decode_actions", "tpl_generate_configs", "tpl_generate_configs_pyseed", "tpl_forward_generate",
+    "tpl_generate_configs_device_work_bytes", "tpl_generate_configs_device",
     "tpl_policy_image_bytes", "tpl_policy_pack", "tpl_policy_act",
     "tpl_explore_actions", "tpl_actor_rollout",
 ]
@@ -144,6 +145,9 @@ def lib() -> C.CDLL:
     L.tpl_set_tuning.argtypes = [vp, i32, i32]
     L.tpl_generate_configs.argtypes = [i32, i32, u64, i64, i64, i32, i64, vp, vp, vp, vp]
     L.tpl_generate_configs_pyseed.argtypes = [i32, i32, vp, i64, i32, i64, vp, vp, vp, vp]
+    L.tpl_generate_configs_device_work_bytes.restype = sz
+    L.tpl_generate_configs_device_work_bytes.argtypes = [i32, i64]
+    L.tpl_generate_configs_device.argtypes = [i32, i32, u64, i64, i64, i64, vp, vp, vp, vp, vp, vp, sz, vp]
     L.tpl_forward_generate.argtypes = [i32, i32, i32, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp]
     L.tpl_synth_configs.argtypes = [vp, u64, i64, i64, vp, vp, vp]
     L.tpl_synth_actions.argtypes = [vp, u64, i64, i64, u64, vp, vp]

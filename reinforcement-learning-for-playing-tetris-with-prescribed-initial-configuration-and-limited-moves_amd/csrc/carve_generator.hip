@@ -6,8 +6,8 @@
 //
 // The board is kept in the same column form as on the device (ten 20-bit words, bit r = row r), with the same
 // encoded shape table (tpl_device.h), so a column's top is one count-trailing-zeros and a carve is one AND per
-// piece column.  Random decisions are counter-based: decision k of configuration g is
-// lo + rng(seed, 4, g, k) % (hi - lo + 1), independent of the thread count.
+// piece column.  Random decisions are counter-based: decision k of configuration g is the draw rng(seed, 4, g, k)
+// reduced to [lo, hi] by multiply-high (rng_range), independent of the thread count.
 #include "tpl_internal.h"
 #include "py_random.h"
 
@@ -21,8 +21,9 @@ namespace tpl {
 namespace {
 
 struct Decisions {
-    uint64_t seed, index, counter = 0;
-    int randint(int lo, int hi) { return lo + (int)(rng(seed, 4, index, counter++) % (uint64_t)(hi - lo + 1)); }
+    uint64_t base, counter = 0;
+    Decisions(uint64_t seed, uint64_t index) : base(rng_base(seed, 4, index)) {}
+    int randint(int lo, int hi) { return rng_range(rng_at(base, counter++), lo, hi); }
 };
 
 struct Shape {
@@ -202,7 +203,7 @@ extern "C" int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t
                                     int32_t* solution_len) {
     if (first < 0) return tpl::fail_msg(TPL_ERR_ARG, "first is negative");
     return run_generator(L, M, count, threads, max_iters, rows, pieces, solution, solution_len,
-                         [=](int64_t k) { return tpl::Decisions{seed, (uint64_t)(first + k)}; });
+                         [=](int64_t k) { return tpl::Decisions(seed, (uint64_t)(first + k)); });
 }
 
 extern "C" int tpl_generate_configs_pyseed(int32_t L, int32_t M, const uint64_t* seeds, int64_t count, int32_t threads,

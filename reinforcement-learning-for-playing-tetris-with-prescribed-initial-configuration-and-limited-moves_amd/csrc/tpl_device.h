@@ -241,10 +241,17 @@ __host__ __device__ __forceinline__ uint64_t sm64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
+// rng(seed, stream, index, counter) in two stages: the part that is fixed per (seed, stream, index) and the draw
+__host__ __device__ __forceinline__ uint64_t rng_base(uint64_t seed, uint64_t stream, uint64_t index) {
+    return sm64(sm64(seed ^ (stream * 0xD1B54A32D192ED03ULL)) ^ index);
+}
+__host__ __device__ __forceinline__ uint64_t rng_at(uint64_t base, uint64_t counter) { return sm64(base ^ counter); }
 __host__ __device__ __forceinline__ uint64_t rng(uint64_t seed, uint64_t stream, uint64_t index, uint64_t counter) {
-    uint64_t h = sm64(seed ^ (stream * 0xD1B54A32D192ED03ULL));
-    h = sm64(h ^ index);
-    return sm64(h ^ counter);
+    return rng_at(rng_base(seed, stream, index), counter);
+}
+// a draw reduced to [lo, hi] by multiply-high of its upper half (no division on the device)
+__host__ __device__ __forceinline__ int rng_range(uint64_t draw, int lo, int hi) {
+    return lo + (int)(((draw >> 32) * (uint64_t)(hi - lo + 1)) >> 32);
 }
 
 __host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {

@@ -132,6 +132,27 @@ class BatchedTetris:
         if old is not None:
             old.record_stream(torch.cuda.current_stream(self.device))
 
+    def carved_configs(self, count: int, seed: Optional[int] = None, first: int = 0, with_solutions: bool = False,
+                       max_iters: int = 0):
+        """Carved (solvable) configurations generated ON THE DEVICE, one per lane -- the same configurations
+        generate_configs(L, M, count, seed, first) builds on the host.  Returns device tensors (rows int16 [count, 20],
+        pieces uint8 [count, M+1]) and, with_solutions, (solution uint8 [count, M, 2], solution_len int32 [count]);
+        raises if a configuration hit the iteration cap."""
+        seed = self.seed if seed is None else seed
+        d = self.device
+        rows = torch.empty((count, 20), dtype=torch.int16, device=d)
+        pieces = torch.empty((count, self.M + 1), dtype=torch.uint8, device=d)
+        sol = torch.zeros((count, self.M, 2), dtype=torch.uint8, device=d) if with_solutions else None
+        sol_len = torch.zeros(count, dtype=torch.int32, device=d) if with_solutions else None
+        status = torch.empty(count, dtype=torch.int32, device=d)
+        nbytes = self._lib.tpl_generate_configs_device_work_bytes(self.M, count)
+        work = torch.empty(nbytes, dtype=torch.uint8, device=d)
+        check(self._lib.tpl_generate_configs_device(self.L, self.M, seed, first, count, max_iters, _ptr(rows), _ptr(pieces),
+                                                    _ptr(sol), _ptr(sol_len), _ptr(status), _ptr(work), nbytes, self._stream()))
+        if bool(status.any()):
+            raise _lib.TplError(f"{int(status.sum())} configuration(s) hit the iteration cap")
+        return (rows, pieces, sol, sol_len) if with_solutions else (rows, pieces)
+
     def synthetic_configs(self, count: int, seed: Optional[int] = None, first: int = 0):
         """The synthetic boards / piece lists of SURVEY 8(d), generated on the device."""
         seed = self.seed if seed is None else seed

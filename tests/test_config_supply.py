@@ -151,6 +151,24 @@ def test_native_generator_argument_errors():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("L,M,n", [(5, 20, 10000), (10, 40, 3000), (15, 40, 96), (1, 1, 65), (3, 254, 40)])
+def test_device_generator_equals_the_host_generator(L, M, n):
+    """tpl_generate_configs_device (one configuration per lane) == tpl_generate_configs (host threads): boards,
+    piece lists, solutions."""
+    import torch
+    import tetris_piclim as T
+    rows, pieces, sol, sol_len = T.generate_configs(L, M, n, seed=12, first=5, with_solutions=True)
+    env = T.BatchedTetris(L, M, 64)
+    d_rows, d_pieces, d_sol, d_len = env.carved_configs(n, seed=12, first=5, with_solutions=True)
+    assert np.array_equal(d_rows.cpu().numpy().view(np.uint16), rows)
+    assert np.array_equal(d_pieces.cpu().numpy(), pieces)
+    assert np.array_equal(d_len.cpu().numpy(), sol_len) and np.array_equal(d_sol.cpu().numpy(), sol)
+    with pytest.raises(T.TplError):
+        env.carved_configs(64, seed=12, max_iters=2)       # the cap is reported, not hung on
+    env.terminate()
+
+
+@pytest.mark.gpu
 def test_forward_pool_replays_to_a_win_on_the_gpu():
     import torch
     import tetris_piclim as T
