@@ -13,7 +13,7 @@ rows, pieces = env.synthetic_configs(n)
 env.load_configs(rows, pieces)
 env.reset()
 torch.manual_seed(0)
-for use_graph, variant in ((False, 1), (True, 1)):
+for use_graph in (False, True):
     act = T.Actor(env, T.PolicyMLP(), use_graph=use_graph, fused=True)
     act.run(20)
     torch.cuda.synchronize()
@@ -22,4 +22,4 @@ for use_graph, variant in ((False, 1), (True, 1)):
     act.run(200)
     e1.record()
     torch.cuda.synchronize()
-    print(f"n={n} graph={use_graph} variant={variant}: {e0.elapsed_time(e1) / 200 * 1e3:.1f} us per iteration", flush=True)
+    print(f"n={n} graph={use_graph}: {e0.elapsed_time(e1) / 200 * 1e3:.1f} us per iteration", flush=True)

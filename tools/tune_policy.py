@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B the policy kernels' tuning knobs in one process: standalone policy kernel and the actor megakernel."""
+"""Time the policy kernel and the actor megakernel on the bench's config-5 workload (median of interleaved rounds)."""
 import os
 import statistics
 import sys
@@ -16,28 +16,19 @@ env.reset()
 torch.manual_seed(0)
 image = T.actor.policy_image(T.PolicyMLP(), env.device)
 out = torch.empty(n, dtype=torch.uint8, device=env.device)
-combos = [(1, 0)]
-res = {c: ([], []) for c in combos}
-for rnd in range(4):
-    for c in combos:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(50):
-            env.policy_act(image, out=out)
-        e1.record()
-        torch.cuda.synchronize()
-        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        if c[0] == 1:
-            f0.record()
-            env.actor_rollout(image, 40, record=True)
-            f1.record()
-            torch.cuda.synchronize()
-        if rnd:
-            res[c][0].append(e0.elapsed_time(e1) / 50 * 1e3)
-            if c[0] == 1:
-                res[c][1].append(f0.elapsed_time(f1) / 40 * 1e3)
-for c, (a, b) in res.items():
-    line = f"n={n} variant={c[0]} stagger={c[1]}: policy {statistics.median(a):.1f} us"
-    if b:
-        line += f"   megakernel {statistics.median(b):.1f} us/iteration"
-    print(line, flush=True)
+policy, mega = [], []
+for rnd in range(5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        env.policy_act(image, out=out)
+    e1.record()
+    f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    f0.record()
+    env.actor_rollout(image, 40, record=True)
+    f1.record()
+    torch.cuda.synchronize()
+    if rnd:
+        policy.append(e0.elapsed_time(e1) / 50 * 1e3)
+        mega.append(f0.elapsed_time(f1) / 40 * 1e3)
+print(f"n={n}: policy kernel {statistics.median(policy):.1f} us   megakernel {statistics.median(mega):.1f} us/iteration", flush=True)
