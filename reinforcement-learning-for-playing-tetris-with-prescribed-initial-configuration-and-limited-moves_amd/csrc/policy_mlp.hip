@@ -135,21 +135,22 @@ __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, v), zero));
 }
 
+// weights -> LDS with every 16-byte piece of a thread in flight at once (20 per thread at 512 threads): a
+// load-store-load-store loop would pay the L2 latency once per piece
 template <int kThreads>
 __device__ __forceinline__ void load_image(uint4* s_image, const uint4* image) {
     constexpr int kPieces = kImageBytes / 16;
-    for (int base = 0; base < kPieces; base += kThreads * 8) {
-        uint4 v[8];
+    constexpr int kPer = (kPieces + kThreads - 1) / kThreads;
+    uint4 v[kPer];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = base + u * kThreads + (int)threadIdx.x;
-            v[u] = image[i < kPieces ? i : kPieces - 1];
-        }
+    for (int u = 0; u < kPer; ++u) {
+        const int i = u * kThreads + (int)threadIdx.x;
+        v[u] = image[i < kPieces ? i : kPieces - 1];
+    }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = base + u * kThreads + (int)threadIdx.x;
-            if (i < kPieces) s_image[i] = v[u];
-        }
+    for (int u = 0; u < kPer; ++u) {
+        const int i = u * kThreads + (int)threadIdx.x;
+        if (i < kPieces) s_image[i] = v[u];
     }
     __syncthreads();
 }
