@@ -25,42 +25,94 @@ int fail_msg(int code, const char* fmt, ...) {
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+// A state plane holds whole blocks of the widest step-kernel geometry: boards past num_envs are padding that the
+// step kernel may read and write back but never advances (they are created finished).
+constexpr size_t kPlanePad = 512 * 4;
+static inline size_t plane_bytes(int64_t n) { return align_up((size_t)n, kPlanePad) * sizeof(uint4); }
 // piece words of a configuration: entries 0..M+1 must be addressable (pieces[1] after the last move)
 static inline int piece_words(int M) { return (M + 2 + kWindowStride - 1) / kWindowStride; }
 static inline size_t record_stride(int M) { return align_up(32 + 4 * (size_t)(piece_words(M) - 1), 64); }
 
 // ---------------------------------------------------------------------------------------------- kernels
 // One Tetris.move per board (:354-422).  ACTION form: act0 = rot*10+loc; MOVE form: act0 = rot, act1 = loc.
-// Each lane owns kBpl boards (block-strided, so every load is still 1 KiB per wave); all their loads are
-// issued before the first move is computed.
+// Each lane owns kBpl boards (block-strided, so every load is still 1 KiB per wave).  The kernel is written in
+// phases so that a wave makes as few dependent trips to memory as the rules allow -- the whole grid is resident at
+// once, so the time of a launch is the length of one wave's chain, not a sum over rounds of waves:
+//   0  every board's state words and actions are requested
+//   1  the piece-word gathers of the boards whose window runs out with this move are requested
+//   2  the moves are computed (registers and LDS only)
+//   3  reward / done / cleared are written
+//   4  the pool records of the boards that finished are requested (auto-reset)
+//   5  the state words are written
 template <bool kActionForm, bool kAutoReset, int kBpl, int kThreads>
 __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
     __shared__ ShapeWord s_shape[32];
     __shared__ uint32_t s_stat[4];
 
-    // board loads first: the shape table's trip to LDS then rides in their shadow instead of ahead of them
+    // phase 0.  The shape table's trip to LDS rides in the shadow of the board loads instead of ahead of them.
     const int64_t base = (int64_t)blockIdx.x * (kThreads * kBpl) + threadIdx.x;
     uint4 A[kBpl], B[kBpl];
     uint32_t a0[kBpl], a1[kBpl];
+    bool valid[kBpl];
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
+        // No branch around the loads, so all of a lane's requests leave before the first wait.  The planes are
+        // padded to whole blocks with boards that are finished for good (tpl_create), so a lane past the end
+        // reads one of those; its action comes from the last real board and is never used.
         const int64_t i = base + (int64_t)k * kThreads;
-        if (i < p.n) {
-            A[k] = p.plane_a[i];
-            B[k] = p.plane_b[i];
-            a0[k] = load_int(p.act0, p.dtype, i);
-            a1[k] = kActionForm ? 0u : load_int(p.act1, p.dtype, i);
-        }
+        valid[k] = i < p.n;
+        const int64_t j = valid[k] ? i : p.n - 1;
+        A[k] = p.plane_a[i];
+        B[k] = p.plane_b[i];
+        a0[k] = load_int(p.act0, p.int_bytes, j);
+        a1[k] = kActionForm ? 0u : load_int(p.act1, p.int_bytes, j);
     }
     if (threadIdx.x < 32) s_shape[threadIdx.x] = kShapeTable[threadIdx.x];
     if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
     __syncthreads();
 
-    bool finished = false;
+    // phase 1.  pieces.pop(0) (:356) moves the cursor to moves_used + 1 whatever the move does.  When that is a
+    // multiple of eight the window is down to its last two entries and piece word cursor/8 replaces it.
+    uint32_t word[kBpl], cursor[kBpl], episode[kBpl];
+    bool live[kBpl], refill[kBpl];
+#pragma unroll
+    for (int k = 0; k < kBpl; ++k) {
+        // an empty statement that needs every phase-0 result: it pins the one wait for phase 0 here, ahead of all
+        // the gathers (left alone, the compiler waits for board k only after the gather of board k-1 has left,
+        // which then has to be waited for as well)
+        asm volatile("" ::"v"(A[k].x), "v"(B[k].x), "v"(a0[k]), "v"(a1[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < kBpl; ++k) {
+        const uint32_t moves = (A[k].y >> 28) | ((A[k].w >> 28) << 4);
+        episode[k] = (B[k].z >> 28) | ((B[k].y >> 28) << 4);
+        cursor[k] = moves + 1u;
+        live[k] = (B[k].w >> 30) == ST_RUNNING;
+        refill[k] = live[k] && (cursor[k] & (uint32_t)(kWindowStride - 1)) == 0u && p.n_cfg != 0u;
+    }
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
         const int64_t i = base + (int64_t)k * kThreads;
-        if (i >= p.n) continue;
+        word[k] = 0;
+        if (refill[k]) {
+            const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, episode[k], p.seed, p.n_cfg, p.assign_mode);
+            word[k] = *(const uint32_t*)(p.pool + (size_t)cfg * p.stride + 32u + 4u * ((cursor[k] >> 3) - 1u));
+        }
+    }
+
+    // phase 2
+    float reward[kBpl];
+    uint32_t n_clear[kBpl], next_episode[kBpl];
+    bool done[kBpl], reload[kBpl];
+    bool finished = false;
+#pragma unroll
+    for (int k = 0; k < kBpl; ++k) {
+        reward[k] = 0.0f;
+        n_clear[k] = 0;
+        next_episode[k] = 0;
+        done[k] = true;
+        reload[k] = false;
+        if (!live[k]) continue;                               // frozen: reward 0, done, state untouched
         uint32_t rot, loc;
         if (kActionForm) {
             rot = a0[k] / 10u;
@@ -71,53 +123,72 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         }
         Board s;
         unpack_board(A[k], B[k], s);
+        bool topout;
+        n_clear[k] = move_board(s, s_shape, rot, loc, p.L, p.M, topout);
+        s.window = refill[k] ? word[k] : (s.window >> 3);     // the falling piece is consumed even on a top-out
 
-        float reward = 0.0f;
-        uint32_t n_clear = 0;
-        bool done = true;
-        if (s.state == ST_RUNNING) {
-            // pieces.pop(0) (:356) moves the cursor to moves_used + 1 whatever the move does.  When that is a
-            // multiple of eight the window is down to its last two entries and piece word cursor/8 replaces it;
-            // the gather is issued before the move so that its latency overlaps the move.
-            const uint32_t cursor = s.moves + 1u;
-            const bool refill = (cursor & (uint32_t)(kWindowStride - 1)) == 0u && p.n_cfg != 0u;
-            uint32_t word = 0;
-            if (refill) {
-                const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, s.episode, p.seed, p.n_cfg, p.assign_mode);
-                word = *(const uint32_t*)(p.pool + (size_t)cfg * p.stride + 32u + 4u * ((cursor >> 3) - 1u));
-            }
-
-            bool topout;
-            n_clear = move_board(s, s_shape, rot, loc, p.L, p.M, topout);
-            s.window = refill ? word : (s.window >> 3);      // the falling piece is consumed even on a top-out
-
-            reward = p.r_line * (float)n_clear;
-            if (s.state == ST_WON) reward = reward + p.r_win;
-            if (s.state >= ST_LOST_LIMIT) reward = reward + p.r_lose;
-            done = s.state != ST_RUNNING;
-
-            uint4 A2, B2;
-            if (done) {
-                // adds of a constant collapse to one popcount per wave; the line sum is rarely non-zero
-                finished = true;
-                atomicAdd(&s_stat[0], 1u);
-                if (s.lines) atomicAdd(&s_stat[1], s.lines);
-                if (s.state == ST_WON) atomicAdd(&s_stat[2], 1u);
-                if (s.state == ST_LOST_TOPOUT) atomicAdd(&s_stat[3], 1u);
-            }
-            if (kAutoReset && done) {
-                const uint32_t ep = (s.episode + 1u) & 0xFFu;
-                const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, ep, p.seed, p.n_cfg, p.assign_mode);
-                load_config(p.pool, p.stride, cfg, ep, A2, B2);
-            } else {
-                pack_board(s, A2, B2);
-            }
-            p.plane_a[i] = A2;
-            p.plane_b[i] = B2;
+        reward[k] = p.r_line * (float)n_clear[k];
+        if (s.state == ST_WON) reward[k] = reward[k] + p.r_win;
+        if (s.state >= ST_LOST_LIMIT) reward[k] = reward[k] + p.r_lose;
+        done[k] = s.state != ST_RUNNING;
+        if (done[k]) {
+            // adds of a constant collapse to one popcount per wave; the line sum is rarely non-zero
+            finished = true;
+            atomicAdd(&s_stat[0], 1u);
+            if (s.lines) atomicAdd(&s_stat[1], s.lines);
+            if (s.state == ST_WON) atomicAdd(&s_stat[2], 1u);
+            if (s.state == ST_LOST_TOPOUT) atomicAdd(&s_stat[3], 1u);
         }
-        if (p.reward) p.reward[i] = reward;
-        if (p.done) p.done[i] = done ? 1 : 0;
-        if (p.cleared) p.cleared[i] = (uint8_t)n_clear;
+        reload[k] = kAutoReset && done[k];
+        next_episode[k] = (s.episode + 1u) & 0xFFu;
+        pack_board(s, A[k], B[k]);
+    }
+
+    // phase 3
+#pragma unroll
+    for (int k = 0; k < kBpl; ++k) {
+        const int64_t i = base + (int64_t)k * kThreads;
+        if (!valid[k]) continue;
+        if (p.reward) p.reward[i] = reward[k];
+        if (p.done) p.done[i] = done[k] ? 1 : 0;
+        if (p.cleared) p.cleared[i] = (uint8_t)n_clear[k];
+    }
+
+    // phase 4: reset()/load_warm_reset() (:438-449) of the boards that finished.  One divergent region for all of
+    // a lane's boards, with the records landing in fresh registers: every request leaves before the first wait.
+    // (A lane in the region for one board only reads record 0 for its others and drops it.)
+    if (kAutoReset) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < kBpl; ++k) any = any || reload[k];
+        if (any) {
+            uint4 RA[kBpl], RB[kBpl];
+#pragma unroll
+            for (int k = 0; k < kBpl; ++k) {
+                const int64_t i = base + (int64_t)k * kThreads;
+                const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, next_episode[k], p.seed, p.n_cfg, p.assign_mode);
+                const uint4* rec = (const uint4*)(p.pool + (size_t)(reload[k] ? cfg : 0u) * p.stride);
+                RA[k] = rec[0];
+                RB[k] = rec[1];
+            }
+#pragma unroll
+            for (int k = 0; k < kBpl; ++k) {
+                if (!reload[k]) continue;
+                A[k] = RA[k];
+                // the record carries episode 0: stamp the new one (as load_config does)
+                B[k] = make_uint4(RB[k].x, RB[k].y | ((next_episode[k] >> 4) << 28), RB[k].z | (next_episode[k] << 28), RB[k].w);
+            }
+        }
+    }
+
+    // phase 5.  With auto-reset every lane stores (a frozen or padding board is written back as it was read): no
+    // branch between the stores, so none of them waits for an earlier one to be acknowledged.
+#pragma unroll
+    for (int k = 0; k < kBpl; ++k) {
+        const int64_t i = base + (int64_t)k * kThreads;
+        if (!kAutoReset && !live[k]) continue;
+        p.plane_a[i] = A[k];
+        p.plane_b[i] = B[k];
     }
 
     // per-block statistics of the episodes that finished in this step -> one sharded 64-bit atomic per counter
@@ -426,7 +497,7 @@ static int launch_step(tpl_env* e, const void* act0, const void* act1, int32_t d
     if (dtype != TPL_U8 && dtype != TPL_I32 && dtype != TPL_I64) return fail_msg(TPL_ERR_ARG, "unknown integer dtype %d", dtype);
     if (e->auto_reset && e->pool.n_cfg == 0) return fail_msg(TPL_ERR_STATE, "auto_reset needs tpl_load_configs first");
     StepArgs a = make_args(e);
-    a.act0 = act0; a.act1 = act1; a.dtype = dtype; a.reward = reward; a.done = done; a.cleared = cleared;
+    a.act0 = act0; a.act1 = act1; a.int_bytes = dtype == TPL_U8 ? 1u : dtype == TPL_I32 ? 4u : 8u; a.reward = reward; a.done = done; a.cleared = cleared;
     const bool action_form = act1 == nullptr;
     switch (e->boards_per_lane) {
         case 1: launch_step_bpl<1>(e->block_threads, action_form, e->auto_reset != 0, a, stream); break;
@@ -450,9 +521,7 @@ const char* tpl_version(void) { return "tetris_piclim 0.1.0 (gfx950)"; }
 
 size_t tpl_workspace_bytes(int64_t num_envs, int32_t M) {
     if (num_envs <= 0 || M < 1) return 0;
-    const size_t n = (size_t)num_envs;
-    return align_up(n * sizeof(uint4), 256) * 2 +
-           align_up((size_t)kStatShards * kStatStride * sizeof(unsigned long long), 256);
+    return plane_bytes(num_envs) * 2 + align_up((size_t)kStatShards * kStatStride * sizeof(unsigned long long), 256);
 }
 
 size_t tpl_pool_bytes(int64_t n_cfg, int32_t M) {
@@ -488,13 +557,15 @@ int tpl_create(tpl_env** out, int64_t num_envs, int32_t L, int32_t M, int32_t de
         if (err != hipSuccess) { delete e; return fail_msg(TPL_ERR_NOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(err)); }
         e->owned = base;
     }
-    const size_t n = (size_t)num_envs;
-    e->plane_a = (uint4*)base; base += align_up(n * sizeof(uint4), 256);
-    e->plane_b = (uint4*)base; base += align_up(n * sizeof(uint4), 256);
+    const size_t n = (size_t)num_envs, padded = plane_bytes(num_envs) / sizeof(uint4);
+    e->plane_a = (uint4*)base; base += plane_bytes(num_envs);
+    e->plane_b = (uint4*)base; base += plane_bytes(num_envs);
     e->stats = (unsigned long long*)base;
-    // every board: empty, running, no pieces.  Synchronised, because the caller's later work may run on a stream
-    // that does not order itself against the null stream.
+    // every board: empty, running, no pieces; every padding board: lost.  Synchronised, because the caller's later
+    // work may run on a stream that does not order itself against the null stream.
     hipError_t err = hipMemset(e->plane_a, 0, need);
+    if (err == hipSuccess && padded > n)
+        err = hipMemsetD32((hipDeviceptr_t)(e->plane_b + n), (int)((uint32_t)ST_LOST_LIMIT << 30), (padded - n) * 4);
     if (err == hipSuccess) err = hipStreamSynchronize(nullptr);
     if (err != hipSuccess) {
         if (e->owned) (void)hipFree(e->owned);

@@ -12,7 +12,7 @@ struct StepArgs {
     uint32_t L, M;
     const void* act0;          // action, or rot
     const void* act1;          // loc (move form) or null (action form)
-    int32_t dtype;
+    uint32_t int_bytes;        // 1, 4 or 8: width of the little-endian integers act0/act1 point to
     float* reward;
     uint8_t* done;
     uint8_t* cleared;
@@ -41,10 +41,15 @@ inline StepArgs make_args(const tpl_env* e) {
     return a;
 }
 
-__device__ __forceinline__ uint32_t load_int(const void* p, int32_t dtype, int64_t i) {
-    if (dtype == TPL_U8) return ((const uint8_t*)p)[i];
-    if (dtype == TPL_I32) return (uint32_t)((const int32_t*)p)[i];
-    return (uint32_t)((const long long*)p)[i];
+// Element i of an array of 1-, 4- or 8-byte little-endian integers, as its low 32 bits, without a branch on the
+// width: the aligned word that holds the element's first byte is read and shifted.  (For one-byte elements that
+// word may reach up to three bytes past the end of the array -- never past the 4-byte unit the last element is in.)
+__device__ __forceinline__ uint32_t load_int(const void* p, uint32_t bytes, int64_t i) {
+    const char* q = (const char*)p + i * (int64_t)bytes;
+    const uint32_t skew = (uint32_t)((uintptr_t)q & 3u);
+    const uint32_t w = *(const uint32_t*)(q - skew);
+    const uint32_t v = w >> (8u * skew);
+    return bytes == 1u ? (v & 0xFFu) : v;
 }
 
 // (re)initialise a board from pool entry `cfg`.  reset()/load_warm_reset() (:438-449), with the counters

@@ -282,9 +282,12 @@ class BatchedTetris:
     def raw_planes(self):
         """Copies of the two resident state planes, int32 [N, 4] each (layout in DESIGN.md section 2)."""
         n = self.num_envs
-        stride = (n * 16 + 255) // 256 * 256
-        a = self._workspace[: n * 16].view(torch.int32).view(n, 4).clone()
-        b = self._workspace[stride: stride + n * 16].view(torch.int32).view(n, 4).clone()
+        pa, pb = C.c_void_p(), C.c_void_p()
+        check(self._lib.tpl_state_ptrs(self._h, C.byref(pa), C.byref(pb)))
+        base = self._workspace.data_ptr()
+        off_a, off_b = pa.value - base, pb.value - base
+        a = self._workspace[off_a: off_a + n * 16].view(torch.int32).view(n, 4).clone()
+        b = self._workspace[off_b: off_b + n * 16].view(torch.int32).view(n, 4).clone()
         return a, b
 
     def expand_states(self, states_a: torch.Tensor, states_b: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
