@@ -227,8 +227,10 @@ static inline uint32_t fmix32(uint32_t h) {
 int64_t to_env_assign(const to_env* e, int64_t board, uint32_t episode) {
     uint64_t g = (uint64_t)(e->global_offset + board);
     if (e->assign_mode == 1) return (int64_t)((g + (uint64_t)episode) % (uint64_t)e->n_cfg);
-    uint32_t h = fmix32((uint32_t)g ^ ((uint32_t)(g >> 32) * 0x9E3779B9u) ^ (uint32_t)e->seed);
-    h = fmix32(h + episode * 0x9E3779B1u + (uint32_t)(e->seed >> 32));
+    /* 24-bit multiplies (low 24 bits of each factor, low 32 bits of the product), one finaliser round */
+    uint32_t x = ((uint32_t)g + (episode & 0xFFFFFFu) * 0x9E3779u) ^ (((uint32_t)(g >> 32) & 0xFFFFFFu) * 0x85EBCBu)
+                 ^ (uint32_t)(sm64(e->seed) >> 32);
+    uint32_t h = fmix32(x);
     return (int64_t)(((uint64_t)h * (uint64_t)(uint32_t)e->n_cfg) >> 32);
 }
 

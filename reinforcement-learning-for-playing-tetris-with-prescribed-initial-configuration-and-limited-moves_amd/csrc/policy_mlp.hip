@@ -434,7 +434,8 @@ __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q
             const uint32_t act0 = pick_action(lg[0], g, lane), act1 = pick_action(lg[1], g, lane);
             uint32_t action = (g >> 1) ? act1 : act0;
             action = explore(action, q.explore_seed, (uint64_t)(p.global_offset + b), q.step0 + t, q.eps_q24);
-            const uint32_t rot = action / 10u, loc = action - rot * 10u;
+            uint32_t rot, loc;
+            split_action(action, rot, loc);
             float reward;
             Tally mine;
             const bool done = advance_board<kAutoReset>(s, cfg, rot, loc, p, (uint32_t)b, s_shape, reward, mine);

@@ -31,7 +31,14 @@ constexpr size_t kPlanePad = 512 * 4;
 static inline size_t plane_bytes(int64_t n) { return align_up((size_t)n, kPlanePad) * sizeof(uint4); }
 // piece words of a configuration: entries 0..M+1 must be addressable (pieces[1] after the last move)
 static inline int piece_words(int M) { return (M + 2 + kWindowStride - 1) / kWindowStride; }
-static inline size_t record_stride(int M) { return align_up(32 + 4 * (size_t)(piece_words(M) - 1), 64); }
+// record stride: a power of two (64, 128 or 256 bytes), so that a record's address is one shift-and-add
+static inline uint32_t record_stride_shift(int M) {
+    const size_t need = 32 + 4 * (size_t)(piece_words(M) - 1);
+    uint32_t shift = 6;
+    while (((size_t)1 << shift) < need) ++shift;
+    return shift;
+}
+static inline size_t record_stride(int M) { return (size_t)1 << record_stride_shift(M); }
 
 // ---------------------------------------------------------------------------------------------- kernels
 // One Tetris.move per board (:354-422).  ACTION form: act0 = rot*10+loc; MOVE form: act0 = rot, act1 = loc.
@@ -44,10 +51,21 @@ static inline size_t record_stride(int M) { return align_up(32 + 4 * (size_t)(pi
 //   3  reward / done / cleared are written
 //   4  the pool records of the boards that finished are requested (auto-reset)
 //   5  the state words are written
+#ifdef TPL_DIAG_CLOCK
+// diagnostic build only (tools/step_timeline.py): every wave stamps the 100 MHz real-time counter
+#define TPL_STAMP(k) stamp[k] = __builtin_amdgcn_s_memrealtime()   /* wave-uniform: stays in scalar registers */
+#else
+#define TPL_STAMP(k) do { } while (0)
+#endif
+
 template <bool kActionForm, bool kAutoReset, int kBpl, int kThreads>
 __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
     __shared__ ShapeWord s_shape[32];
     __shared__ uint32_t s_stat[4];
+#ifdef TPL_DIAG_CLOCK
+    unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    TPL_STAMP(0);
 
     // phase 0.  The shape table's trip to LDS rides in the shadow of the board loads instead of ahead of them.
     const int64_t base = (int64_t)blockIdx.x * (kThreads * kBpl) + threadIdx.x;
@@ -64,8 +82,12 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         const int64_t j = valid[k] ? i : p.n - 1;
         A[k] = p.plane_a[i];
         B[k] = p.plane_b[i];
-        a0[k] = load_int(p.act0, p.int_bytes, j);
-        a1[k] = kActionForm ? 0u : load_int(p.act1, p.int_bytes, j);
+#ifdef TPL_X_NOACT
+        a0[k] = (uint32_t)((j * 2654435761u) >> 7) % 40u;
+#else
+        a0[k] = load_int(p.act0, p.int_shift, j);
+#endif
+        a1[k] = kActionForm ? 0u : load_int(p.act1, p.int_shift, j);
     }
     if (threadIdx.x < 32) s_shape[threadIdx.x] = kShapeTable[threadIdx.x];
     if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
@@ -82,6 +104,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         // which then has to be waited for as well)
         asm volatile("" ::"v"(A[k].x), "v"(B[k].x), "v"(a0[k]), "v"(a1[k]));
     }
+    TPL_STAMP(1);
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
         const uint32_t moves = (A[k].y >> 28) | ((A[k].w >> 28) << 4);
@@ -95,8 +118,8 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         const int64_t i = base + (int64_t)k * kThreads;
         word[k] = 0;
         if (refill[k]) {
-            const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, episode[k], p.seed, p.n_cfg, p.assign_mode);
-            word[k] = *(const uint32_t*)(p.pool + (size_t)cfg * p.stride + 32u + 4u * ((cursor[k] >> 3) - 1u));
+            const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, episode[k], p.seed_mix, p.n_cfg, p.assign_mode);
+            word[k] = *(const uint32_t*)(pool_record(p.pool, p.stride_shift, cfg) + 32u + 4u * ((cursor[k] >> 3) - 1u));
         }
     }
 
@@ -115,8 +138,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         if (!live[k]) continue;                               // frozen: reward 0, done, state untouched
         uint32_t rot, loc;
         if (kActionForm) {
-            rot = a0[k] / 10u;
-            loc = a0[k] - rot * 10u;
+            split_action(a0[k], rot, loc);
         } else {
             rot = a0[k];
             loc = a1[k];
@@ -144,6 +166,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         pack_board(s, A[k], B[k]);
     }
 
+    TPL_STAMP(2);
     // phase 3
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
@@ -166,8 +189,8 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
 #pragma unroll
             for (int k = 0; k < kBpl; ++k) {
                 const int64_t i = base + (int64_t)k * kThreads;
-                const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, next_episode[k], p.seed, p.n_cfg, p.assign_mode);
-                const uint4* rec = (const uint4*)(p.pool + (size_t)(reload[k] ? cfg : 0u) * p.stride);
+                const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, next_episode[k], p.seed_mix, p.n_cfg, p.assign_mode);
+                const uint4* rec = (const uint4*)pool_record(p.pool, p.stride_shift, reload[k] ? cfg : 0u);
                 RA[k] = rec[0];
                 RB[k] = rec[1];
             }
@@ -181,6 +204,11 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         }
     }
 
+#ifdef TPL_DIAG_CLOCK
+#pragma unroll
+    for (int k = 0; k < kBpl; ++k) asm volatile("" ::"v"(A[k].x), "v"(B[k].x));
+#endif
+    TPL_STAMP(3);
     // phase 5.  With auto-reset every lane stores (a frozen or padding board is written back as it was read): no
     // branch between the stores, so none of them waits for an earlier one to be acknowledged.
 #pragma unroll
@@ -191,6 +219,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         p.plane_b[i] = B[k];
     }
 
+    TPL_STAMP(4);
     // per-block statistics of the episodes that finished in this step -> one sharded 64-bit atomic per counter
     if (__syncthreads_or(finished ? 1 : 0)) {
         if (threadIdx.x < 4) {
@@ -199,6 +228,14 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
                              (unsigned long long)v);
         }
     }
+#ifdef TPL_DIAG_CLOCK
+    __builtin_amdgcn_s_waitcnt(0);           // the stores have been acknowledged
+    TPL_STAMP(5);
+    if (p.diag && (threadIdx.x & 63) == 0) {
+        unsigned long long* d = p.diag + 6 * ((size_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6));
+        for (int k = 0; k < 6; ++k) d[k] = stamp[k];
+    }
+#endif
 }
 
 // K consecutive moves per board in ONE launch: the board stays unpacked in registers between
@@ -244,7 +281,8 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
             // next step's action is independent of the board: fetch it under this step's move
             uint32_t act_next = 0;
             if (k + 1 < q.K) act_next = q.actions[(size_t)(k + 1) * q.action_stride + i];
-            const uint32_t rot = act / 10u, loc = act - rot * 10u;
+            uint32_t rot, loc;
+            split_action(act, rot, loc);
             float reward;
             const bool done = advance_board<kAutoReset>(s, cfg, rot, loc, p, (uint32_t)i, s_shape, reward, tally);
             rsum = rsum + reward;
@@ -272,9 +310,9 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs p, const u
         unpack_board(p.plane_a[i], p.plane_b[i], s);
         ep = (s.episode + 1u) & 0xFFu;
     }
-    const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, ep, p.seed, p.n_cfg, p.assign_mode);
+    const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, ep, p.seed_mix, p.n_cfg, p.assign_mode);
     uint4 A, B;
-    load_config(p.pool, p.stride, cfg, ep, A, B);
+    load_config(p.pool, p.stride_shift, cfg, ep, A, B);
     p.plane_a[i] = A;
     p.plane_b[i] = B;
 }
@@ -497,7 +535,7 @@ static int launch_step(tpl_env* e, const void* act0, const void* act1, int32_t d
     if (dtype != TPL_U8 && dtype != TPL_I32 && dtype != TPL_I64) return fail_msg(TPL_ERR_ARG, "unknown integer dtype %d", dtype);
     if (e->auto_reset && e->pool.n_cfg == 0) return fail_msg(TPL_ERR_STATE, "auto_reset needs tpl_load_configs first");
     StepArgs a = make_args(e);
-    a.act0 = act0; a.act1 = act1; a.int_bytes = dtype == TPL_U8 ? 1u : dtype == TPL_I32 ? 4u : 8u; a.reward = reward; a.done = done; a.cleared = cleared;
+    a.act0 = act0; a.act1 = act1; a.int_shift = dtype == TPL_U8 ? 0u : dtype == TPL_I32 ? 2u : 3u; a.reward = reward; a.done = done; a.cleared = cleared;
     const bool action_form = act1 == nullptr;
     switch (e->boards_per_lane) {
         case 1: launch_step_bpl<1>(e->block_threads, action_form, e->auto_reset != 0, a, stream); break;
@@ -617,11 +655,11 @@ int tpl_load_configs(tpl_env* e, const uint16_t* rows, const uint8_t* pieces, in
     }
     e->pool.owned = newly_owned;
     e->pool.rec = (uint8_t*)base;
-    e->pool.stride = (uint32_t)record_stride(e->M);
+    e->pool.stride_shift = record_stride_shift(e->M);
     e->pool.n_cfg = n_cfg;
     TPL_HIP(hipMemsetAsync(base, 0, need, (hipStream_t)stream));     // record padding reads as zero
     hipLaunchKernelGGL(pack_configs_kernel, dim3(blocks_for(n_cfg)), dim3(kBlock), 0, (hipStream_t)stream, rows, pieces,
-                       n_cfg, (uint32_t)e->M, (uint32_t)piece_words(e->M), e->pool.rec, e->pool.stride);
+                       n_cfg, (uint32_t)e->M, (uint32_t)piece_words(e->M), e->pool.rec, (uint32_t)record_stride(e->M));
     TPL_HIP(hipGetLastError());
     return TPL_OK;
 }
@@ -793,5 +831,14 @@ int tpl_synth_actions(tpl_env* e, uint64_t seed, int64_t first, int64_t count, u
     TPL_HIP(hipGetLastError());
     return TPL_OK;
 }
+
+#ifdef TPL_DIAG_CLOCK
+// diagnostic build only: where the step kernel writes its per-wave stamps (6 x uint64 per wave), or null
+int tpl_dev_set_step_diag(tpl_env* e, void* diag) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    e->step_diag = (unsigned long long*)diag;
+    return TPL_OK;
+}
+#endif
 
 }  // extern "C"

@@ -260,11 +260,15 @@ __host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
 }
 
 // which pool entry episode `episode` of global board `g` = global_offset + i starts from.
-// hash mode: two rounds of a 32-bit finaliser, range-reduced with a multiply-high.
+// hash mode: (g, episode, seed) folded into 32 bits with 24-bit multiplies (full rate on the vector ALU), one round of
+// a 32-bit finaliser (a bijection, so boards 2^32 apart at most share a draw), range-reduced with a multiply-high.
+// `seed_mix` = assign_seed(seed), computed once on the host.
 // sequential mode: (g + episode) mod n_cfg, done with 32-bit remainders only (offset_mod = global_offset mod n_cfg
 // comes from the host) because a 64-bit remainder is a long software routine on the GPU.
+__host__ __device__ __forceinline__ uint32_t assign_seed(uint64_t seed) { return (uint32_t)(sm64(seed) >> 32); }
+
 __device__ __forceinline__ uint32_t assign_config(int64_t global_offset, uint32_t offset_mod, uint32_t i, uint32_t episode,
-                                                  uint64_t seed, uint32_t n_cfg, int mode) {
+                                                  uint32_t seed_mix, uint32_t n_cfg, int mode) {
     if (mode == 1) {
         uint64_t t = (uint64_t)offset_mod + (uint64_t)(i % n_cfg);
         if (t >= n_cfg) t -= n_cfg;
@@ -273,9 +277,8 @@ __device__ __forceinline__ uint32_t assign_config(int64_t global_offset, uint32_
         return (uint32_t)t;
     }
     const uint64_t g = (uint64_t)global_offset + i;
-    uint32_t h = fmix32((uint32_t)g ^ ((uint32_t)(g >> 32) * 0x9E3779B9u) ^ (uint32_t)seed);
-    h = fmix32(h + episode * 0x9E3779B1u + (uint32_t)(seed >> 32));
-    return (uint32_t)(((uint64_t)h * (uint64_t)n_cfg) >> 32);
+    const uint32_t x = ((uint32_t)g + __umul24(episode, 0x9E3779u)) ^ __umul24((uint32_t)(g >> 32), 0x85EBCBu) ^ seed_mix;
+    return __umulhi(fmix32(x), n_cfg);
 }
 
 }  // namespace tpl

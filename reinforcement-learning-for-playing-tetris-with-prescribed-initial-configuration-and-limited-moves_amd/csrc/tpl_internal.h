@@ -11,8 +11,8 @@ constexpr int kStatShards = 256;
 constexpr int kStatStride = 16;   // uint64 per shard -> one 128-B line each
 
 struct Pool {
-    uint8_t* rec = nullptr;    // [n_cfg] records of `stride` bytes: plane-A word, plane-B word, piece words 1..
-    uint32_t stride = 0;
+    uint8_t* rec = nullptr;    // [n_cfg] records of 1 << stride_shift bytes: plane-A word, plane-B word, piece words 1..
+    uint32_t stride_shift = 0;
     int64_t n_cfg = 0;
     void* owned = nullptr;
 };
@@ -33,6 +33,9 @@ struct tpl_env {
     unsigned long long* stats = nullptr;// [kStatShards][kStatStride]
     void* owned = nullptr;
     tpl::Pool pool;
+#ifdef TPL_DIAG_CLOCK
+    unsigned long long* step_diag = nullptr;
+#endif
 };
 
 namespace tpl {

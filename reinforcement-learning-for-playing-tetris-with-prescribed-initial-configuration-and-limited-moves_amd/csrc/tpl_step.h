@@ -12,20 +12,23 @@ struct StepArgs {
     uint32_t L, M;
     const void* act0;          // action, or rot
     const void* act1;          // loc (move form) or null (action form)
-    uint32_t int_bytes;        // 1, 4 or 8: width of the little-endian integers act0/act1 point to
+    uint32_t int_shift;        // 0, 2 or 3: log2 of the width of the little-endian integers act0/act1 point to
     float* reward;
     uint8_t* done;
     uint8_t* cleared;
     float r_line, r_win, r_lose;
     // configuration pool (auto-reset, window refills)
     const uint8_t* pool;
-    uint32_t stride;
+    uint32_t stride_shift;     // records are 1 << stride_shift bytes apart
     uint32_t n_cfg;
     int32_t assign_mode;
-    uint64_t seed;
+    uint32_t seed_mix;         // assign_seed(seed)
     int64_t global_offset;
     uint32_t offset_mod;       // global_offset mod n_cfg
     unsigned long long* stats;
+#ifdef TPL_DIAG_CLOCK
+    unsigned long long* diag;  // diagnostic build: per-wave clock stamps of the step kernel
+#endif
 };
 
 // host: the arguments every board-advancing kernel takes from the handle
@@ -34,29 +37,43 @@ inline StepArgs make_args(const tpl_env* e) {
     a.plane_a = e->plane_a; a.plane_b = e->plane_b;
     a.n = e->n; a.L = (uint32_t)e->L; a.M = (uint32_t)e->M;
     a.r_line = e->r_line; a.r_win = e->r_win; a.r_lose = e->r_lose;
-    a.pool = e->pool.rec; a.stride = e->pool.stride;
-    a.n_cfg = (uint32_t)e->pool.n_cfg; a.assign_mode = e->assign_mode; a.seed = e->seed;
+    a.pool = e->pool.rec; a.stride_shift = e->pool.stride_shift;
+    a.n_cfg = (uint32_t)e->pool.n_cfg; a.assign_mode = e->assign_mode; a.seed_mix = assign_seed(e->seed);
     a.global_offset = e->global_offset; a.stats = e->stats;
+#ifdef TPL_DIAG_CLOCK
+    a.diag = e->step_diag;
+#endif
     a.offset_mod = e->pool.n_cfg ? (uint32_t)((uint64_t)e->global_offset % (uint64_t)e->pool.n_cfg) : 0u;
     return a;
 }
 
-// Element i of an array of 1-, 4- or 8-byte little-endian integers, as its low 32 bits, without a branch on the
-// width: the aligned word that holds the element's first byte is read and shifted.  (For one-byte elements that
-// word may reach up to three bytes past the end of the array -- never past the 4-byte unit the last element is in.)
-__device__ __forceinline__ uint32_t load_int(const void* p, uint32_t bytes, int64_t i) {
-    const char* q = (const char*)p + i * (int64_t)bytes;
+// Element i of an array of 1-, 4- or 8-byte little-endian integers (1 << shift bytes each), as its low 32 bits,
+// without a branch on the width: the aligned word that holds the element's first byte is read and shifted.  (For
+// one-byte elements that word may reach up to three bytes past the end of the array -- never past the 4-byte unit
+// the last element is in.)
+__device__ __forceinline__ uint32_t load_int(const void* p, uint32_t shift, int64_t i) {
+    const char* q = (const char*)p + (i << shift);
     const uint32_t skew = (uint32_t)((uintptr_t)q & 3u);
     const uint32_t w = *(const uint32_t*)(q - skew);
     const uint32_t v = w >> (8u * skew);
-    return bytes == 1u ? (v & 0xFFu) : v;
+    return shift == 0u ? (v & 0xFFu) : v;
+}
+
+// action = rot * 10 + loc, exact for any 32-bit action, without an integer multiply beyond the one multiply-high
+__device__ __forceinline__ void split_action(uint32_t action, uint32_t& rot, uint32_t& loc) {
+    rot = __umulhi(action, 0xCCCCCCCDu) >> 3;
+    loc = action - ((rot << 3) + (rot << 1));
 }
 
 // (re)initialise a board from pool entry `cfg`.  reset()/load_warm_reset() (:438-449), with the counters
 // zeroed; the record's two state words are one 32-B read.
-__device__ __forceinline__ void load_config(const uint8_t* pool, uint32_t stride, uint32_t cfg, uint32_t episode,
+__device__ __forceinline__ const uint8_t* pool_record(const uint8_t* pool, uint32_t stride_shift, uint32_t cfg) {
+    return pool + ((size_t)cfg << stride_shift);
+}
+
+__device__ __forceinline__ void load_config(const uint8_t* pool, uint32_t stride_shift, uint32_t cfg, uint32_t episode,
                                             uint4& A, uint4& B) {
-    const uint4* rec = (const uint4*)(pool + (size_t)cfg * stride);
+    const uint4* rec = (const uint4*)pool_record(pool, stride_shift, cfg);
     A = rec[0];
     const uint4 pb = rec[1];
     B = make_uint4(pb.x, pb.y | ((episode >> 4) << 28), pb.z | (episode << 28), pb.w);
@@ -68,7 +85,7 @@ struct Tally { uint32_t episodes = 0, lines = 0, wins = 0, topouts = 0; };
 // pool entry of the board's current episode (kept in a register by the multi-step kernels: the window refill needs
 // it every eighth move, and hashing it again each time costs more than the refill itself)
 __device__ __forceinline__ uint32_t current_config(const Board& s, const StepArgs& p, uint32_t i) {
-    return p.n_cfg ? assign_config(p.global_offset, p.offset_mod, i, s.episode, p.seed, p.n_cfg, p.assign_mode) : 0u;
+    return p.n_cfg ? assign_config(p.global_offset, p.offset_mod, i, s.episode, p.seed_mix, p.n_cfg, p.assign_mode) : 0u;
 }
 
 // One step of one unpacked board held in registers: Tetris.move (:354-422) + the window pop/refill + the
@@ -84,7 +101,7 @@ __device__ __forceinline__ bool advance_board(Board& s, uint32_t& cfg, uint32_t 
     const uint32_t cursor = s.moves + 1u;
     const bool refill = (cursor & (uint32_t)(kWindowStride - 1)) == 0u && p.n_cfg != 0u;
     uint32_t word = 0;
-    if (refill) word = *(const uint32_t*)(p.pool + (size_t)cfg * p.stride + 32u + 4u * ((cursor >> 3) - 1u));
+    if (refill) word = *(const uint32_t*)(pool_record(p.pool, p.stride_shift, cfg) + 32u + 4u * ((cursor >> 3) - 1u));
     bool topout;
     const uint32_t n_clear = move_board(s, shape, rot, loc, p.L, p.M, topout);
     s.window = refill ? word : (s.window >> 3);
@@ -99,9 +116,9 @@ __device__ __forceinline__ bool advance_board(Board& s, uint32_t& cfg, uint32_t 
         tally.topouts += s.state == ST_LOST_TOPOUT ? 1u : 0u;
         if (kAutoReset) {
             const uint32_t ep = (s.episode + 1u) & 0xFFu;
-            cfg = assign_config(p.global_offset, p.offset_mod, i, ep, p.seed, p.n_cfg, p.assign_mode);
+            cfg = assign_config(p.global_offset, p.offset_mod, i, ep, p.seed_mix, p.n_cfg, p.assign_mode);
             uint4 A2, B2;
-            load_config(p.pool, p.stride, cfg, ep, A2, B2);
+            load_config(p.pool, p.stride_shift, cfg, ep, A2, B2);
             unpack_board(A2, B2, s);
         }
     }

@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--bpl", type=int, nargs="+", default=[1, 2, 4])
     ap.add_argument("--threads", type=int, nargs="+", default=[256])
     ap.add_argument("--auto-reset", type=int, default=1)
+    ap.add_argument("--action-period", type=int, default=0,
+                    help="reuse the first P action rows cyclically (small P: the actions stay cache-resident)")
     args = ap.parse_args()
     import torch
     import tetris_piclim as T
@@ -33,6 +35,7 @@ def main():
         env.synthetic_actions(t, out=actions[t])
     reward = torch.empty(n, dtype=torch.float32, device=env.device)
     done = torch.empty(n, dtype=torch.uint8, device=env.device)
+    P = args.action_period or K
     combos = [(b, th) for b in args.bpl for th in args.threads]
     res = {c: [] for c in combos}
     for r in range(args.rounds + 1):
@@ -41,7 +44,7 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for t in range(K):
-                env.step_into(actions[t], reward, done)
+                env.step_into(actions[t % P], reward, done)
             e1.record()
             torch.cuda.synchronize()
             if r:
