@@ -292,7 +292,7 @@ def test_many_short_episodes_wrap_the_episode_counter(T, oracle, bpl):
     gpu.terminate()
 
 
-@pytest.mark.parametrize("M", [7, 8, 9, 15, 16, 17, 70, 254])
+@pytest.mark.parametrize("M", [7, 8, 9, 15, 16, 17, 70, 71, 72, 199, 200, 254])      # 71|72, 199|200: record stride 64|128|256
 def test_piece_window_refills_at_every_word_boundary(T, oracle, M):
     """Boards that survive all M moves (empty start, O pieces side by side never top out before M for small M;
     otherwise whatever happens) with random piece lists: checks cur/nxt against the oracle on every step."""
@@ -610,6 +610,32 @@ def test_step_is_graph_capturable_and_replays_exactly(T, oracle):
             assert np.array_equal(_np(rewards[t]), r_c) and np.array_equal(_np(dones[t]), d_c), (rep, t)
     _assert_state_equal(_state(gpu), cpu.get_state(), "graph")
     gpu.terminate()
+
+
+@pytest.mark.parametrize("n", [1, 63, 1000, 2049, 5000])
+def test_ragged_batches_match_oracle_in_every_geometry(T, oracle, n):
+    """Batch sizes that do not fill the last block: the step kernel reads and writes back the padding boards behind
+    the batch (created finished, never advanced, never counted).  Every geometry, auto-reset on, statistics equal."""
+    L, M, seed = 4, 12, 11
+    for bpl in (1, 2, 4):
+        for threads in (64, 128, 256, 512):
+            gpu = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True, reward=(1.0, 2.0, -3.0))
+            gpu.set_tuning(bpl, threads)
+            rows, pieces = gpu.synthetic_configs(97)
+            gpu.load_configs(rows, pieces)
+            gpu.reset()
+            cpu = oracle.Env(n, L, M, 0, seed)
+            cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
+            cpu.set_options(auto_reset=True, assign_mode=0, per_line=1.0, win=2.0, lose=-3.0)
+            cpu.reset()
+            for t in range(2 * M + 3):
+                a = gpu.synthetic_actions(t)
+                _, r_g, d_g, _ = gpu.step(a, observe=False)
+                r_c, d_c = cpu.step(_np(a))
+                assert np.array_equal(_np(r_g), r_c) and np.array_equal(_np(d_g).astype(np.uint8), d_c), (bpl, threads, t)
+            _assert_state_equal(_state(gpu), cpu.get_state(), f"n={n} bpl={bpl} threads={threads}")
+            assert gpu.stats() == cpu.stats()
+            gpu.terminate()
 
 
 def test_ragged_sizes_and_errors(T):

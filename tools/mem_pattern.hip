@@ -75,6 +75,8 @@ __global__ __launch_bounds__(256) void flags_kernel(Args p) {
     p.a[i] = A; p.b[i] = B;
 }
 
+__global__ void empty_kernel(int* p) { if (p && threadIdx.x == 9999) *p = 1; }
+
 template <typename F>
 static float time_us(F launch, int reps) {
     hipEvent_t e0, e1;
@@ -117,7 +119,9 @@ int main(int argc, char** argv) {
     FLAGS(8, "flags: + done write (LDS-staged lines)", 65.0);
     FLAGS(7, "flags: + action + reward + done", 70.0);
     FLAGS(11, "flags: + action + reward + staged done", 70.0);
-    for (int round = 0; round < 3; ++round) {
+    cases.push_back({"empty kernel, 1 block (launch period)", [&](int) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, 0, (int*)nullptr); }, 0.0});
+    cases.push_back({"empty kernel, 2048 blocks", [&](int) { hipLaunchKernelGGL(empty_kernel, dim3(2048), dim3(256), 0, 0, (int*)nullptr); }, 0.0});
+    for (int round = 0; round < 2; ++round) {
         printf("-- round %d\n", round);
         for (auto& c : cases) report(c.name, time_us(c.launch, steps), c.bytes * n);
     }
