@@ -20,7 +20,7 @@ _EXTRA = os.environ.get("TPL_EXTRA_DEFINE", "")
 LIB_PATH = os.path.join(_CSRC, "libtetris_piclim_diag.so" if _DIAG else
                         f"libtetris_piclim_{_EXTRA}.so" if _EXTRA else "libtetris_piclim.so")
 _UNITS = [os.path.join(_CSRC, f) for f in ("tetris_piclim.hip", "carve_generator.hip", "carve_device.hip",
-                                           "forward_generator.hip", "policy_mlp.hip")]
+                                           "forward_generator.hip", "policy_mlp.hip", "observe.hip")]
 _SOURCES = _UNITS + [os.path.join(_CSRC, "tpl_device.h"), os.path.join(_CSRC, "tpl_internal.h"),
                      os.path.join(_CSRC, "tpl_step.h"), os.path.join(_CSRC, "py_random.h"),
                      os.path.join(_ROOT, "include", "tetris_piclim.h")]

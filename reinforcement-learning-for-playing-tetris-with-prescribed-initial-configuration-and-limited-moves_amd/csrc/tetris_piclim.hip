@@ -367,8 +367,9 @@ __global__ __launch_bounds__(kBlock) void export_kernel(const uint4* plane_a, co
     if (pieces_left) pieces_left[i] = (uint8_t)(M + 1u - s.moves - (s.state == ST_LOST_TOPOUT ? 1u : 0u));
 }
 
-// Observation [n][217]: a wave expands its 64 boards cooperatively so that every store instruction writes
-// 256 contiguous bytes.  Each lane first turns its own board into a row-major 200-bit cell vector
+// Observation [n][217], element-wise form (the fast form is observe.hip; this one serves outputs that are not
+// 16-byte aligned): a wave expands its 64 boards cooperatively so that every store instruction writes 256
+// contiguous bytes.  Each lane first turns its own board into a row-major 200-bit cell vector
 // (7 words) + one feature word in LDS; then for each board all 64 lanes emit its 217 values.
 template <typename T>
 __device__ __forceinline__ T obs_cast(float v);
@@ -721,6 +722,9 @@ int tpl_get_state(tpl_env* e, uint16_t* rows, uint8_t* cur, uint8_t* nxt, uint8_
 
 static int launch_expand(tpl_env* e, const uint4* plane_a, const uint4* plane_b, int64_t n, void* out, int32_t dtype,
                          hipStream_t stream) {
+    if (dtype != TPL_F32 && dtype != TPL_BF16) return fail_msg(TPL_ERR_ARG, "unknown observation dtype %d", dtype);
+    if (observe_fast_path(out)) return launch_observe(plane_a, plane_b, n, (uint32_t)e->L, (uint32_t)e->M, out, dtype, stream);
+    // an output that is not 16-byte aligned (a slice of a larger tensor): element-wise stores
     const dim3 grid(blocks_for(n)), block(kBlock);
     if (dtype == TPL_F32)
         hipLaunchKernelGGL(expand_obs_kernel<float>, grid, block, 0, stream, plane_a, plane_b, n, (uint32_t)e->L,

@@ -49,6 +49,11 @@ int fail_msg(int code, const char* fmt, ...);
         if (e_ != hipSuccess) return ::tpl::fail_msg(TPL_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+// observe.hip: the [N,217] observation with 16-byte stores (needs a 16-byte aligned output)
+bool observe_fast_path(const void* out);
+int launch_observe(const uint4* plane_a, const uint4* plane_b, int64_t n, uint32_t L, uint32_t M, void* out, int32_t dtype,
+                   hipStream_t stream);
+
 struct DeviceGuard {
     int prev = -1;
     bool ok = true;

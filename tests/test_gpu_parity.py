@@ -446,6 +446,44 @@ def test_observation_matches_oracle(T, oracle):
     gpu.terminate()
 
 
+@pytest.mark.parametrize("n", [1, 7, 64, 65, 129, 4097])
+def test_observation_on_dense_boards_frozen_wins_and_odd_sizes(T, oracle, n):
+    """The 16-byte-store observation kernel: boards with every cell pattern (dense random rows), boards frozen after a
+    win whose last clear overshot L (lines left below zero), batch sizes around the 64-board span of a wave, f32
+    and bf16, and an output that is not 16-byte aligned (element-wise path)."""
+    import torch
+    L, M = 2, 30
+    rng = np.random.default_rng(100 + n)
+    rows = rng.integers(0, 1 << 10, (n, 20)).astype(np.uint16)
+    rows[:, :6] = 0                                    # room to play
+    rows[rows == 0x3FF] = 0x3FE
+    if n >= 7:                                         # a double clear from lines=1 on a board that needs L=2: overshoot
+        rows[3] = 0
+        rows[3, 17] = 0x3FE                            # one cell missing at x=0: an upright I at x=0 clears rows 17..19
+        rows[3, 18] = 0x3FE
+        rows[3, 19] = 0x3FE
+    pieces = rng.integers(0, 7, (n, M + 1)).astype(np.uint8)
+    pieces[:, 0] = 0                                   # I first
+    gpu = T.BatchedTetris(L, M, n, assign="sequential", config_pool=(rows, pieces))
+    cpu = oracle.Env(n, L, M)
+    cpu.set_pool(rows, pieces)
+    cpu.set_options(assign_mode=1)
+    gpu.reset(); cpu.reset()
+    spare = torch.empty(n * 217 + 8, dtype=torch.float32, device=gpu.device)
+    for t in range(10):
+        rot = np.full(n, 1 if t == 0 else t % 4, np.uint8)
+        loc = np.full(n, 0 if t == 0 else (3 * t) % 10, np.uint8)
+        gpu.move(rot, loc); cpu.move(rot, loc)
+        want = cpu.expand_obs()
+        assert np.array_equal(_np(gpu.observe(torch.float32)), want), t
+        assert np.array_equal(_np(gpu.observe(torch.bfloat16).float()), want), t
+        unaligned = spare[1: 1 + n * 217].view(n, 217)             # 4 bytes off a 16-byte boundary
+        assert np.array_equal(_np(gpu.observe(out=unaligned)), want), t
+    if n >= 7:
+        assert want[3, 214] < 0 and want[3, 216] == 1              # the overshoot really happened and is frozen
+    gpu.terminate()
+
+
 def test_sharding_is_independent_of_the_number_of_gpus(T):
     """Two handles with global offsets reproduce one handle over the whole batch (the multi-GPU partition)."""
     import torch
