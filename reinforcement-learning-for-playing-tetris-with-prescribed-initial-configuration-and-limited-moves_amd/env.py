@@ -190,8 +190,21 @@ class BatchedTetris:
         check(self._lib.tpl_move(self._h, _ptr(rot), _ptr(loc), code, _ptr(reward), _ptr(done), _ptr(cleared), self._stream()))
         return reward, done.view(torch.bool), cleared
 
+    def _own(self, t: torch.Tensor, dtype, what: str, shape=None) -> torch.Tensor:
+        """A caller-owned buffer the library will read or write through a raw pointer: it must be exactly what the
+        kernel assumes (an out-of-range access on the device can take the whole GPU down)."""
+        shape = (self.num_envs,) if shape is None else shape
+        ok = dtype if isinstance(dtype, (tuple, list, dict)) else (dtype,)
+        if (not isinstance(t, torch.Tensor) or t.dtype not in ok or tuple(t.shape) != tuple(shape) or t.device != self.device
+                or not t.is_contiguous()):
+            raise ValueError(f"{what} must be a contiguous {'/'.join(str(d) for d in ok)} tensor of shape {tuple(shape)} on {self.device}")
+        return t
+
     def step_into(self, action: torch.Tensor, reward: torch.Tensor, done: torch.Tensor) -> None:
         """step() writing into caller-owned buffers (uint8/int32/int64 action, f32 reward, uint8 done)."""
+        self._own(action, _INT_CODES, "action")
+        self._own(reward, torch.float32, "reward")
+        self._own(done, torch.uint8, "done")
         check(self._lib.tpl_step(self._h, _ptr(action), _INT_CODES[action.dtype], _ptr(reward), _ptr(done), self._stream()))
 
     def step(self, action, observe: bool = True, obs_dtype=torch.float32):
@@ -225,21 +238,25 @@ class BatchedTetris:
 
     def rollout_into(self, actions: torch.Tensor, K: int) -> None:
         """rollout() without outputs (statistics only): the throughput form used by bench.py."""
+        if (actions.dtype != torch.uint8 or actions.dim() != 2 or actions.shape[1] != self.num_envs or actions.stride(1) != 1
+                or actions.device != self.device or not 1 <= K <= actions.shape[0]):
+            raise ValueError(f"actions must be uint8 [>= K, {self.num_envs}] on {self.device} with unit inner stride")
         check(self._lib.tpl_rollout(self._h, _ptr(actions), actions.stride(0), K, None, None, None, None, self._stream()))
 
     def observe(self, dtype=torch.float32, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[N, 217] observation for Model(217, 14) (model/train.py:26)."""
         if out is None:
             out = torch.empty((self.num_envs, OBS_DIM), dtype=dtype, device=self.device)
+        self._own(out, _OBS_CODES, "out", (self.num_envs, OBS_DIM))
         check(self._lib.tpl_expand_obs(self._h, _ptr(out), _OBS_CODES[out.dtype], self._stream()))
         return out
 
     def decode_actions(self, logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[N, 14] policy outputs (f32 or bf16) -> uint8 actions: argmax of 4 rotation logits and 10 location logits."""
-        if logits.shape != (self.num_envs, 14) or not logits.is_contiguous():
-            raise ValueError(f"logits must be contiguous [{self.num_envs}, 14]")
+        self._own(logits, _OBS_CODES, "logits", (self.num_envs, 14))
         if out is None:
             out = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        self._own(out, torch.uint8, "out")
         check(self._lib.tpl_decode_actions(self._h, _ptr(logits), _OBS_CODES[logits.dtype], _ptr(out), self._stream()))
         return out
 
@@ -248,13 +265,19 @@ class BatchedTetris:
         pack_policy(...).  Returns the uint8 actions; fills `logits` ([N, 14] float32) when given."""
         if out is None:
             out = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
-        if logits is not None and (logits.shape != (self.num_envs, 14) or logits.dtype != torch.float32 or not logits.is_contiguous()):
-            raise ValueError("logits must be a contiguous float32 [N, 14] tensor")
+        self._own(out, torch.uint8, "out")
+        self._image(image)
+        if logits is not None:
+            self._own(logits, torch.float32, "logits", (self.num_envs, 14))
         check(self._lib.tpl_policy_act(self._h, _ptr(image), _ptr(out), _ptr(logits), self._stream()))
         return out
 
+    def _image(self, image: torch.Tensor) -> torch.Tensor:
+        return self._own(image, torch.uint8, "image (the device copy of pack_policy(...))", (self._lib.tpl_policy_image_bytes(),))
+
     def explore_actions(self, action: torch.Tensor, epsilon: float, seed: int = 0, step: int = 0) -> torch.Tensor:
         """Epsilon-greedy in place: action[i] becomes uniform in [0, 40) with probability epsilon."""
+        self._own(action, torch.uint8, "action")
         check(self._lib.tpl_explore_actions(self._h, _ptr(action), float(epsilon), int(seed), int(step), self._stream()))
         return action
 
@@ -264,6 +287,9 @@ class BatchedTetris:
         registers).  Returns the trajectory: actions/rewards/dones [steps, N] and, if asked, the 32-byte state of
         every board before each step as two int32 [steps, N, 4] tensors."""
         n, d = self.num_envs, self.device
+        self._image(image)
+        if steps < 1:
+            raise ValueError("steps must be positive")
         out = {}
         if record:
             out["actions"] = torch.empty((steps, n), dtype=torch.uint8, device=d)
@@ -293,8 +319,8 @@ class BatchedTetris:
     def expand_states(self, states_a: torch.Tensor, states_b: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
         """[K, 217] observations of K recorded 32-byte states (int32 [K, 4] pairs as actor_rollout(record_states=True)
         returns them, e.g. a replay-buffer minibatch)."""
-        a = states_a.reshape(-1, 4).contiguous()
-        b = states_b.reshape(-1, 4).contiguous()
+        a = states_a.to(self.device).reshape(-1, 4).contiguous()
+        b = states_b.to(self.device).reshape(-1, 4).contiguous()
         if a.shape != b.shape or a.dtype != torch.int32 or b.dtype != torch.int32:
             raise ValueError("states_a / states_b must be int32 [..., 4] tensors of equal shape")
         out = torch.empty((a.shape[0], OBS_DIM), dtype=dtype, device=self.device)
