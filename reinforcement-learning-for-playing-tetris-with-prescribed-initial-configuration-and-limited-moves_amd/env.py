@@ -123,6 +123,10 @@ class BatchedTetris:
         n_cfg = rows.shape[0]
         if rows.shape != (n_cfg, 20) or pieces.shape != (n_cfg, self.M + 1):
             raise ValueError(f"rows must be [n,20] and pieces [n,{self.M + 1}]; got {tuple(rows.shape)} {tuple(pieces.shape)}")
+        if n_cfg == 0:
+            raise ValueError("the pool needs at least one configuration")
+        if int(pieces.max()) > 6:                       # tetrominos[piece] of the reference raises IndexError here
+            raise ValueError("piece ids must be in 0..6 (I L J T S Z O)")
         nbytes = self._lib.tpl_pool_bytes(n_cfg, self.M)
         pool_mem = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         check(self._lib.tpl_load_configs(self._h, _ptr(rows), _ptr(pieces), n_cfg, _ptr(pool_mem), nbytes, self._stream()))
