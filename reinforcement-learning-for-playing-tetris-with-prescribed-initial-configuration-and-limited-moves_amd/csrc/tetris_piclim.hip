@@ -277,6 +277,11 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
         unpack_board(A, B, s);
         uint32_t cfg = current_config(s, p, (uint32_t)i);
         float rsum = 0.0f;
+        // The first action must have ARRIVED before the loop is entered.  Otherwise its register is "possibly still
+        // being loaded" at the loop header on one of the two ways in, and the compiler puts a full memory wait at
+        // the top of every iteration -- right behind the requests (next action, window word) that iteration has
+        // just issued to ride under the move.
+        asm volatile("" ::"v"(act));
         for (uint32_t k = 0; k < q.K; ++k) {
             // next step's action is independent of the board: fetch it under this step's move
             uint32_t act_next = 0;
