@@ -82,11 +82,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         const int64_t j = valid[k] ? i : p.n - 1;
         A[k] = p.plane_a[i];
         B[k] = p.plane_b[i];
-#ifdef TPL_X_NOACT
-        a0[k] = (uint32_t)((j * 2654435761u) >> 7) % 40u;
-#else
         a0[k] = load_int(p.act0, p.int_shift, j);
-#endif
         a1[k] = kActionForm ? 0u : load_int(p.act1, p.int_shift, j);
     }
     if (threadIdx.x < 32) s_shape[threadIdx.x] = kShapeTable[threadIdx.x];
