@@ -165,31 +165,28 @@ __device__ __forceinline__ uint32_t move_board(Board& s, const ShapeWord* shape,
     // right clamp only (:363-364)
     loc = min(loc, (uint32_t)kCols - w);
 
-    // the four board columns under the piece, c[loc .. loc+3], through a 4-stage blend network keyed on the
-    // bits of loc.  Written as mask blends (one v_bfi_b32 each) on purpose: a `cond ? c[k+1] : c[k]` form is
-    // turned back into a runtime-indexed array by the compiler and lands in scratch/LDS.
-    const uint32_t m0 = 0u - (loc & 1u), m1 = 0u - ((loc >> 1) & 1u), m2 = 0u - ((loc >> 2) & 1u),
-                   m3 = 0u - ((loc >> 3) & 1u);
-    uint32_t a[10], b[10], d[4];
+    // calculate_drop_deltas (:427-433).  The top of EVERY column (20 when empty, via a sentinel bit) is one
+    // v_ffbl each; the ten tops are packed a byte apiece into an 80-bit string, of which the piece needs the four
+    // bytes starting at byte `loc` -- a word select on loc>>2 and one v_alignbyte.  (Selecting the four column
+    // words themselves and then taking their tops costs a 23-blend network; and a `c[loc + k]` form is turned into
+    // a runtime-indexed array by the compiler and lands in scratch.)  Bytes past column 9 read 0 and belong to
+    // piece columns past its width, whose table bias of 64 keeps them out of the minimum.
+    uint32_t t[kCols];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) a[k] = blend(m0, s.c[k + 1], s.c[k]);
-    a[9] = s.c[9];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) b[k] = blend(m1, a[k + 2], a[k]);
-    b[8] = a[8]; b[9] = a[9];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) d[k] = blend(m2, b[k + 4], b[k]);
-    d[0] = blend(m3, b[8], d[0]);
-    d[1] = blend(m3, b[9], d[1]);
-
-    // calculate_drop_deltas (:427-433): top of each column (20 when empty, via a sentinel bit) minus the
-    // piece's reverse topography; columns past the width carry +64 and never win the min.
-    uint32_t best = 0xFFu;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t top = (uint32_t)__builtin_ctz(d[k] | (1u << kRows));
-        best = min(best, top + ((sh.y >> (8 * k)) & 0xFFu));
-    }
+    for (int k = 0; k < kCols; ++k) t[k] = (uint32_t)__builtin_ctz(s.c[k] | (1u << kRows));
+    uint32_t p0 = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
+    uint32_t p1 = t[4] | (t[5] << 8) | (t[6] << 16) | (t[7] << 24);
+    uint32_t p2 = t[8] | (t[9] << 8);
+    // keep the three words straight-line: left alone, the compiler sinks the tops of columns 0-3 into a divergent
+    // branch on loc < 4 (saving five instructions for some lanes, paying two exec-mask branches in every wave)
+    asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2));
+    const uint32_t word = loc >> 2;                               // loc <= 9 after the clamp
+    const uint32_t lo = word == 0u ? p0 : word == 1u ? p1 : p2;
+    const uint32_t hi = word == 0u ? p1 : word == 1u ? p2 : 0u;
+    const uint32_t tops = __builtin_amdgcn_alignbyte(hi, lo, loc & 3u);
+    // top - reverse_topography per piece column, as four byte sums (no carry: a top is at most 20, a bias at most 64)
+    const uint32_t sums = tops + sh.y;
+    const uint32_t best = min(min(sums & 0xFFu, (sums >> 8) & 0xFFu), min((sums >> 16) & 0xFFu, sums >> 24));
     // calculate_drop (:424-425): min(deltas) - 1, with the table's +3 bias removed
     const int drop = (int)best - 4;
 
