@@ -145,9 +145,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         n_clear[k] = move_board(s, s_shape, rot, loc, p.L, p.M, topout);
         s.window = refill[k] ? word[k] : (s.window >> 3);     // the falling piece is consumed even on a top-out
 
-        reward[k] = p.r_line * (float)n_clear[k];
-        if (s.state == ST_WON) reward[k] = reward[k] + p.r_win;
-        if (s.state >= ST_LOST_LIMIT) reward[k] = reward[k] + p.r_lose;
+        reward[k] = step_reward(p, n_clear[k], s.state);
         done[k] = s.state != ST_RUNNING;
         if (done[k]) {
             // adds of a constant collapse to one popcount per wave; the line sum is rarely non-zero

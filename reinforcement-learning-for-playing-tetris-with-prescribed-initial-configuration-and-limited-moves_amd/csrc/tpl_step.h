@@ -79,6 +79,16 @@ __device__ __forceinline__ void load_config(const uint8_t* pool, uint32_t stride
     B = make_uint4(pb.x, pb.y | ((episode >> 4) << 28), pb.z | (episode << 28), pb.w);
 }
 
+// reward = per_line * rows_cleared (+ win when the move wins) (+ lose when the move loses): one rounded multiply,
+// then at most one rounded add.  The round-to-nearest intrinsics keep the compiler from contracting the pair into an
+// FMA, whose single rounding differs from the CPU's two when per_line * 3 is not exact.
+__device__ __forceinline__ float step_reward(const StepArgs& p, uint32_t n_clear, uint32_t state) {
+    float reward = __fmul_rn(p.r_line, (float)n_clear);
+    if (state == ST_WON) reward = __fadd_rn(reward, p.r_win);
+    if (state >= ST_LOST_LIMIT) reward = __fadd_rn(reward, p.r_lose);
+    return reward;
+}
+
 // episodes a lane finished, accumulated in registers across the steps of one launch
 struct Tally { uint32_t episodes = 0, lines = 0, wins = 0, topouts = 0; };
 
@@ -105,9 +115,7 @@ __device__ __forceinline__ bool advance_board(Board& s, uint32_t& cfg, uint32_t 
     bool topout;
     const uint32_t n_clear = move_board(s, shape, rot, loc, p.L, p.M, topout);
     s.window = refill ? word : (s.window >> 3);
-    reward = p.r_line * (float)n_clear;
-    if (s.state == ST_WON) reward = reward + p.r_win;
-    if (s.state >= ST_LOST_LIMIT) reward = reward + p.r_lose;
+    reward = step_reward(p, n_clear, s.state);
     const bool done = s.state != ST_RUNNING;
     if (done) {
         tally.episodes += 1u;
