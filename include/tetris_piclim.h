@@ -114,7 +114,8 @@ int tpl_get_state(tpl_env* env, uint16_t* rows, uint8_t* cur, uint8_t* nxt, uint
                   uint8_t* moves, uint8_t* state, uint8_t* pieces_left, void* stream);
 
 /* Observation for Model(217, 14) (model/train.py:26): out [n][217] of `dtype`:
- * 200 cells row-major (y*10+x), one-hot current piece (7), one-hot next piece (7), L_rem, M_rem, terminal. */
+ * 200 cells row-major (y*10+x), one-hot current piece (7), one-hot next piece (7), L_rem, M_rem, terminal.
+ * Any `out` is accepted; a 16-byte aligned one is written with 16-byte stores (the fast path). */
 int tpl_expand_obs(tpl_env* env, void* out, int32_t dtype, void* stream);
 
 /* Policy head -> action for Model(217, 14) (model/train.py:26; the reference never decodes its 14 outputs):
