@@ -79,6 +79,36 @@ def measure_fused_rollout(torch, T, env, actions, first, K, chunk):
     return timed(torch, dev, run, 1) / (launches * chunk)
 
 
+def measure_strong_scaling(torch, T, dev, rank, world, L, M, total, seed, K, chunk, barrier, max_over_ranks):
+    """BASELINE configs[3]: ONE batch of `total` boards sharded by global board index over the ranks (fixed total
+    work).  Side figure only; `value` stays the weak-scaling job.  Reported both ways: one launch per step (where the
+    per-launch dispatch gap dominates a shard of 131,072 boards) and `chunk` steps per launch."""
+    shard = T.sharding.strong_shard(rank, world, total)
+    env = T.BatchedTetris(L, M, shard.boards, device=dev, seed=seed, global_offset=shard.global_offset,
+                          auto_reset=True, assign="hash")
+    rows, pieces = env.synthetic_configs(shard.boards, first=shard.global_offset)
+    env.load_configs(rows, pieces)
+    env.reset()
+    S = max(chunk, min(K, 500) // chunk * chunk)
+    actions = torch.empty((S, shard.boards), dtype=torch.uint8, device=dev)
+    for t in range(S):
+        env.synthetic_actions(t, out=actions[t])
+    reward = torch.empty(shard.boards, dtype=torch.float32, device=dev)
+    done = torch.empty(shard.boards, dtype=torch.uint8, device=dev)
+    for t in range(20):
+        env.step_into(actions[t % S], reward, done)
+    torch.cuda.synchronize(dev)
+    barrier()
+    step = iter(range(S))
+    ms_step = max_over_ranks(timed(torch, dev, lambda: env.step_into(actions[next(step)], reward, done), S))
+    barrier()
+    ms_fused = max_over_ranks(measure_fused_rollout(torch, T, env, actions, 0, S, chunk))
+    env.terminate()
+    return {"global_boards": total, "boards_per_gpu": shard.boards, "unit": "env-steps/s",
+            "one_launch_per_step": {"value": float(total) / (ms_step * 1e-3), "ms_per_step": ms_step},
+            "fused_rollout": {"value": float(total) / (ms_fused * 1e-3), "ms_per_step": ms_fused, "steps_per_launch": chunk}}
+
+
 def measure_carved_pool(torch, T, env, actions, reward, done, W, K, pool, seed):
     """SURVEY 8(d) "realism run": the same step loop on a pool of CARVED (solvable) configurations."""
     n, dev, S = env.num_envs, env.device, actions.shape[0]
@@ -237,6 +267,9 @@ def main():
         carved = measure_carved_pool(torch, T, env, actions, reward, done, W, K, args.carved_pool, args.seed)
     env.terminate()
     del actions
+    strong = None
+    if world > 1 and args.chunk > 0:
+        strong = measure_strong_scaling(torch, T, dev, rank, world, L, M, n, args.seed, K, args.chunk, barrier, max_over_ranks)
     actor = None
     if args.actor_boards > 0 and world == 1:
         actor = measure_actor_loop(torch, T, dev, L, M, args.actor_boards, args.seed)
@@ -273,6 +306,7 @@ def main():
                          "kernel": "step_kernel<action, auto_reset>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BOARD_STEP * n},
             "fused_rollout": fused,
+            "strong_scaling": strong,
             "carved_pool_run": carved,
             "actor_loop": actor,
             "mean_episodic_return": mean_return if episodes else None,
