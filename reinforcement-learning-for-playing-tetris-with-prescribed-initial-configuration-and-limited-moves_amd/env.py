@@ -51,6 +51,8 @@ class BatchedTetris:
         self._lib = _lib.lib()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.device = torch.device("cuda", idx)
+        self._index = idx
+        self._shape1 = torch.Size((self.num_envs,))
         self.seed, self.global_offset = int(seed), int(global_offset)
         nbytes = self._lib.tpl_workspace_bytes(self.num_envs, self.M)
         self._workspace = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
@@ -70,7 +72,8 @@ class BatchedTetris:
 
     # ------------------------------------------------------------------------------------------ plumbing
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        # the current stream of this device as a raw hipStream_t (an int; ctypes passes it as void*)
+        return torch._C._cuda_getCurrentRawStream(self._index)
 
     def _apply_options(self):
         mode = {"hash": _lib.TPL_ASSIGN_HASH, "sequential": _lib.TPL_ASSIGN_SEQUENTIAL}[self.assign]
@@ -206,10 +209,18 @@ class BatchedTetris:
 
     def step_into(self, action: torch.Tensor, reward: torch.Tensor, done: torch.Tensor) -> None:
         """step() writing into caller-owned buffers (uint8/int32/int64 action, f32 reward, uint8 done)."""
-        self._own(action, _INT_CODES, "action")
-        self._own(reward, torch.float32, "reward")
-        self._own(done, torch.uint8, "done")
-        check(self._lib.tpl_step(self._h, _ptr(action), _INT_CODES[action.dtype], _ptr(reward), _ptr(done), self._stream()))
+        code, dev, shape = _INT_CODES.get(action.dtype), self.device, self._shape1
+        # the hot call of a host-driven loop: the same checks as _own(), written flat (about a microsecond for all three)
+        if not (code is not None and reward.dtype is torch.float32 and done.dtype is torch.uint8
+                and action.shape == shape and reward.shape == shape and done.shape == shape
+                and action.device == dev and reward.device == dev and done.device == dev
+                and action.is_contiguous() and reward.is_contiguous() and done.is_contiguous()):
+            self._own(action, _INT_CODES, "action")
+            self._own(reward, torch.float32, "reward")
+            self._own(done, torch.uint8, "done")
+        rc = self._lib.tpl_step(self._h, action.data_ptr(), code, reward.data_ptr(), done.data_ptr(), self._stream())
+        if rc:
+            check(rc)
 
     def step(self, action, observe: bool = True, obs_dtype=torch.float32):
         """step(action) with action = rot*10 + loc.  Returns (obs [N,217] or None, reward, done, info)."""
