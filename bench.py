@@ -109,6 +109,36 @@ def measure_strong_scaling(torch, T, dev, rank, world, L, M, total, seed, K, chu
             "fused_rollout": {"value": float(total) / (ms_fused * 1e-3), "ms_per_step": ms_fused, "steps_per_launch": chunk}}
 
 
+def measure_config_supply(torch, T, dev, L, M, seed):
+    """rates of the prescribed-configuration suppliers (side figures).  Carving on the device
+    (one configuration per lane) and on the host cores produce the same configurations; the forward generator +
+    solver is host code."""
+    import numpy as np
+    env = T.BatchedTetris(L, M, 64, device=dev, seed=seed)
+    count = 1 << 18
+    env.carved_configs(4096)                                     # load the kernel
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    rows, _ = env.carved_configs(count)                           # returns after the status check (host sync)
+    dt_dev = time.perf_counter() - t0
+    host_count = 1 << 14
+    t0 = time.perf_counter()
+    hrows, _ = T.generate_configs(L, M, host_count, seed=seed)
+    dt_host = time.perf_counter() - t0
+    same = bool(np.array_equal(rows[:host_count].cpu().numpy().view(np.uint16), hrows))
+    env.terminate()
+    games = 4000
+    t0 = time.perf_counter()
+    fw = T.forward_generate(5, 20, np.arange(games))
+    dt_fw = time.perf_counter() - t0
+    return {"unit": "configurations/s", "L": L, "M": M,
+            "carve_device": {"value": count / dt_dev, "count": count},
+            "carve_host": {"value": host_count / dt_host, "count": host_count, "threads": T._lib.cpu_budget(),
+                           "equal_to_device_output": same},
+            "forward_generator_solver_host": {"value": games / dt_fw, "games": games, "L": 5, "M": 20,
+                                              "winnable_fraction": float(fw["winnable"].mean())}}
+
+
 def measure_carved_pool(torch, T, env, actions, reward, done, W, K, pool, seed):
     """SURVEY 8(d) "realism run": the same step loop on a pool of CARVED (solvable) configurations."""
     n, dev, S = env.num_envs, env.device, actions.shape[0]
@@ -274,6 +304,10 @@ def main():
     if args.actor_boards > 0 and world == 1:
         actor = measure_actor_loop(torch, T, dev, L, M, args.actor_boards, args.seed)
 
+    supply = None
+    if world == 1 and args.carved_pool > 0:
+        supply = measure_config_supply(torch, T, dev, L, M, args.seed)
+
     if rank == 0:
         achieved = ALGO_BYTES_PER_BOARD_STEP * n / (kernel_ms * 1e-3) / 1e9
         traffic = None
@@ -308,6 +342,7 @@ def main():
             "fused_rollout": fused,
             "strong_scaling": strong,
             "carved_pool_run": carved,
+            "config_supply": supply,
             "actor_loop": actor,
             "mean_episodic_return": mean_return if episodes else None,
             "episodes": episodes,
