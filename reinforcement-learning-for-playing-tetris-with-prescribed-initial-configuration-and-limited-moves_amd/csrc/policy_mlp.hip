@@ -135,24 +135,23 @@ __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, v), zero));
 }
 
-// weights -> LDS with every 16-byte piece of a thread in flight at once (20 per thread at 512 threads): a
-// load-store-load-store loop would pay the L2 latency once per piece
+// weights -> LDS by LDS-DMA (`global_load_lds_dwordx4`): one instruction of a wave moves 64 consecutive 16-byte
+// pieces from memory straight into LDS at a wave-uniform base.  No registers are held, so the whole image is in
+// flight at once (the register form -- load every piece of a thread, then store them -- measured 0.8 us slower on
+// the 35-us policy kernel).  Tried and dropped: starting layer 1 of the first tile while W2..W5 are still arriving
+// (two LDS arrays, a counted wait, a second barrier after layer 1) -- 1.5 us SLOWER.
 template <int kThreads>
 __device__ __forceinline__ void load_image(uint4* s_image, const uint4* image) {
+    typedef __attribute__((address_space(1))) const void global_ptr;
+    typedef __attribute__((address_space(3))) void lds_ptr;
     constexpr int kPieces = kImageBytes / 16;
-    constexpr int kPer = (kPieces + kThreads - 1) / kThreads;
-    uint4 v[kPer];
-#pragma unroll
-    for (int u = 0; u < kPer; ++u) {
-        const int i = u * kThreads + (int)threadIdx.x;
-        v[u] = image[i < kPieces ? i : kPieces - 1];
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    for (int chunk = wave; chunk * 64 < kPieces; chunk += kThreads / 64) {
+        const int i = chunk * 64 + lane;
+        if (i < kPieces)                                        // lane k of the instruction lands at base + 16 k
+            __builtin_amdgcn_global_load_lds((global_ptr*)(image + i), (lds_ptr*)(s_image + chunk * 64), 16, 0, 0);
     }
-#pragma unroll
-    for (int u = 0; u < kPer; ++u) {
-        const int i = u * kThreads + (int)threadIdx.x;
-        if (i < kPieces) s_image[i] = v[u];
-    }
-    __syncthreads();
+    __syncthreads();                                            // (its fence waits for the transfers)
 }
 
 // a board -> its cell bit vector in the internal order (bit 20x + y; extras as bits 200..213 and 216) and the two
@@ -310,25 +309,36 @@ __device__ __forceinline__ void both_features(const uint32_t (&own)[8], int g, u
 
 __global__ __launch_bounds__(512, 2) void policy_kernel(const PolicyArgs p) {
     __shared__ uint4 s_image[kImageBytes / 16];
-    load_image<512>(s_image, p.image);
     const uint8_t* lds = (const uint8_t*)s_image;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int64_t tiles = (p.n + 31) / 32;
+    const int64_t tile0 = (int64_t)blockIdx.x * 8 + wave, tile_step = (int64_t)gridDim.x * 8;
+    // the first tile's boards are requested ahead of the weights and arrive under their transfer
+    uint4 A, B;                                                   // the boards of the tile about to be computed
+    {
+        const int64_t b0 = tile0 * 32 + (g >> 1) * 16 + c;
+        const int64_t j = b0 < p.n ? b0 : p.n - 1;                // a lane past the end holds the last real board
+        A = p.plane_a[j];
+        B = p.plane_b[j];
+    }
+    load_image<512>(s_image, p.image);
 #ifdef TPL_DIAG_CLOCK
     // diagnostic build only (tools/policy_clock.py): shader-clock and 100 MHz real-time stamps around the tile loop
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < tiles; tile += (int64_t)gridDim.x * 8) {
+    for (int64_t tile = tile0; tile < tiles; tile += tile_step) {
         const int64_t b = tile * 32 + (g >> 1) * 16 + c;
         const bool valid = b < p.n;
         Board s;
-        if (valid) {
-            unpack_board(p.plane_a[b], p.plane_b[b], s);
-        } else {
-#pragma unroll
-            for (int k = 0; k < kCols; ++k) s.c[k] = 0;
-            s.window = 0x3FFFFFFFu; s.state = 0; s.lines = 0; s.moves = 0; s.episode = 0;
+        unpack_board(A, B, s);
+        // the next tile's boards are requested now and used a whole tile of matrix work later (no per-lane branch:
+        // the loads land in the registers the loop carries)
+        if (tile + tile_step < tiles) {
+            const int64_t bn = b + tile_step * 32;
+            const int64_t jn = bn < p.n ? bn : p.n - 1;
+            A = p.plane_a[jn];
+            B = p.plane_b[jn];
         }
         uint32_t own[8], fb[2][8];
         board_features(s, p.L, p.M, own);
