@@ -677,6 +677,43 @@ def test_ragged_batches_match_oracle_in_every_geometry(T, oracle, n):
             gpu.terminate()
 
 
+def test_randomised_sweep_of_sizes_rules_and_geometries(T, oracle):
+    """Thirty random draws of (L, M, batch, pool, assignment, auto-reset, reward, geometry, action dtype), each stepped
+    past several episode ends and compared with the oracle: rewards, dones, final state, statistics."""
+    import torch
+    rng = np.random.default_rng(2024)
+    for case in range(30):
+        L = int(rng.integers(1, 13))
+        M = int(rng.choice([1, 2, 5, 7, 8, 9, 16, 23, 40, 71, 72, 100]))
+        n = int(rng.choice([1, 17, 64, 100, 513, 3000]))
+        pool = int(rng.integers(1, 200))
+        assign = ["hash", "sequential"][int(rng.integers(0, 2))]
+        auto = bool(rng.integers(0, 2))
+        reward = tuple(float(x) for x in rng.choice([0.0, 0.1, 1.0, -0.3, 2.5], 3))
+        bpl, threads = int(rng.choice([1, 2, 4])), int(rng.choice([64, 128, 256, 512]))
+        dtype = [np.uint8, np.int32, np.int64][int(rng.integers(0, 3))]
+        seed, offset = int(rng.integers(0, 1 << 30)), int(rng.integers(0, 1 << 20))
+        tag = f"case {case}: L={L} M={M} n={n} pool={pool} {assign} auto={auto} reward={reward} bpl={bpl}x{threads} {dtype.__name__}"
+        gpu = T.BatchedTetris(L, M, n, seed=seed, global_offset=offset, auto_reset=auto, assign=assign, reward=reward)
+        gpu.set_tuning(bpl, threads)
+        rows, pieces = gpu.synthetic_configs(pool, seed=seed + 1)
+        gpu.load_configs(rows, pieces)
+        gpu.reset()
+        cpu = oracle.Env(n, L, M, offset, seed)
+        cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
+        cpu.set_options(auto_reset=auto, assign_mode=0 if assign == "hash" else 1, per_line=reward[0], win=reward[1], lose=reward[2])
+        cpu.reset()
+        for t in range(min(3 * M + 5, 60)):
+            a = rng.integers(0, 40, n).astype(np.uint8)
+            _, r_g, d_g, _ = gpu.step(torch.from_numpy(a.astype(dtype)), observe=False)
+            r_c, d_c = cpu.step(a)
+            assert np.array_equal(_np(r_g), r_c) and np.array_equal(_np(d_g).astype(np.uint8), d_c), (tag, t)
+        _assert_state_equal(_state(gpu), cpu.get_state(), tag)
+        assert gpu.stats() == cpu.stats(), tag
+        assert np.array_equal(_np(gpu.observe()), cpu.expand_obs()), tag
+        gpu.terminate()
+
+
 def test_ragged_sizes_and_errors(T):
     for n in (1, 63, 65, 257):
         env = T.BatchedTetris(4, 9, n, assign="sequential")
