@@ -703,15 +703,28 @@ def test_randomised_sweep_of_sizes_rules_and_geometries(T, oracle):
         cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
         cpu.set_options(auto_reset=auto, assign_mode=0 if assign == "hash" else 1, per_line=reward[0], win=reward[1], lose=reward[2])
         cpu.reset()
-        for t in range(min(3 * M + 5, 60)):
-            a = rng.integers(0, 40, n).astype(np.uint8)
-            _, r_g, d_g, _ = gpu.step(torch.from_numpy(a.astype(dtype)), observe=False)
-            r_c, d_c = cpu.step(a)
-            assert np.array_equal(_np(r_g), r_c) and np.array_equal(_np(d_g).astype(np.uint8), d_c), (tag, t)
+        twin = T.BatchedTetris(L, M, n, seed=seed, global_offset=offset, auto_reset=auto, assign=assign, reward=reward)
+        twin.load_configs(rows, pieces)                            # the same run through the fused K-step kernel
+        twin.reset()
+        steps = min(3 * M + 5, 60)
+        acts = rng.integers(0, 40, (steps, n)).astype(np.uint8)
+        rewards = np.zeros((steps, n), np.float32)
+        dones = np.zeros((steps, n), np.uint8)
+        for t in range(steps):
+            _, r_g, d_g, _ = gpu.step(torch.from_numpy(acts[t].astype(dtype)), observe=False)
+            rewards[t], dones[t] = cpu.step(acts[t])
+            assert np.array_equal(_np(r_g), rewards[t]) and np.array_equal(_np(d_g).astype(np.uint8), dones[t]), (tag, t)
         _assert_state_equal(_state(gpu), cpu.get_state(), tag)
         assert gpu.stats() == cpu.stats(), tag
         assert np.array_equal(_np(gpu.observe()), cpu.expand_obs()), tag
-        gpu.terminate()
+        cut = int(rng.integers(1, steps)) if steps > 1 else 1
+        dev_acts = torch.from_numpy(acts).to(twin.device)
+        parts = [twin.rollout(dev_acts[:cut], per_step=True)] + ([twin.rollout(dev_acts[cut:], per_step=True)] if cut < steps else [])
+        assert np.array_equal(np.concatenate([_np(q[2]) for q in parts]), rewards), tag
+        assert np.array_equal(np.concatenate([_np(q[3]).astype(np.uint8) for q in parts]), dones), tag
+        _assert_state_equal(_state(twin), cpu.get_state(), tag + " (rollout)")
+        assert twin.stats() == cpu.stats(), tag
+        gpu.terminate(); twin.terminate()
 
 
 def test_ragged_sizes_and_errors(T):
