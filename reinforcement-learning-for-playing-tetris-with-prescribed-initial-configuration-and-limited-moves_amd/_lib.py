@@ -62,7 +62,7 @@ def _source_digest() -> str:
     h = hashlib.sha256()
     for path in _SOURCES:
         with open(path, "rb") as f:
-            h.update(path.encode() + b"\0" + f.read())
+            h.update(os.path.relpath(path, _ROOT).encode() + b"\0" + f.read())   # relative: the tree may be copied
     return h.hexdigest()
 
 
