@@ -285,8 +285,9 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
             float reward;
             const bool done = advance_board<kAutoReset>(s, cfg, rot, loc, p, (uint32_t)i, s_shape, reward, tally);
             rsum = rsum + reward;
-            if (q.reward_steps) q.reward_steps[(size_t)k * p.n + i] = reward;
-            if (q.done_steps) q.done_steps[(size_t)k * p.n + i] = done ? 1 : 0;
+            // (non-temporal: a trajectory is written once and consumed later, by someone else)
+            if (q.reward_steps) __builtin_nontemporal_store(reward, q.reward_steps + (size_t)k * p.n + i);
+            if (q.done_steps) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), q.done_steps + (size_t)k * p.n + i);
             act = act_next;
         }
         pack_board(s, A, B);
