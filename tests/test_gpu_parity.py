@@ -578,7 +578,8 @@ def test_long_soak_against_the_oracle(T, oracle, L, M):
     """Two thousand lockstep steps with auto-reset from carved (solvable) configurations mixed with synthetic
     ones, alternating single steps and fused rollouts; compared with the oracle at the end and on the way."""
     import torch
-    n, seed, steps = 16384, 1000 + L, 2000
+    import os
+    n, seed, steps = 16384, 1000 + L, int(os.environ.get("TPL_SOAK_STEPS", "2000"))    # a one-off longer run: TPL_SOAK_STEPS=40000
     gen = min(L, 16)
     c_rows, c_pieces = T.generate_configs(gen, M, 1500, seed=seed) if M >= 2 * gen else (np.zeros((0, 20), np.uint16), np.zeros((0, M + 1), np.uint8))
     gpu = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True, reward=(0.5, 4.0, -0.25))
