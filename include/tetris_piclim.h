@@ -113,6 +113,10 @@ int tpl_rollout(tpl_env* env, const uint8_t* actions, int64_t action_stride, int
 int tpl_get_state(tpl_env* env, uint16_t* rows, uint8_t* cur, uint8_t* nxt, uint8_t* lines,
                   uint8_t* moves, uint8_t* state, uint8_t* pieces_left, void* stream);
 
+/* Replaces reading Tetris.board (game/tetris.py:186; the first element of get_state(), :435-436) for every board:
+ * cells [n][20][10] uint8, 0 / 1 (the storage of a bool array), row 0 = top.  `cells` must be 16-byte aligned. */
+int tpl_get_board(tpl_env* env, uint8_t* cells, void* stream);
+
 /* Observation for Model(217, 14) (model/train.py:26): out [n][217] of `dtype`:
  * 200 cells row-major (y*10+x), one-hot current piece (7), one-hot next piece (7), L_rem, M_rem, terminal.
  * Any `out` is accepted; a 16-byte aligned one is written with 16-byte stores (the fast path). */

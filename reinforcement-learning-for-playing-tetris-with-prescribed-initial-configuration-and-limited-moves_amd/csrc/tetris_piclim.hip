@@ -720,6 +720,14 @@ int tpl_get_state(tpl_env* e, uint16_t* rows, uint8_t* cur, uint8_t* nxt, uint8_
     return TPL_OK;
 }
 
+int tpl_get_board(tpl_env* e, uint8_t* cells, void* stream) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!cells) return fail_msg(TPL_ERR_ARG, "cells is null");
+    if (((uintptr_t)cells & 15u) != 0) return fail_msg(TPL_ERR_ARG, "cells must be 16-byte aligned");
+    DeviceGuard guard(e->device);
+    return launch_cells(e->plane_a, e->plane_b, e->n, cells, (hipStream_t)stream);
+}
+
 static int launch_expand(tpl_env* e, const uint4* plane_a, const uint4* plane_b, int64_t n, void* out, int32_t dtype,
                          hipStream_t stream) {
     if (dtype != TPL_F32 && dtype != TPL_BF16) return fail_msg(TPL_ERR_ARG, "unknown observation dtype %d", dtype);

@@ -54,6 +54,9 @@ bool observe_fast_path(const void* out);
 int launch_observe(const uint4* plane_a, const uint4* plane_b, int64_t n, uint32_t L, uint32_t M, void* out, int32_t dtype,
                    hipStream_t stream);
 
+// observe.hip: Tetris.board of every board as bytes [n][20][10] (needs a 16-byte aligned output)
+int launch_cells(const uint4* plane_a, const uint4* plane_b, int64_t n, uint8_t* out, hipStream_t stream);
+
 struct DeviceGuard {
     int prev = -1;
     bool ok = true;

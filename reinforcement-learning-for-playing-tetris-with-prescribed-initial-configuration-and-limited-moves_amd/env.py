@@ -355,11 +355,14 @@ class BatchedTetris:
     def get_state(self):
         """Batched Tetris.get_state() (game/tetris.py:435-436):
         (board bool[N,20,10], pieces[0], pieces[1], L - lines_cleared, M - moves_used, state)."""
-        s = self.packed_state()
-        rows = s["rows"].to(torch.int32) & 0xFFFF
-        board = ((rows.unsqueeze(-1) >> torch.arange(10, device=self.device, dtype=torch.int32)) & 1).to(torch.bool)
-        return (board, s["cur"], s["nxt"], self.L - s["lines"].to(torch.int32), self.M - s["moves"].to(torch.int32),
-                s["state"])
+        n, d = self.num_envs, self.device
+        cells = torch.empty((n, 20, 10), dtype=torch.uint8, device=d)
+        check(self._lib.tpl_get_board(self._h, _ptr(cells), self._stream()))
+        s = {k: torch.empty(n, dtype=torch.uint8, device=d) for k in ("cur", "nxt", "lines", "moves", "state")}
+        check(self._lib.tpl_get_state(self._h, None, _ptr(s["cur"]), _ptr(s["nxt"]), _ptr(s["lines"]), _ptr(s["moves"]),
+                                      _ptr(s["state"]), None, self._stream()))
+        return (cells.view(torch.bool), s["cur"], s["nxt"], self.L - s["lines"].to(torch.int32),
+                self.M - s["moves"].to(torch.int32), s["state"])
 
     lines_cleared = property(lambda self: self.packed_state()["lines"])
     moves_used = property(lambda self: self.packed_state()["moves"])

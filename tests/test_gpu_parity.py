@@ -480,6 +480,8 @@ def test_observation_on_dense_boards_frozen_wins_and_odd_sizes(T, oracle, n):
         assert np.array_equal(_np(gpu.observe(torch.bfloat16).float()), want), t
         unaligned = spare[1: 1 + n * 217].view(n, 217)             # 4 bytes off a 16-byte boundary
         assert np.array_equal(_np(gpu.observe(out=unaligned)), want), t
+        board = gpu.get_state()[0]                                 # Tetris.board, bool [n, 20, 10] (tpl_get_board)
+        assert board.dtype == torch.bool and np.array_equal(_np(board).reshape(n, 200), want[:, :200].astype(bool)), t
     if n >= 7:
         assert want[3, 214] < 0 and want[3, 216] == 1              # the overshoot really happened and is frozen
     gpu.terminate()
