@@ -364,9 +364,18 @@ class BatchedTetris:
         return (cells.view(torch.bool), s["cur"], s["nxt"], self.L - s["lines"].to(torch.int32),
                 self.M - s["moves"].to(torch.int32), s["state"])
 
-    lines_cleared = property(lambda self: self.packed_state()["lines"])
-    moves_used = property(lambda self: self.packed_state()["moves"])
-    state = property(lambda self: self.packed_state()["state"])
+    _FIELDS = ("rows", "cur", "nxt", "lines", "moves", "state", "pieces_left")
+
+    def _field(self, name: str) -> torch.Tensor:
+        """One array of packed_state() (the kernel skips the outputs it is not asked for)."""
+        out = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        ptrs = [_ptr(out) if k == name else None for k in self._FIELDS]
+        check(self._lib.tpl_get_state(self._h, *ptrs, self._stream()))
+        return out
+
+    lines_cleared = property(lambda self: self._field("lines"))
+    moves_used = property(lambda self: self._field("moves"))
+    state = property(lambda self: self._field("state"))
 
     def snapshot(self) -> torch.Tensor:
         """Copy of the whole resident state (boards, counters, windows, statistics)."""

@@ -731,13 +731,17 @@ def test_randomised_sweep_of_sizes_rules_and_geometries(T, oracle):
 
 
 def test_ragged_sizes_and_errors(T):
+    import torch
     for n in (1, 63, 65, 257):
         env = T.BatchedTetris(4, 9, n, assign="sequential")
         rows, pieces = env.synthetic_configs(7)
         env.load_configs(rows, pieces)
         env.reset()
         env.step(env.synthetic_actions(0))
-        assert env.packed_state()["moves"].shape[0] == n
+        s = env.packed_state()
+        assert s["moves"].shape[0] == n
+        # the reference's public attributes, batched: each is one field of packed_state()
+        assert torch.equal(env.lines_cleared, s["lines"]) and torch.equal(env.moves_used, s["moves"]) and torch.equal(env.state, s["state"])
         env.terminate()
     env = T.BatchedTetris(4, 9, 8)
     with pytest.raises(T.TplError):
