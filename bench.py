@@ -46,7 +46,10 @@ def cpu_baseline(L, M, seed):
         steps = int(max(40, min(20000, 5.0 * (done / sec) / boards)))
         done, sec = O.bench_run(seed, boards, L, M, steps, cores)
     return {"value": done / sec, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{boards} boards x {steps} lockstep steps, L={L} M={M}, auto-reset, {cores} threads, {sec:.1f}s"}
+            "sample": f"{boards} boards x {steps} lockstep steps, L={L} M={M}, auto-reset, {cores} threads, {sec:.1f}s",
+            "note": "the C port of the step; the Python reference itself (it cannot travel to this box) ran the same "
+                    "workload at 61-68 k moves/s per core in the build container, the port at 12-14 M: 175-235x per core "
+                    "(tests/golden/time_reference.py)"}
 
 
 def timed(torch, dev, fn, reps):
