@@ -307,13 +307,17 @@ __device__ __forceinline__ void both_features(const uint32_t (&own)[8], int g, u
     }
 }
 
-__global__ __launch_bounds__(512, 2) void policy_kernel(const PolicyArgs p) {
+// two waves per SIMD.  (Twelve waves -- three per SIMD, the kernel fits 168 registers -- measured 6 % slower; halving
+// the A-fragment LDS reads, as a timing experiment, gained 3 %: the kernel is bound by neither occupancy nor LDS
+// bandwidth but by the matrix pipe at the clock the chip holds.)
+constexpr int kPolicyWaves = 8;
+__global__ __launch_bounds__(64 * kPolicyWaves) void policy_kernel(const PolicyArgs p) {
     __shared__ uint4 s_image[kImageBytes / 16];
     const uint8_t* lds = (const uint8_t*)s_image;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int64_t tiles = (p.n + 31) / 32;
-    const int64_t tile0 = (int64_t)blockIdx.x * 8 + wave, tile_step = (int64_t)gridDim.x * 8;
+    const int64_t tile0 = (int64_t)blockIdx.x * kPolicyWaves + wave, tile_step = (int64_t)gridDim.x * kPolicyWaves;
     // the first tile's boards are requested ahead of the weights and arrive under their transfer
     uint4 A, B;                                                   // the boards of the tile about to be computed
     {
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void policy_kernel(const PolicyArgs p) {
         A = p.plane_a[j];
         B = p.plane_b[j];
     }
-    load_image<512>(s_image, p.image);
+    load_image<64 * kPolicyWaves>(s_image, p.image);
 #ifdef TPL_DIAG_CLOCK
     // diagnostic build only (tools/policy_clock.py): shader-clock and 100 MHz real-time stamps around the tile loop
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void policy_kernel(const PolicyArgs p) {
 #ifdef TPL_DIAG_CLOCK
     if (lane == 0 && p.diag) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long* d = p.diag + 2 * ((size_t)blockIdx.x * 8 + wave);
+        unsigned long long* d = p.diag + 2 * ((size_t)blockIdx.x * kPolicyWaves + wave);
         d[0] = t1 - t0;
         d[1] = r1 - r0;
     }
@@ -483,8 +487,8 @@ extern "C" int tpl_policy_act(tpl_env* e, const void* image, uint8_t* action, fl
     p.logits = nullptr;
 #endif
     // one resident workgroup per CU (the weights fill its LDS), eight waves of 32 boards, looping over board tiles
-    const int64_t groups = ((e->n + 31) / 32 + 7) / 8;
-    hipLaunchKernelGGL(policy_kernel, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(512), 0, (hipStream_t)stream, p);
+    const int64_t groups = ((e->n + 31) / 32 + kPolicyWaves - 1) / kPolicyWaves;
+    hipLaunchKernelGGL(policy_kernel, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(64 * kPolicyWaves), 0, (hipStream_t)stream, p);
     TPL_HIP(hipGetLastError());
     return TPL_OK;
 }
