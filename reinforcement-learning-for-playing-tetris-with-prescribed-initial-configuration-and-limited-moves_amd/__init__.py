@@ -11,7 +11,7 @@ from ._lib import (LIB_PATH, SYMBOLS, TplError, build_library, forward_generate,
                    shape_info)
 
 __all__ = ["BatchedTetris", "Tetris", "OBS_DIM", "NUM_ACTIONS", "RUNNING", "WON", "LOST", "TplError",
-           "build_library", "shape_info", "generate_configs", "forward_generate", "pack_policy", "LIB_PATH", "SYMBOLS"]
+           "RandomPieceGenerator", "build_library", "shape_info", "generate_configs", "forward_generate", "pack_policy", "LIB_PATH", "SYMBOLS"]
 
 
 def __getattr__(name):
@@ -24,6 +24,8 @@ def __getattr__(name):
         return getattr(importlib.import_module(__name__ + ".pool"), name)
     if name in ("sharding", "actor", "pool"):
         return importlib.import_module(__name__ + "." + name)
+    if name == "RandomPieceGenerator":
+        return getattr(importlib.import_module(__name__ + ".pieces"), name)
     if name in ("Actor", "PolicyMLP"):
         return getattr(importlib.import_module(__name__ + ".actor"), name)
     raise AttributeError(name)
