@@ -213,6 +213,13 @@ int tpl_forward_generate(int32_t L, int32_t M, int32_t initial_height_max, int32
                          int64_t count, int32_t threads, uint16_t* rows, uint8_t* sequence, uint8_t* winnable,
                          int32_t* failed_attempts, uint8_t* solution, uint8_t* solver_stack, int32_t* solution_len);
 
+/* Replaces Tetris.carve(piece, rotations, location, allow_partial) (game/tetris.py:286-352), the inverse of a move
+ * and the carving generator's building block, on ONE board in HOST memory: rows[20] is modified in place when the
+ * carve succeeds; *carved = 1 / 0.  (The reference does not clamp here: a location that puts the piece outside the
+ * board is an argument error.) */
+int tpl_carve(uint16_t* rows, int32_t piece, int32_t rotations, int32_t location, int32_t allow_partial,
+              int32_t* carved);
+
 /* Synthetic workload of SURVEY 8(d), generated on the device from a counter-based hash
  * keyed by (seed, stream, global board index, counter); DESIGN.md states the function. */
 int tpl_synth_configs(tpl_env* env, uint64_t seed, int64_t first, int64_t count,

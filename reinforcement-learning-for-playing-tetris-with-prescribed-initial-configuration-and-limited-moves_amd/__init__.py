@@ -7,11 +7,11 @@ The directory name is not a Python identifier; import it as `import tetris_picli
 root) or with importlib.import_module.
 """
 from . import _lib
-from ._lib import (LIB_PATH, SYMBOLS, TplError, build_library, forward_generate, generate_configs, pack_policy,
+from ._lib import (LIB_PATH, SYMBOLS, TplError, build_library, carve, forward_generate, generate_configs, pack_policy,
                    shape_info)
 
 __all__ = ["BatchedTetris", "Tetris", "OBS_DIM", "NUM_ACTIONS", "RUNNING", "WON", "LOST", "TplError",
-           "RandomPieceGenerator", "build_library", "shape_info", "generate_configs", "forward_generate", "pack_policy", "LIB_PATH", "SYMBOLS"]
+           "RandomPieceGenerator", "carve", "build_library", "shape_info", "generate_configs", "forward_generate", "pack_policy", "LIB_PATH", "SYMBOLS"]
 
 
 def __getattr__(name):

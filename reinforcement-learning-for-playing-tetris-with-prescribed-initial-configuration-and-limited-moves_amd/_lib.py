@@ -34,7 +34,7 @@ _SOURCES = _UNITS + [os.path.join(_CSRC, "tpl_device.h"), os.path.join(_CSRC, "t
 SYMBOLS = [
     "tpl_last_error", "tpl_version", "tpl_workspace_bytes", "tpl_pool_bytes", "tpl_create", "tpl_destroy",
     "tpl_set_options", "tpl_load_configs", "tpl_reset", "tpl_move", "tpl_step", "tpl_get_state",
-    "tpl_expand_obs", "tpl_expand_states", "tpl_get_board", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
+    "tpl_expand_obs", "tpl_expand_states", "tpl_get_board", "tpl_carve", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
     "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_decode_actions", "tpl_generate_configs", "tpl_generate_configs_pyseed", "tpl_forward_generate",
     "tpl_generate_configs_device_work_bytes", "tpl_generate_configs_device",
     "tpl_policy_image_bytes", "tpl_policy_pack", "tpl_policy_act",
@@ -148,6 +148,7 @@ def lib() -> C.CDLL:
     L.tpl_shape_info.argtypes = [i32, i32, C.POINTER(i32), C.POINTER(i32), vp, vp]
     L.tpl_state_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.tpl_get_board.argtypes = [vp, vp, vp]
+    L.tpl_carve.argtypes = [vp, i32, i32, i32, i32, C.POINTER(i32)]
     L.tpl_set_tuning.argtypes = [vp, i32, i32]
     L.tpl_generate_configs.argtypes = [i32, i32, u64, i64, i64, i32, i64, vp, vp, vp, vp]
     L.tpl_generate_configs_pyseed.argtypes = [i32, i32, vp, i64, i32, i64, vp, vp, vp, vp]
@@ -181,6 +182,16 @@ def cpu_budget() -> int:
     except (OSError, ValueError):
         pass
     return max(1, n)
+
+
+def carve(rows, piece: int, rotations: int, location: int, allow_partial: bool):
+    """Tetris.carve (game/tetris.py:286-352) on one board given as uint16 rows[20] (host); returns (ok, rows_after)."""
+    import numpy as np
+    r = np.ascontiguousarray(rows, dtype=np.uint16).copy()
+    ok = C.c_int32(0)
+    check(lib().tpl_carve(r.ctypes.data_as(C.c_void_p), int(piece), int(rotations), int(location), int(bool(allow_partial)),
+                          C.byref(ok)))
+    return bool(ok.value), r
 
 
 def generate_configs(L: int, M: int, count: int = 0, seed: int = 0, first: int = 0, threads: int = 0,

@@ -213,3 +213,26 @@ extern "C" int tpl_generate_configs_pyseed(int32_t L, int32_t M, const uint64_t*
     return run_generator(L, M, count, threads, max_iters, rows, pieces, solution, solution_len,
                          [=](int64_t k) { return tpl::PyRandom(seeds[k]); });
 }
+
+// Tetris.carve(piece, rotations, location, allow_partial) (:286-311) on one board in the interchange layout (HOST
+// memory, modified in place when the carve succeeds): the inverse of a move, the generator's building block.
+extern "C" int tpl_carve(uint16_t* rows, int32_t piece, int32_t rotations, int32_t location, int32_t allow_partial,
+                         int32_t* carved) {
+    using namespace tpl;
+    if (!rows || !carved) return fail_msg(TPL_ERR_ARG, "rows/carved is null");
+    if (piece < 0 || piece > 6 || rotations < 0) return fail_msg(TPL_ERR_ARG, "piece %d / rotations %d out of range", piece, rotations);
+    const int w = (int)((kShapeTableHost[piece * 4 + (rotations & 3)].x >> 16) & 7u);
+    if (location < 0 || location + w > kCols) return fail_msg(TPL_ERR_ARG, "location %d puts the piece outside the board", location);
+    uint32_t col[kCols] = {0};
+    for (int r = 0; r < kRows; ++r)
+        for (int x = 0; x < kCols; ++x) col[x] |= (uint32_t)((rows[r] >> x) & 1u) << r;
+    const bool ok = carve(col, piece, rotations, location, allow_partial != 0);
+    if (ok)
+        for (int r = 0; r < kRows; ++r) {
+            uint32_t v = 0;
+            for (int x = 0; x < kCols; ++x) v |= ((col[x] >> r) & 1u) << x;
+            rows[r] = (uint16_t)v;
+        }
+    *carved = ok ? 1 : 0;
+    return TPL_OK;
+}

@@ -444,6 +444,7 @@ class Tetris:
         self._pieces_host = np.asarray(pieces, dtype=np.uint8).reshape(-1, M + 1)
         self._env = BatchedTetris(L, M, 1, device=device, assign="sequential", config_pool=(rows, self._pieces_host))
         self._episode = 0
+        self._board = None
         self._env.reset()
 
     def _config(self) -> int:
@@ -457,18 +458,34 @@ class Tetris:
 
     def move(self, rotations: int, location: int) -> None:
         self._env.move(torch.tensor([rotations], dtype=torch.int64), torch.tensor([location], dtype=torch.int64))
+        self._board = None
 
     def reset(self) -> None:
         self._episode += 1
         self._env.reset(mask=[1])
+        self._board = None
 
     def _s(self):
         return {k: v.cpu().numpy() for k, v in self._env.packed_state().items()}
 
     @property
     def board(self) -> np.ndarray:
-        rows = self._s()["rows"][0].view(np.uint16)
-        return ((rows[:, None] >> np.arange(10)) & 1).astype(bool)
+        """The 20x10 bool array, as in the reference a LIVE object: the same array is returned until the next move()
+        or reset(), carve() works on it, and writes to it are seen by carve() (not by move(): the board the moves
+        are played on lives on the device)."""
+        if self._board is None:
+            rows = self._s()["rows"][0].view(np.uint16)
+            self._board = ((rows[:, None] >> np.arange(10)) & 1).astype(bool)
+        return self._board
+
+    def carve(self, piece: int, rotations: int, location: int, allow_partial: bool) -> bool:
+        """Tetris.carve (game/tetris.py:286-352): removes the piece from where move() would have put it, on `board`."""
+        board = self.board
+        rows = (board.astype(np.uint16) << np.arange(10, dtype=np.uint16)).sum(1).astype(np.uint16)
+        ok, after = _lib.carve(rows, piece, rotations, location, allow_partial)
+        if ok:
+            board[:] = ((after[:, None] >> np.arange(10)) & 1).astype(bool)
+        return ok
 
     @property
     def pieces(self) -> list:
@@ -485,4 +502,5 @@ class Tetris:
                 self.M - int(s["moves"][0]), self._STATE[int(s["state"][0])])
 
     def terminate(self) -> None:
+        _ = self.board                     # the reference's attributes stay readable after terminate()
         self._env.terminate()

@@ -140,6 +140,27 @@ def test_pool_file_round_trip(tmp_path):
         T.save_pool(path, 5, 21, rows, pieces)
 
 
+def test_native_carve_equals_the_oracle_carve(oracle):
+    """tpl_carve (the product's Tetris.carve) against the oracle's on random boards, pieces, rotations, columns."""
+    import tetris_piclim as T
+    rng = np.random.default_rng(77)
+    carved = 0
+    for _ in range(4000):
+        rows = rng.integers(0, 1 << 10, 20).astype(np.uint16)
+        rows[: int(rng.integers(0, 16))] = 0
+        piece, rot = int(rng.integers(0, 7)), int(rng.integers(0, 6))
+        _, w, _, _ = T.shape_info(piece, rot)
+        loc = int(rng.integers(0, 10 - w + 1))
+        partial = bool(rng.integers(0, 2))
+        ok_o, after_o = oracle.carve(rows, piece, rot, loc, partial)
+        ok_p, after_p = T.carve(rows, piece, rot, loc, partial)
+        assert ok_o == ok_p and np.array_equal(after_o, after_p)
+        carved += ok_p
+    assert 200 < carved < 3800
+    with pytest.raises(T.TplError):
+        T.carve(np.zeros(20, np.uint16), 0, 0, 8, False)          # a flat I at column 8 sticks out of the board
+
+
 def test_native_generator_argument_errors():
     import tetris_piclim as T
     with pytest.raises(T.TplError):

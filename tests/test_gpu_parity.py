@@ -80,6 +80,29 @@ def test_reference_test_carving_invertability_verbatim(T):
     game.terminate()
 
 
+def test_reference_test_carving_repeatability_verbatim(T):
+    """The reference's own TestTetris.test_carving_repeatability (game/main.py:32-47): carving a full stack with a
+    game's solution, last piece first, rebuilds that game's board.  `tetris.Tetris` swapped, nothing else changed
+    (self.assertTrue -> assert)."""
+    tetris = T
+    L, M = 15, 40
+    game = tetris.Tetris(L, M, warm_reset=False, debug=True)
+
+    comparative_game = tetris.Tetris(L, M, warm_reset=False, debug=True)
+    comparative_game.board[-L:, :] = True
+
+
+    for i in range(len(game.solution) - 1, -1, -1):
+        piece = game.pieces[i]
+        rotations, location = game.solution[i]
+        assert comparative_game.carve(piece, rotations, location, i==(len(game.solution) - 1)), 'Carving with solution failed'
+
+    game.terminate()
+
+    assert np.array_equal(game.board, comparative_game.board), 'Carving repeat failed'
+    comparative_game.terminate()
+
+
 # ------------------------------------------------------------------------------------------------- F2
 @pytest.mark.parametrize("name", ["carved_L5_M20.npz", "carved_L10_M40.npz"])
 def test_f2_carved_solutions_win(T, name):
