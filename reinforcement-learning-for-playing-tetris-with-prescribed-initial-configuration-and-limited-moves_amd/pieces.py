@@ -11,6 +11,19 @@ from __future__ import annotations
 import random
 from typing import List, Tuple
 
+# letter -> piece id of Tetris.move (game/tetris.py:8-16)
+piece_translations = {"I": 0, "L": 1, "J": 2, "T": 3, "S": 4, "Z": 5, "O": 6}
+
+
+def get_tetromino(piece: int, rotations: int):
+    """The reference's get_tetromino (game/tetris.py:60-61): (mask, reverse_topography) of `piece` after `rotations`
+    quarter turns -- a bool array [h, w] and a tuple of w ints -- decoded from the table the device kernels use."""
+    import numpy as np
+    from ._lib import shape_info
+    h, w, masks, topo = shape_info(piece, rotations)
+    mask = np.array([[(m >> x) & 1 for x in range(w)] for m in masks], dtype=bool)
+    return mask, tuple(int(t) for t in topo)
+
 
 class RandomPieceGenerator:
     def __init__(self, rng=None) -> None:

@@ -49,6 +49,10 @@ def test_device_shape_table_matches_reference_table():
             assert masks == f["mask"][p, rr, :h].tolist() and topo == f["revtopo"][p, rr, :w].tolist()
     with pytest.raises(T.TplError):
         T.shape_info(7, 0)
+    # the reference's module-level accessor, same table
+    mask, topo = T.get_tetromino(1, 5)                       # L after 5 quarter turns = after 1
+    assert mask.dtype == bool and mask.shape == (3, 2) and mask.tolist() == [[True, True], [False, True], [False, True]]
+    assert topo == (0, 2) and T.piece_translations["T"] == 3
 
 
 def test_sizes_and_argument_errors_without_gpu():
