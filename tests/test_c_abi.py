@@ -63,3 +63,24 @@ def test_standalone_c_program_reproduces_the_oracle(tmp_path):
     assert [int(x) for x in out["stats"].split()] == [s["episodes"], s["lines"], s["wins"], s["topouts"]]
     got = out["reward_sum"].split()
     assert float(got[0]) == round(reward_sum, 1) and int(got[2]) == done_count
+
+
+def test_host_generators_under_address_and_ub_sanitizers(tmp_path):
+    """The host code of the library (carving generator, CPython random stream, forward generator + solver, tpl_carve)
+    compiled host-only with -fsanitize=address,undefined and driven by tests/c_abi/sanitize_host.cpp: every
+    configuration it generates is also carved back from a full stack with its own solution.  (Device code cannot
+    run under a sanitizer on this pool; the host side can, on the CPU.)"""
+    import tetris_piclim as T
+    csrc = os.path.dirname(T._lib.LIB_PATH)
+    flags = ["-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I", os.path.join(ROOT, "include")]
+    objs = []
+    for unit in ("carve_generator.hip", "forward_generator.hip"):
+        obj = str(tmp_path / (unit + ".o"))
+        _compile(["hipcc", "--cuda-host-only"] + flags + ["-c", os.path.join(csrc, unit), "-o", obj])
+        objs.append(obj)
+    exe = str(tmp_path / "sanitize_host")
+    _compile(["/opt/rocm/lib/llvm/bin/clang++"] + flags + [os.path.join(ROOT, "tests", "c_abi", "sanitize_host.cpp")] + objs +
+             ["-o", exe, "-lpthread"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0 and "sanitizer run ok" in res.stdout, res.stdout + res.stderr
