@@ -10,16 +10,32 @@ boards from the device pool) over one batch of synthetic actions.  Workload = BA
 all resident in HBM before the timed region.  N > 1 shards boards by global index, one process per GPU, no
 data-path collective; one RCCL all-reduce of the episodic-return counters closes the timed region.
 
+`python bench.py --gpus N` with N > 1 and no RANK in the environment starts the N ranks itself (a child
+`python -m torch.distributed.run`, spawned before anything touches the GPU) and exits with the child's status.
+
+Timing: `value` and `ms_per_step` come from a HIP-event pair on the launch stream around EXACTLY K step
+launches (max over ranks), the region bracketed by barrier + synchronize on both sides; the job's one collective (the
+all-reduce of the return counters) closes the region and is reported apart as `collective_ms`, the host's wall clock
+over region + collective as `wall_ms_per_step`.  A third event after the first launch separates what the first
+launch after a synchronize costs (the queue has run dry: the GPU wakes up) from the launch period of the other K-1,
+which is `roofline.kernel_ms`; `roofline.sustained` is the same loop over 2000 launches right after.
+
 Prints ONE JSON line (rank 0).  `roofline` prices the step kernel against HBM with the canonical
 96 B/board-step of SURVEY 8(d); `cpu_baseline` is the CPU oracle (a scalar C port of the reference's move)
-timed on this box's host cores over a bounded sample of the same workload.  Side figures that never enter
-`value`: `fused_rollout` (tpl_rollout), `carved_pool_run` (the step loop on carved configurations),
-`actor_loop` (BASELINE configs[4]: 262,144 boards driven by the 217-128-128-128-128-14 policy).
+timed on this box's host cores over a bounded sample of the same workload, with the NumPy per-board restatement
+(the reference's own operation sequence) beside it.  Side figures that never enter `value`: `fused_rollout`
+(tpl_rollout), `carved_pool_run` (the step loop on carved configurations), `config1_run` (BASELINE configs[1]:
+65,536 boards, L=5, M=20), `actor_loop` (BASELINE configs[4]: 262,144 boards driven by the 217-128-128-128-128-14
+policy).  The side figures that own their boards run BEFORE the timed region (the chip is then in the power state of
+a running job, not of a process that has just finished importing torch).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -31,7 +47,25 @@ HBM_PEAK_GBS = 8000.0                   # MI355X HBM3E peak (MI355X_MICROARCH.md
 MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(L, M, seed):
+def numpy_port_leg(L, M, seed, cores, seconds=3.0):
+    """the NumPy per-board restatement of the reference's move (oracle/numpy_port.py: the reference's
+    own operation sequence, so its rate on a core is the reference's rate on that core), one process per host core.
+    Started BEFORE this process touches the GPU (a process that has initialised HIP must not exec another)."""
+    cmd = [sys.executable, "-m", "oracle.numpy_port", str(seed), "256", str(L), str(M), str(seconds)]
+    procs = [subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, text=True) for _ in range(cores)]
+    rates = []
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        if p.returncode == 0:
+            rates.append(json.loads(out.strip().splitlines()[-1])["moves_per_s"])
+    if len(rates) != cores:
+        return None
+    return {"value": sum(rates), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "per_core": sum(rates) / cores,
+            "sample": f"{cores} processes x {seconds:.0f} s of move-and-reset over 256 synthetic configurations, L={L} M={M}"}
+
+
+def cpu_baseline(L, M, seed, numpy_leg):
     """The oracle's loop (game/performance_test.py:13-17 shape: move, reset when finished) on the host cores."""
     from oracle import oracle as O
     import tetris_piclim as T
@@ -45,11 +79,21 @@ def cpu_baseline(L, M, seed):
             break
         steps = int(max(40, min(20000, 5.0 * (done / sec) / boards)))
         done, sec = O.bench_run(seed, boards, L, M, steps, cores)
-    return {"value": done / sec, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{boards} boards x {steps} lockstep steps, L={L} M={M}, auto-reset, {cores} threads, {sec:.1f}s",
-            "note": "the C port of the step; the Python reference itself (it cannot travel to this box) ran the same "
-                    "workload at 61-68 k moves/s per core in the build container, the port at 12-14 M: 175-235x per core "
-                    "(tests/golden/time_reference.py)"}
+    out = {"value": done / sec, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{boards} boards x {steps} lockstep steps, L={L} M={M}, auto-reset, {cores} threads, {sec:.1f}s",
+           "numpy_port": numpy_leg}
+    if numpy_leg:
+        out["c_port_over_numpy_port_per_core"] = (done / sec / cores) / numpy_leg["per_core"]
+    try:
+        # the Python reference itself cannot travel to this box; its rate beside both restatements was measured in
+        # the build container (tests/golden/time_reference.py), one core each, same workload
+        ref = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_timing.json")))
+        out["reference_in_build_container"] = {k: ref[k] for k in (
+            "reference_moves_per_s", "numpy_port_moves_per_s", "c_port_env_steps_per_s", "c_port_over_reference",
+            "numpy_port_over_reference")}
+    except (OSError, KeyError, ValueError):
+        pass
+    return out
 
 
 def timed(torch, dev, fn, reps):
@@ -199,6 +243,50 @@ def measure_actor_loop(torch, T, dev, L, M, boards, seed):
     return out
 
 
+def measure_config1(torch, T, dev, seed, chunk):
+    """BASELINE configs[1]: 65,536 boards, random prescribed initial configurations, L=5, M=20, one GPU.  Side figure
+    with its own roofline: a launch this small is bound by the dispatch period of dependent launches, not by HBM."""
+    n, L, M, K = 65536, 5, 20, 400
+    env = T.BatchedTetris(L, M, n, device=dev, seed=seed, auto_reset=True, assign="hash")
+    rows, pieces = env.synthetic_configs(n)
+    env.load_configs(rows, pieces)
+    env.reset()
+    actions = torch.empty((K, n), dtype=torch.uint8, device=dev)
+    for t in range(K):
+        env.synthetic_actions(t, out=actions[t])
+    reward = torch.empty(n, dtype=torch.float32, device=dev)
+    done = torch.empty(n, dtype=torch.uint8, device=dev)
+    for t in range(50):
+        env.step_into(actions[t], reward, done)
+    torch.cuda.synchronize(dev)
+    step = iter(range(K))
+    ms = timed(torch, dev, lambda: env.step_into(actions[next(step)], reward, done), K)
+    out = {"workload": f"{n} boards, random initial configs, L={L} M={M}, auto-reset, uniform actions", "unit": "env-steps/s",
+           "value": float(n) / (ms * 1e-3), "ms_per_step": ms,
+           "roofline": {"bound": "hbm", "achieved": ALGO_BYTES_PER_BOARD_STEP * n / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": ALGO_BYTES_PER_BOARD_STEP * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "kernel": "step_kernel<action, auto_reset>", "kernel_ms": ms}}
+    if chunk > 0:
+        ms_f = measure_fused_rollout(torch, T, env, actions, 0, K // chunk * chunk, chunk)
+        out["fused_rollout"] = {"value": float(n) / (ms_f * 1e-3), "ms_per_step": ms_f, "steps_per_launch": chunk}
+    env.terminate()
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks as a CHILD process -- this process has not
+    imported torch or touched the GPU, and it never execs -- and hand back the child's exit status."""
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = str(sock.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,15 +301,31 @@ def main():
     ap.add_argument("--actor-boards", type=int, default=262144, help="boards of the config-5 actor-loop side measurement (0 = skip)")
     ap.add_argument("--carved-pool", type=int, default=65536, help="size of the carved pool of the realism run (0 = skip)")
     ap.add_argument("--chunk", type=int, default=50, help="steps per launch of the fused-rollout side measurement (0 = skip)")
+    ap.add_argument("--sustained", type=int, default=2000, help="launches of the sustained pass after the timed region (0 = skip)")
+    ap.add_argument("--no-config1", action="store_true", help="skip the BASELINE configs[1] side line")
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
+        ap.error("--gpus and --steps must be positive, --warmup non-negative")
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` or under "
+                 f"torch.distributed.run with --nproc-per-node equal to --gpus")
+
+    # the NumPy leg of the CPU baseline runs in child processes, so it goes first: nothing here has touched the GPU yet
+    numpy_leg = None
+    if world == 1 and not args.no_cpu_baseline:
+        import tetris_piclim as T0
+        numpy_leg = numpy_port_leg(args.L, args.M, args.seed, T0._lib.cpu_budget())
 
     import torch
     import torch.distributed as dist
     import tetris_piclim as T
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     # TPL_BENCH_BACKEND=gloo and TPL_BENCH_ONE_GPU=1 exist only to rehearse the multi-rank path on a one-GPU box
     backend = os.environ.get("TPL_BENCH_BACKEND", "nccl")
     if os.environ.get("TPL_BENCH_ONE_GPU") == "1":
@@ -236,6 +340,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    ranks_seen = dist.get_world_size() if world > 1 else 1
 
     def barrier():
         if world > 1:
@@ -247,7 +352,28 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def every_rank(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if world == 1:
+            return [float(x)]
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        return [float(g.item()) for g in got]
+
     n, L, M, K, W = args.boards, args.L, args.M, args.steps, args.warmup
+
+    # ---- side figures that own their boards (never part of `value`) run first
+    actor = supply = config1 = strong = None
+    if world == 1:
+        if args.actor_boards > 0:
+            actor = measure_actor_loop(torch, T, dev, L, M, args.actor_boards, args.seed)
+        if args.carved_pool > 0:
+            supply = measure_config_supply(torch, T, dev, L, M, args.seed)
+        if not args.no_config1:
+            config1 = measure_config1(torch, T, dev, args.seed, args.chunk)
+    elif args.chunk > 0:
+        strong = measure_strong_scaling(torch, T, dev, rank, world, L, M, n, args.seed, K, args.chunk, barrier, max_over_ranks)
+
     pool = args.pool or n
     shard = T.sharding.weak_shard(rank, world, n)               # batch-index sharding: contiguous blocks
     env = T.BatchedTetris(L, M, n, device=dev, seed=args.seed, global_offset=shard.global_offset, auto_reset=True,
@@ -258,7 +384,7 @@ def main():
     env.reset()
     # synthetic actions for every step, staged in HBM before timing (at most 4096 distinct steps = 4 GiB at 2^20
     # boards; a longer run cycles through them)
-    S = min(W + K, 4096)
+    S = min(max(W + K, 64), 4096)
     actions = torch.empty((S, n), dtype=torch.uint8, device=dev)
     for t in range(S):
         env.synthetic_actions(t, out=actions[t])
@@ -274,25 +400,53 @@ def main():
     barrier()
     torch.cuda.synchronize(dev)
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev_a, ev_b, ev_c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     t0 = time.perf_counter()
-    ev0.record()
-    for t in range(W, W + K):
+    ev_a.record()                                                 # same stream as the kernel launches
+    env.step_into(actions[W % S], reward, done)
+    ev_b.record()                                                 # (one marker inside the region: it sits in `value`)
+    for t in range(W + 1, W + K):
         env.step_into(actions[t % S], reward, done)
-    ev1.record()                                                  # same stream as the kernel launches
+    ev_c.record()
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
     # the one collective of the job: RCCL all-reduce (sum) of [return sum, episodes] over xGMI
     mean_return, episodes = T.sharding.mean_episodic_return(env.stats_tensor(), env.reward_params)
-    torch.cuda.synchronize(dev)
+    t2 = time.perf_counter()
     barrier()
     torch.cuda.synchronize(dev)
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-    kernel_ms = ev0.elapsed_time(ev1) / K                         # average launch-to-launch duration of the step kernel
+    t3 = time.perf_counter()
+    region_ms_rank = ev_a.elapsed_time(ev_c)
+    per_rank_ms = every_rank(region_ms_rank / K)
+    region_ms = max(per_rank_ms) * K                              # max over ranks
+    first_ms = max_over_ranks(ev_a.elapsed_time(ev_b))
+    steady_ms = max_over_ranks(ev_b.elapsed_time(ev_c) / (K - 1)) if K > 1 else first_ms
+    wall_ms = max_over_ranks((t3 - t0) * 1e3)
+    collective_ms = max_over_ranks((t2 - t1) * 1e3)
 
-    # ---- side figures (not part of `value`)
+    # ---- the same loop, sustained: `--sustained` launches with an event every 50, right after the timed region
+    sustained = None
+    if args.sustained >= 100:
+        groups = args.sustained // 50
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(groups + 1)]
+        evs[0].record()
+        for g in range(groups):
+            for t in range(50):
+                env.step_into(actions[(g * 50 + t) % S], reward, done)
+            evs[g + 1].record()
+        torch.cuda.synchronize(dev)
+        per = [evs[g].elapsed_time(evs[g + 1]) / 50 for g in range(groups)]
+        sustained = {"launches": groups * 50, "kernel_ms_mean": max_over_ranks(evs[0].elapsed_time(evs[-1]) / (groups * 50)),
+                     "kernel_ms_median_of_50s": statistics.median(per), "kernel_ms_min_of_50s": min(per),
+                     "kernel_ms_max_of_50s": max(per)}
+        sustained["value"] = float(n) * world / (sustained["kernel_ms_mean"] * 1e-3)
+        sustained["frac"] = ALGO_BYTES_PER_BOARD_STEP * n / (sustained["kernel_ms_median_of_50s"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+
+    # ---- side figures on the main boards (after the timed region)
     fused = None
-    if args.chunk > 0 and K >= args.chunk and W + K <= S:
+    if args.chunk > 0 and S >= args.chunk:
         barrier()
-        ms = max_over_ranks(measure_fused_rollout(torch, T, env, actions, W, K, args.chunk))
+        ms = max_over_ranks(measure_fused_rollout(torch, T, env, actions, 0, S // args.chunk * args.chunk, args.chunk))
         fused = {"value": float(n) * world / (ms * 1e-3), "unit": "env-steps/s", "steps_per_launch": args.chunk,
                  "ms_per_step": ms, "outputs": "per-step reward f32 + done u8 written", "kernel": "rollout_kernel<auto_reset>"}
     carved = None
@@ -300,19 +454,9 @@ def main():
         carved = measure_carved_pool(torch, T, env, actions, reward, done, W, K, args.carved_pool, args.seed)
     env.terminate()
     del actions
-    strong = None
-    if world > 1 and args.chunk > 0:
-        strong = measure_strong_scaling(torch, T, dev, rank, world, L, M, n, args.seed, K, args.chunk, barrier, max_over_ranks)
-    actor = None
-    if args.actor_boards > 0 and world == 1:
-        actor = measure_actor_loop(torch, T, dev, L, M, args.actor_boards, args.seed)
-
-    supply = None
-    if world == 1 and args.carved_pool > 0:
-        supply = measure_config_supply(torch, T, dev, L, M, args.seed)
 
     if rank == 0:
-        achieved = ALGO_BYTES_PER_BOARD_STEP * n / (kernel_ms * 1e-3) / 1e9
+        achieved = ALGO_BYTES_PER_BOARD_STEP * n / (steady_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -323,12 +467,12 @@ def main():
                 traffic = None
         out = {
             "metric": "env-steps/sec (whole node) at 1M parallel 20x10 boards",
-            "value": float(n) * world * K / elapsed,
+            "value": float(n) * world * K / (region_ms * 1e-3),
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
-            "ms_per_step": elapsed / K * 1e3,
+            "ms_per_step": region_ms / K,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -338,20 +482,32 @@ def main():
                                    f"uniform random actions, auto-reset from a {pool}-entry device pool "
                                    "(BASELINE configs[2])",
                        "boards_per_gpu": n, "L": L, "M": M, "parallelism": f"batch-shard x{world}"},
+            "timing": {"clock": "HIP events on the launch stream around the K launches, max over ranks",
+                       "per_rank_ms_per_step": per_rank_ms, "wall_ms_per_step": wall_ms / K, "collective_ms": collective_ms,
+                       "first_launch_ms": first_ms, "other_launches_ms": steady_ms,
+                       "note": "the first launch after a synchronize finds an empty queue and pays the GPU's wake-up; "
+                               "the other K-1 run back to back"},
+            "ranks_seen": ranks_seen,
+            "backend": (backend if world > 1 else None),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "step_kernel<action, auto_reset>", "kernel_ms": kernel_ms,
+                         "kernel": "step_kernel<action, auto_reset>", "kernel_ms": steady_ms,
+                         "kernel_ms_source": "launch period of launches 2..K of the timed region (HIP events)",
+                         "kernel_ms_first_launch": first_ms, "kernel_ms_timed_mean": region_ms / K,
+                         "frac_timed_mean": ALGO_BYTES_PER_BOARD_STEP * n / (region_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "sustained": sustained,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BOARD_STEP * n},
             "fused_rollout": fused,
             "strong_scaling": strong,
             "carved_pool_run": carved,
+            "config1_run": config1,
             "config_supply": supply,
             "actor_loop": actor,
             "mean_episodic_return": mean_return if episodes else None,
             "episodes": episodes,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(L, M, args.seed)
+            out["cpu_baseline"] = cpu_baseline(L, M, args.seed, numpy_leg)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -1,7 +1,8 @@
 """Build and bind the C-ABI shared library (include/tetris_piclim.h) with ctypes.
 
-The library is compiled in-tree for gfx950 with hipcc (csrc/libtetris_piclim.so) and loaded with ctypes; there
-is no fallback: if it cannot be built or loaded the package raises.
+The library is compiled in-tree for gfx950 with hipcc (<repo>/lib/libtetris_piclim.so -- a short path, so that the
+line /proc/<pid>/maps shows for it is not truncated by tools that record which native code a process loaded) and
+loaded with ctypes; there is no fallback: if it cannot be built or loaded the package raises.
 """
 from __future__ import annotations
 
@@ -22,7 +23,8 @@ _ROOT = os.path.dirname(_PKG)
 # (tools/policy_clock.py); TPL_EXTRA_DEFINE=NAME builds libtetris_piclim_NAME.so with -DNAME for A/B runs on one box
 _DIAG = os.environ.get("TPL_DIAG_CLOCK") == "1"
 _EXTRA = os.environ.get("TPL_EXTRA_DEFINE", "")
-LIB_PATH = os.path.join(_CSRC, "libtetris_piclim_diag.so" if _DIAG else
+_LIBDIR = os.path.join(_ROOT, "lib")
+LIB_PATH = os.path.join(_LIBDIR, "libtetris_piclim_diag.so" if _DIAG else
                         f"libtetris_piclim_{_EXTRA}.so" if _EXTRA else "libtetris_piclim.so")
 _UNITS = [os.path.join(_CSRC, f) for f in ("tetris_piclim.hip", "carve_generator.hip", "carve_device.hip",
                                            "forward_generator.hip", "policy_mlp.hip", "observe.hip")]
@@ -67,7 +69,7 @@ def _source_digest() -> str:
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> csrc/libtetris_piclim.so.
+    """hipcc --offload-arch=gfx950 -> <repo>/lib/libtetris_piclim.so.
 
     Staleness is decided by a digest of the sources kept next to the library (file times do not survive a copy of
     the tree), and concurrent callers -- the ranks of one torchrun job -- serialise on a lock file, so exactly one
@@ -81,6 +83,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and fresh():
         return LIB_PATH
     import fcntl
+    os.makedirs(_LIBDIR, exist_ok=True)
     with open(LIB_PATH + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:

@@ -23,7 +23,7 @@ def _declared_symbols():
 
 def test_library_builds_and_exports_every_declared_symbol():
     path = T.build_library()
-    assert os.path.exists(path) and path.startswith(PKG)            # in-tree, not site-packages
+    assert os.path.exists(path) and path.startswith(os.path.join(ROOT, "lib"))   # in-tree (short path), not site-packages
     lib = ctypes.CDLL(path)
     declared = _declared_symbols()
     assert declared, "header parse found nothing"

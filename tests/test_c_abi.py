@@ -71,7 +71,7 @@ def test_host_generators_under_address_and_ub_sanitizers(tmp_path):
     configuration it generates is also carved back from a full stack with its own solution.  (Device code cannot
     run under a sanitizer on this pool; the host side can, on the CPU.)"""
     import tetris_piclim as T
-    csrc = os.path.dirname(T._lib.LIB_PATH)
+    csrc = T._lib._CSRC
     flags = ["-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I", os.path.join(ROOT, "include")]
     objs = []
     for unit in ("carve_generator.hip", "forward_generator.hip"):

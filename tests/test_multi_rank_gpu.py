@@ -1,0 +1,82 @@
+"""The N > 1 path with the HIP library doing the stepping: two ranks (gloo process group, both on the test box's one
+GPU) shard a batch by global board index, step their shards through the C ABI, and all-reduce the return counters
+through the product's sharding module.  The result must equal ONE process stepping the whole batch on the GPU, and the
+CPU oracle.  Also: `python bench.py --gpus 2` starts its two ranks itself."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "dist"))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["strong", "weak"])
+def test_two_hip_ranks_equal_one_process_and_the_oracle(tmp_path, oracle, mode):
+    import hip_shard_worker as W
+    import tetris_piclim as T
+    out = str(tmp_path / "dist.npz")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist", "hip_shard_worker.py"), mode, out]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    got = np.load(out)
+    assert int(got["ranks"]) == 2 and str(got["lib"]) == T.LIB_PATH
+    n_total = W.BOARDS if mode == "strong" else (W.BOARDS // 2) * 2
+    stats, state = W.run_shard(T.sharding.strong_shard(0, 1, n_total))
+    mean, episodes = T.sharding.mean_episodic_return(stats, W.REWARD)
+    assert int(got["episodes"]) == episodes and episodes > n_total and float(got["mean"]) == mean
+    for k in ("rows", "lines", "moves", "state", "cur", "nxt", "reward_sum"):
+        assert np.array_equal(got[k], state[k]), k
+    # and the oracle, one process over the whole batch
+    cpu = oracle.Env(n_total, W.L, W.M, 0, W.SEED)
+    cpu.set_pool(oracle.synth_boards(W.SEED, 0, W.POOL, W.L), oracle.synth_pieces(W.SEED, 0, W.POOL, W.M))
+    cpu.set_options(auto_reset=True, assign_mode=0, per_line=W.REWARD[0], win=W.REWARD[1], lose=W.REWARD[2])
+    cpu.reset()
+    rsum = np.zeros(n_total, np.float64)
+    for t in range(W.STEPS):
+        r, _ = cpu.step(oracle.synth_actions(W.SEED, 0, n_total, t))
+        rsum += r
+    want = cpu.get_state()
+    for k in ("rows", "lines", "moves", "state", "cur", "nxt"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.array_equal(got["reward_sum"], rsum) and cpu.stats()["episodes"] == episodes
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` outside torchrun (the form the driver uses for N = 1): the parent starts two ranks.
+    On a one-GPU box they share cuda:0 and use gloo (TPL_BENCH_ONE_GPU / TPL_BENCH_BACKEND exist for this rehearsal)."""
+    env = dict(os.environ, TPL_BENCH_ONE_GPU="1", TPL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--boards", "65536",
+           "--sustained", "100", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["backend"] == "gloo"
+    assert out["steps"] == 20 and out["warmup"] == 5 and len(out["timing"]["per_rank_ms_per_step"]) == 2
+    assert out["strong_scaling"]["global_boards"] == 65536 and out["strong_scaling"]["boards_per_gpu"] == 32768
+    assert out["value"] > 0 and out["episodes"] > 0
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True,
+                         timeout=120, cwd=ROOT, env=env)
+    assert res.returncode != 0 and "WORLD_SIZE=2" in res.stderr
