@@ -64,7 +64,13 @@ size_t tpl_pool_bytes(int64_t n_cfg, int32_t M);
  * `global_offset` is the global index of this handle's board 0 (batch-index sharding over GPUs); `seed`
  * keys the configuration assignment.  `workspace` is caller-owned device memory of at least
  * tpl_workspace_bytes() (256-byte aligned), or NULL to let the library hipMalloc its own.
- * Limits: 1 <= L <= 255, 1 <= M <= 254. */
+ * Limits: 1 <= L <= 250, 1 <= M <= 254.
+ *
+ * Which configuration an episode starts from: the pool entry is a function of (seed, global board index, the step
+ * at which the episode begins) -- TPL_ASSIGN_HASH: a hash of the three; TPL_ASSIGN_SEQUENTIAL: (global index + step)
+ * mod pool size, so boards that start together take adjacent entries.  Steps are counted on the device since the last
+ * full reset (64 bits), so a board's sequence of configurations never repeats and does not depend on how the batch is
+ * sharded over GPUs.  The whole resident state, step counters included, lives in the workspace. */
 int tpl_create(tpl_env** out, int64_t num_envs, int32_t L, int32_t M, int32_t device_id,
                int64_t global_offset, uint64_t seed, void* workspace, size_t workspace_bytes);
 
@@ -73,19 +79,40 @@ int tpl_destroy(tpl_env* env);
 
 /* auto_reset: a board that finishes during a step is re-initialised from the pool in that same step
  * (done is still reported 1 for that step).  Off: finished boards are frozen (reward 0, done 1).
- * reward = per_line * rows_cleared (+ win when the move wins) (+ lose when the move loses). */
+ * reward = per_line * rows_cleared (+ win when the move wins) (+ lose when the move loses).
+ * Changing assign_mode once a pool is loaded leaves the running boards without a way back to their piece lists: the
+ * next call that advances boards fails with TPL_ERR_STATE until tpl_reset(env, NULL, stream) has run. */
 int tpl_set_options(tpl_env* env, int32_t auto_reset, int32_t assign_mode,
                     float reward_per_line, float reward_win, float reward_lose);
 
-/* Replaces the warm-reset supply (queue of (board, pieces), game/tetris.py:195,445-449): uploads a pool of
- * prescribed configurations that resets draw from.  rows: [n_cfg][20] uint16, pieces: [n_cfg][M+1] uint8,
- * both device pointers.  `pool_mem` is caller-owned device memory of tpl_pool_bytes() or NULL. */
+/* Replaces the warm-reset supply (queue of (board, pieces) fed by two producers, game/tetris.py:195-211,445-449,
+ * 473-488): uploads a pool of prescribed configurations that resets draw from.  rows: [n_cfg][20] uint16, pieces:
+ * [n_cfg][M+1] uint8, both device pointers.  `pool_mem` is caller-owned device memory of tpl_pool_bytes() or NULL.
+ *
+ * The handle keeps TWO pool buffers so that the supply can be refreshed while boards run: the first call fills the
+ * current buffer; every later call fills the other one (on `stream`, e.g. a side stream that a generator feeds) and
+ * makes it current -- episodes that begin afterwards draw from it, boards that are mid-episode finish on the buffer
+ * their configuration lives in (a board carries one bit for it).  A caller-owned `pool_mem` must therefore stay
+ * alive until the call after next.  The buffer a call would overwrite must be out of use: the call fails with
+ * TPL_ERR_STATE unless a full reset, or at least M + 1 steps enqueued through this API, have followed the previous
+ * swap (tpl_pool_info tells).  Work that was captured into a hipGraph keeps the pool pointers it was captured with:
+ * capture again after a swap. */
 int tpl_load_configs(tpl_env* env, const uint16_t* rows, const uint8_t* pieces, int64_t n_cfg,
                      void* pool_mem, size_t pool_bytes, void* stream);
 
-/* Replaces Tetris.reset() (game/tetris.py:438-443).  mask == NULL: every board starts episode 0 and the
- * statistics are zeroed; otherwise boards with mask[i] != 0 start their next episode.  Unlike the reference,
- * lines_cleared / moves_used / state ARE zeroed. */
+/* Which of the two pool buffers is current (0 / 1), the sizes of both, and how many more steps must be enqueued
+ * before tpl_load_configs may overwrite the other one (0 = it may).  Any output may be NULL.  Host-side. */
+int tpl_pool_info(tpl_env* env, int32_t* current_slot, int64_t* n_cfg_current, int64_t* n_cfg_other,
+                  int64_t* steps_until_swap);
+/* For a caller that puts a saved copy of the workspace back (the resident state lives in caller-owned memory): the
+ * boards are then as old as they were when the copy was taken, so the swap guard goes back to the value
+ * tpl_pool_info reported at that moment.  0 <= steps_until_swap <= M + 1. */
+int tpl_pool_set_hold(tpl_env* env, int64_t steps_until_swap);
+
+/* Replaces Tetris.reset() (game/tetris.py:438-443).  mask == NULL: the step counters and the statistics are
+ * zeroed and every board starts an episode at step 0 (from the current pool buffer); otherwise boards with
+ * mask[i] != 0 start an episode at the next step.  Unlike the reference, lines_cleared / moves_used / state ARE
+ * zeroed. */
 int tpl_reset(tpl_env* env, const uint8_t* mask, void* stream);
 
 /* Replaces Tetris.move(rotations, location) (game/tetris.py:354-422), one move on every board.
@@ -147,7 +174,7 @@ int tpl_policy_pack(const float* w1, const float* b1, const float* w2, const flo
                     const float* b3, const float* w4, const float* b4, const float* w5, const float* b5, void* image);
 int tpl_policy_act(tpl_env* env, const void* image, uint8_t* action, float* logits, void* stream);
 /* Epsilon-greedy exploration on an action array: with probability epsilon action[i] is replaced by a uniform
- * action in [0, 40), decided by a hash of (seed, global board index, step). */
+ * action in [0, 40) (a 32-bit draw reduced by multiply-high), decided by a hash of (seed, global board index, step). */
 int tpl_explore_actions(tpl_env* env, uint8_t* action, float epsilon, uint64_t seed, uint32_t step, void* stream);
 /* num_steps iterations of (tpl_policy_act, tpl_explore_actions(step0 + t), tpl_step) in ONE launch: the weights
  * stay in LDS and the boards in registers; only the trajectory leaves the chip.  Outputs, each optional:
@@ -166,6 +193,9 @@ int tpl_shape_info(int32_t piece, int32_t rotations, int32_t* h, int32_t* w, uin
 
 /* Raw device pointers of the resident packed state (for zero-copy inspection; layout in DESIGN.md). */
 int tpl_state_ptrs(tpl_env* env, void** plane_a, void** plane_b);
+/* The step counters: `count` uint64 values on the device, one per group of 32 boards, each equal to the number of
+ * steps since the last full reset. */
+int tpl_clock_ptr(tpl_env* env, void** clock, int64_t* count);
 
 /* Tuning knobs of the step kernel: boards handled per lane (1, 2 or 4; default 2) and threads per block
  * (64, 128, 256 or 512; default 256).  Results do not depend on them. */

@@ -52,7 +52,11 @@ def lib():
         L.to_env_set_pool.argtypes = [vp, vp, vp, i64]
         L.to_env_set_options.argtypes = [vp, i32, i32, f32, f32, f32]
         L.to_env_assign.restype = i64
-        L.to_env_assign.argtypes = [vp, i64, C.c_uint32]
+        L.to_env_assign.argtypes = [vp, i64, u64]
+        L.to_env_clock.restype = u64
+        L.to_env_clock.argtypes = [vp]
+        L.to_env_birth.restype = u64
+        L.to_env_birth.argtypes = [vp, i64]
         L.to_env_reset.argtypes = [vp, vp]
         L.to_env_move.argtypes = [vp, vp, vp, vp, vp, vp]
         L.to_env_step.argtypes = [vp, vp, vp, vp]
@@ -133,14 +137,22 @@ class Env:
     def set_pool(self, rows, pieces):
         rows = np.ascontiguousarray(rows, dtype=np.uint16).reshape(-1, 20)
         pieces = np.ascontiguousarray(pieces, dtype=np.uint8).reshape(rows.shape[0], self.M + 1)
-        self._pool = (rows, pieces)  # borrowed by the C side: keep alive
+        self._pools = getattr(self, "_pools", []) + [(rows, pieces)]   # borrowed by the C side: keep alive
         lib().to_env_set_pool(self._h, _p(rows), _p(pieces), rows.shape[0])
 
     def set_options(self, auto_reset=False, assign_mode=0, per_line=1.0, win=0.0, lose=0.0):
         lib().to_env_set_options(self._h, int(auto_reset), int(assign_mode), per_line, win, lose)
 
-    def assign(self, board, episode):
-        return lib().to_env_assign(self._h, board, episode)
+    def assign(self, board, birth):
+        """Pool entry (current slot) of the episode of `board` that begins at step `birth`."""
+        return lib().to_env_assign(self._h, board, birth)
+
+    @property
+    def clock(self):
+        return lib().to_env_clock(self._h)
+
+    def birth(self, board):
+        return lib().to_env_birth(self._h, board)
 
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)

@@ -199,17 +199,20 @@ to_env* to_env_create(int64_t n, int L, int M, int64_t global_offset, uint64_t s
     e->reward_per_line = 1.0f; e->reward_win = 0.0f; e->reward_lose = 0.0f;
     e->games = (to_game*)calloc((size_t)n, sizeof(to_game));
     e->pieces = (uint8_t*)calloc((size_t)n * (size_t)(M + 1), 1);
-    e->episode = (uint32_t*)calloc((size_t)n, sizeof(uint32_t));
+    e->birth = (uint64_t*)calloc((size_t)n, sizeof(uint64_t));
     return e;
 }
 
 void to_env_destroy(to_env* e) {
     if (!e) return;
-    free(e->games); free(e->pieces); free(e->episode); free(e);
+    free(e->games); free(e->pieces); free(e->birth); free(e);
 }
 
+/* the first pool goes into the current slot; a later one into the other slot, which becomes current (running boards
+ * keep the piece lists they copied at reset) */
 void to_env_set_pool(to_env* e, const uint16_t* rows, const uint8_t* pieces, int64_t n_cfg) {
-    e->pool_rows = rows; e->pool_pieces = pieces; e->n_cfg = n_cfg;
+    if (e->n_cfg[e->cur_slot] != 0) e->cur_slot ^= 1;
+    e->pool_rows[e->cur_slot] = rows; e->pool_pieces[e->cur_slot] = pieces; e->n_cfg[e->cur_slot] = n_cfg;
 }
 
 void to_env_set_options(to_env* e, int auto_reset, int assign_mode, float per_line, float win, float lose) {
@@ -224,33 +227,42 @@ static inline uint32_t fmix32(uint32_t h) {
     return h;
 }
 
-int64_t to_env_assign(const to_env* e, int64_t board, uint32_t episode) {
+/* hash mode: (g, birth, seed) folded into 32 bits -- for one board the word is birth * odd + const, so distinct births
+ * give distinct words and the sequence of entries has no period -- then one finaliser round and a multiply-high.
+ * sequential mode: (g + birth) mod n_cfg on the low 32 bits of birth. */
+int64_t to_env_assign(const to_env* e, int64_t board, uint64_t birth) {
     uint64_t g = (uint64_t)(e->global_offset + board);
-    if (e->assign_mode == 1) return (int64_t)((g + (uint64_t)episode) % (uint64_t)e->n_cfg);
-    /* 24-bit multiplies (low 24 bits of each factor, low 32 bits of the product), one finaliser round */
-    uint32_t x = ((uint32_t)g + (episode & 0xFFFFFFu) * 0x9E3779u) ^ (((uint32_t)(g >> 32) & 0xFFFFFFu) * 0x85EBCBu)
-                 ^ (uint32_t)(sm64(e->seed) >> 32);
+    uint64_t n_cfg = (uint64_t)e->n_cfg[e->cur_slot];
+    if (e->assign_mode == 1) return (int64_t)((g % n_cfg + (uint64_t)((uint32_t)birth % (uint32_t)n_cfg)) % n_cfg);
+    /* 24-bit multiplies take the low 24 bits of each factor and keep the low 32 bits of the product */
+    uint32_t x = ((uint32_t)g + (uint32_t)birth * 0x9E3779B1u) ^ (((uint32_t)(g >> 32) & 0xFFFFFFu) * 0x85EBCBu)
+                 ^ (((uint32_t)(birth >> 32) & 0xFFFFFFu) * 0xC2B2AFu) ^ (uint32_t)(sm64(e->seed) >> 32);
     uint32_t h = fmix32(x);
-    return (int64_t)(((uint64_t)h * (uint64_t)(uint32_t)e->n_cfg) >> 32);
+    return (int64_t)(((uint64_t)h * (uint64_t)(uint32_t)n_cfg) >> 32);
 }
 
-/* reset()/load_warm_reset() (game/tetris.py:438-449): clear, then take the next (board, pieces).
+uint64_t to_env_clock(const to_env* e) { return e->clock; }
+uint64_t to_env_birth(const to_env* e, int64_t board) { return e->birth[board]; }
+
+/* reset()/load_warm_reset() (game/tetris.py:438-449): clear, then take the next (board, pieces) -- the pool entry that
+ * belongs to an episode of this board beginning at step `birth`.
  * Unlike the reference (which leaves lines_cleared/moves_used/state untouched -- SURVEY 3.3) the
  * counters and the state are zeroed. */
-static void load_config(to_env* e, int64_t b) {
-    int64_t cfg = to_env_assign(e, b, e->episode[b]);
+static void load_config(to_env* e, int64_t b, uint64_t birth) {
+    int64_t cfg = to_env_assign(e, b, birth);
     to_game* g = &e->games[b];
-    memcpy(g->rows, e->pool_rows + cfg * TO_ROWS, sizeof(g->rows));
-    memcpy(e->pieces + b * (e->M + 1), e->pool_pieces + cfg * (e->M + 1), (size_t)(e->M + 1));
+    e->birth[b] = birth;
+    memcpy(g->rows, e->pool_rows[e->cur_slot] + cfg * TO_ROWS, sizeof(g->rows));
+    memcpy(e->pieces + b * (e->M + 1), e->pool_pieces[e->cur_slot] + cfg * (e->M + 1), (size_t)(e->M + 1));
     g->lines_cleared = 0; g->moves_used = 0; g->state = TO_RUNNING; g->cursor = 0;
 }
 
 void to_env_reset(to_env* e, const uint8_t* mask) {
+    /* a full reset() starts the step count over; a masked reset starts the masked boards' next episode at the next step */
+    if (!mask) e->clock = 0;
     for (int64_t b = 0; b < e->n; ++b) {
         if (mask && !mask[b]) continue;
-        /* a full reset() starts episode numbering over; a masked reset starts the board's next episode */
-        e->episode[b] = mask ? ((e->episode[b] + 1u) & 0xFFu) : 0u;
-        load_config(e, b);
+        load_config(e, b, e->clock);
     }
     if (!mask) { e->stat_episodes = e->stat_lines = e->stat_wins = e->stat_topouts = 0; }
 }
@@ -270,10 +282,7 @@ static void env_move_one(to_env* e, int64_t b, int rot, int loc, float* reward, 
             e->stat_wins += (g->state == TO_WON);
             e->stat_topouts += (res < 0);
             if (done) done[b] = 1;
-            if (e->auto_reset) {
-                e->episode[b] = (e->episode[b] + 1u) & 0xFFu;
-                load_config(e, b);
-            }
+            if (e->auto_reset) load_config(e, b, e->clock + 1);   /* its first move is the next step */
         } else if (done) {
             done[b] = 0;
         }
@@ -286,11 +295,13 @@ static void env_move_one(to_env* e, int64_t b, int rot, int loc, float* reward, 
 
 void to_env_move(to_env* e, const uint8_t* rot, const uint8_t* loc, float* reward, uint8_t* done, uint8_t* cleared) {
     for (int64_t b = 0; b < e->n; ++b) env_move_one(e, b, rot[b], loc[b], reward, done, cleared);
+    e->clock += 1;
 }
 
 /* action = rot*10 + loc (4 rotation x 10 location choices) */
 void to_env_step(to_env* e, const uint8_t* action, float* reward, uint8_t* done) {
     for (int64_t b = 0; b < e->n; ++b) env_move_one(e, b, action[b] / 10, action[b] % 10, reward, done, NULL);
+    e->clock += 1;
 }
 
 /* get_state (game/tetris.py:435-436), batched; a missing piece (list exhausted) reads as 7 */

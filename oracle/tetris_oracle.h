@@ -65,14 +65,19 @@ typedef struct {
     int32_t auto_reset;
     int32_t assign_mode;  /* 0 = hashed, 1 = sequential */
     float   reward_per_line, reward_win, reward_lose;
-    /* pool */
-    int64_t n_cfg;
-    const uint16_t* pool_rows;    /* [n_cfg][20] */
-    const uint8_t*  pool_pieces;  /* [n_cfg][M+1] */
+    /* two pool buffers: new episodes start from pool[cur_slot]; a pool set later goes into the other slot, which
+     * becomes current.  (The oracle copies a configuration's piece list into the board at reset, so a board never
+     * looks at its pool again -- which is what the device's slot bit and window refills must amount to.) */
+    int64_t n_cfg[2];
+    const uint16_t* pool_rows[2];    /* [n_cfg][20] */
+    const uint8_t*  pool_pieces[2];  /* [n_cfg][M+1] */
+    int32_t cur_slot;
+    /* steps since the last full reset (the device keeps one such counter per 32 boards; they are all equal) */
+    uint64_t clock;
     /* per-board state */
     to_game* games;       /* [n] */
     uint8_t* pieces;      /* [n][M+1]  current episode's list */
-    uint32_t* episode;    /* [n] episode number modulo 256 (0 for the first; the device keeps 8 bits) */
+    uint64_t* birth;      /* [n] step at which the board's current episode began */
     /* statistics over finished episodes */
     uint64_t stat_episodes, stat_lines, stat_wins, stat_topouts;
 } to_env;
@@ -81,7 +86,10 @@ to_env* to_env_create(int64_t n, int L, int M, int64_t global_offset, uint64_t s
 void    to_env_destroy(to_env* e);
 void    to_env_set_pool(to_env* e, const uint16_t* rows, const uint8_t* pieces, int64_t n_cfg); /* borrowed */
 void    to_env_set_options(to_env* e, int auto_reset, int assign_mode, float per_line, float win, float lose);
-int64_t to_env_assign(const to_env* e, int64_t board, uint32_t episode);
+/* pool entry (in the current slot) of the episode of `board` that begins at step `birth` */
+int64_t to_env_assign(const to_env* e, int64_t board, uint64_t birth);
+uint64_t to_env_clock(const to_env* e);
+uint64_t to_env_birth(const to_env* e, int64_t board);
 void    to_env_reset(to_env* e, const uint8_t* mask /* NULL = all */);
 /* rot/loc are uint8 arrays of length n.  reward/done/cleared may be NULL. */
 void    to_env_move(to_env* e, const uint8_t* rot, const uint8_t* loc, float* reward, uint8_t* done, uint8_t* cleared);

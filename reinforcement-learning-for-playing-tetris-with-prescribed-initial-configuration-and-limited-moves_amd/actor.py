@@ -87,12 +87,13 @@ class Actor:
             self._iteration()
         self.env.restore(saved)                      # capture does not execute, but keep the state untouched regardless
         self._graph = g
+        self._graph_pool = self.env.pool_generation  # the captured launches carry the pool pointers of this moment
 
     def step(self):
         """One obs -> action -> step iteration; results in self.action / self.reward / self.done."""
         if self._use_graph:
-            if self._graph is None:
-                self._capture()
+            if self._graph is None or self._graph_pool != self.env.pool_generation:
+                self._capture()                      # first use, or load_configs() has replaced the pool since
             self._graph.replay()
         else:
             self._iteration()

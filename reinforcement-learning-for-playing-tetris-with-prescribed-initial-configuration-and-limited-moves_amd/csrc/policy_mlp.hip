@@ -382,7 +382,9 @@ __global__ __launch_bounds__(64 * kPolicyWaves) void policy_kernel(const PolicyA
 __device__ __forceinline__ uint32_t explore(uint32_t action, uint64_t seed, uint64_t gidx, uint32_t step, uint32_t eps_q24) {
     uint32_t u = fmix32((uint32_t)gidx ^ ((uint32_t)(gidx >> 32) * 0x9E3779B9u) ^ (uint32_t)seed ^ 0x51ED270Bu);
     u = fmix32(u + step * 0x9E3779B1u + (uint32_t)(seed >> 32));
-    return (u >> 8) < eps_q24 ? ((u & 0xFFu) * 40u) >> 8 : action;
+    // the decision uses the upper 24 bits; the replacement is a second 32-bit draw reduced to [0, 40) by multiply-high
+    // (40 / 2^32 of bias, where eight bits times 40 gave sixteen of the actions 7/256 and the others 6/256)
+    return (u >> 8) < eps_q24 ? __umulhi(fmix32(u ^ 0x2545F491u), 40u) : action;
 }
 
 __global__ __launch_bounds__(kBlock) void explore_kernel(uint8_t* action, int64_t n, uint64_t seed, int64_t global_offset,
@@ -430,9 +432,11 @@ __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q
         } else {
 #pragma unroll
             for (int k = 0; k < kCols; ++k) s.c[k] = 0;
-            s.window = 0x3FFFFFFFu; s.state = ST_LOST_LIMIT; s.lines = 0; s.moves = 0; s.episode = 0;   // frozen filler
+            s.window = 0xFFFFFFFFu; s.window_hi = 0xFu; s.state = ST_LOST_LIMIT; s.lines = 0; s.moves = 0; s.slot = 0;   // frozen filler
         }
-        uint32_t cfg = current_config(s, p, (uint32_t)b);
+        // the tile's 32 boards are one clock group
+        const unsigned long long clock = valid ? p.clock[b >> kClockShift] : 0ull;
+        uint32_t cfg = current_config(s, p, (uint32_t)b, clock);
         for (uint32_t t = 0; t < q.T; ++t) {
             if (q.states_a && valid && writer) {
                 uint4 A, B;
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q
             split_action(action, rot, loc);
             float reward;
             Tally mine;
-            const bool done = advance_board<kAutoReset>(s, cfg, rot, loc, p, (uint32_t)b, s_shape, reward, mine);
+            const bool done = advance_board<kAutoReset>(s, cfg, rot, loc, p, (uint32_t)b, clock + t, s_shape, reward, mine);
             if (valid && writer) {
                 tally.episodes += mine.episodes; tally.lines += mine.lines;
                 tally.wins += mine.wins; tally.topouts += mine.topouts;
@@ -466,6 +470,7 @@ __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q
             pack_board(s, A, B);
             p.plane_a[b] = A;
             p.plane_b[b] = B;
+            if ((b & (kClockGroup - 1)) == 0) p.clock[b >> kClockShift] = clock + q.T;
         }
     }
     flush_tally(tally, s_stat, p.stats);
@@ -514,7 +519,7 @@ extern "C" int tpl_actor_rollout(tpl_env* e, const void* image, int32_t num_step
     if (num_steps < 1) return fail_msg(TPL_ERR_ARG, "num_steps must be >= 1");
     if (!(epsilon >= 0.0f && epsilon <= 1.0f)) return fail_msg(TPL_ERR_ARG, "epsilon must be in [0, 1]");
     if ((states_a == nullptr) != (states_b == nullptr)) return fail_msg(TPL_ERR_ARG, "states_a and states_b go together");
-    if (e->auto_reset && e->pool.n_cfg == 0) return fail_msg(TPL_ERR_STATE, "auto_reset needs tpl_load_configs first");
+    if (int rc = check_can_advance(e)) return rc;
     DeviceGuard guard(e->device);
     ActorArgs q{};
     q.s = make_args(e);
@@ -526,5 +531,6 @@ extern "C" int tpl_actor_rollout(tpl_env* e, const void* image, int32_t num_step
     if (e->auto_reset) hipLaunchKernelGGL(actor_rollout_kernel<true>, grid, block, 0, (hipStream_t)stream, q);
     else hipLaunchKernelGGL(actor_rollout_kernel<false>, grid, block, 0, (hipStream_t)stream, q);
     TPL_HIP(hipGetLastError());
+    count_steps(e, num_steps);
     return TPL_OK;
 }

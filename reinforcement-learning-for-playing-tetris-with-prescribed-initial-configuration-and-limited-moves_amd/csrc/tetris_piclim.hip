@@ -29,11 +29,13 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // step kernel may read and write back but never advances (they are created finished).
 constexpr size_t kPlanePad = 512 * 4;
 static inline size_t plane_bytes(int64_t n) { return align_up((size_t)n, kPlanePad) * sizeof(uint4); }
-// piece words of a configuration: entries 0..M+1 must be addressable (pieces[1] after the last move)
-static inline int piece_words(int M) { return (M + 2 + kWindowStride - 1) / kWindowStride; }
+static inline size_t clock_bytes(int64_t n) { return align_up((size_t)n, kPlanePad) / kClockGroup * sizeof(unsigned long long); }
+// piece words of a configuration: word w = entries [10w, 10w+12) is loaded when the cursor reaches 10w <= M, and
+// entries up to M+1 (pieces[1] after the last move) lie inside word M/10
+static inline int piece_words(int M) { return M / kWindowStride + 1; }
 // record stride: a power of two (64, 128 or 256 bytes), so that a record's address is one shift-and-add
 static inline uint32_t record_stride_shift(int M) {
-    const size_t need = 32 + 4 * (size_t)(piece_words(M) - 1);
+    const size_t need = 32 + 8 * (size_t)(piece_words(M) - 1);
     uint32_t shift = 6;
     while (((size_t)1 << shift) < need) ++shift;
     return shift;
@@ -71,6 +73,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
     const int64_t base = (int64_t)blockIdx.x * (kThreads * kBpl) + threadIdx.x;
     uint4 A[kBpl], B[kBpl];
     uint32_t a0[kBpl], a1[kBpl];
+    unsigned long long clock[kBpl];
     bool valid[kBpl];
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
@@ -82,6 +85,11 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         const int64_t j = valid[k] ? i : p.n - 1;
         A[k] = p.plane_a[i];
         B[k] = p.plane_b[i];
+        // the index of this step: the clock of the wave's first group, read through the scalar cache (the wave owns both
+        // of its groups' clocks and writes both back; all clocks are equal by construction)
+        const int64_t wave_first = (int64_t)blockIdx.x * (kThreads * kBpl) + (int64_t)k * kThreads +
+                                   (int64_t)(__builtin_amdgcn_readfirstlane((int)threadIdx.x) & ~63);
+        clock[k] = p.clock[wave_first >> kClockShift];
         a0[k] = load_int(p.act0, p.int_shift, j);
         a1[k] = kActionForm ? 0u : load_int(p.act1, p.int_shift, j);
     }
@@ -90,45 +98,47 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
     __syncthreads();
 
     // phase 1.  pieces.pop(0) (:356) moves the cursor to moves_used + 1 whatever the move does.  When that is a
-    // multiple of eight the window is down to its last two entries and piece word cursor/8 replaces it.
-    uint32_t word[kBpl], cursor[kBpl], episode[kBpl];
+    // multiple of ten the window is down to its last two entries and piece word cursor/10 replaces it.
+    uint64_t word[kBpl];
+    uint32_t moves[kBpl], refill_word[kBpl];
     bool live[kBpl], refill[kBpl];
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
         // an empty statement that needs every phase-0 result: it pins the one wait for phase 0 here, ahead of all
         // the gathers (left alone, the compiler waits for board k only after the gather of board k-1 has left,
         // which then has to be waited for as well)
-        asm volatile("" ::"v"(A[k].x), "v"(B[k].x), "v"(a0[k]), "v"(a1[k]));
+        asm volatile("" ::"v"(A[k].x), "v"(B[k].x), "v"(a0[k]), "v"(a1[k]), "s"(clock[k]));
     }
     TPL_STAMP(1);
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
-        const uint32_t moves = (A[k].y >> 28) | ((A[k].w >> 28) << 4);
-        episode[k] = (B[k].z >> 28) | ((B[k].y >> 28) << 4);
-        cursor[k] = moves + 1u;
-        live[k] = (B[k].w >> 30) == ST_RUNNING;
-        refill[k] = live[k] && (cursor[k] & (uint32_t)(kWindowStride - 1)) == 0u && p.n_cfg != 0u;
+        moves[k] = packed_moves(A[k]);
+        const uint32_t cursor = moves[k] + 1u;
+        refill_word[k] = div10(cursor);
+        live[k] = packed_state(B[k]) == ST_RUNNING;
+        refill[k] = live[k] && cursor - refill_word[k] * 10u == 0u && (p.n_cfg[0] | p.n_cfg[1]) != 0u;
     }
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
         const int64_t i = base + (int64_t)k * kThreads;
         word[k] = 0;
         if (refill[k]) {
-            const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, episode[k], p.seed_mix, p.n_cfg, p.assign_mode);
-            word[k] = *(const uint32_t*)(pool_record(p.pool, p.stride_shift, cfg) + 32u + 4u * ((cursor[k] >> 3) - 1u));
+            // the board's episode began at step clock - moves_used, in the pool buffer the board carries
+            const uint32_t slot = packed_slot(B[k]);
+            const uint32_t cfg = config_of(p, (uint32_t)i, clock[k] - moves[k], slot);
+            word[k] = piece_word_at(pool_record(p, slot, cfg), refill_word[k]);
         }
     }
 
     // phase 2
     float reward[kBpl];
-    uint32_t n_clear[kBpl], next_episode[kBpl];
+    uint32_t n_clear[kBpl];
     bool done[kBpl], reload[kBpl];
     bool finished = false;
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
         reward[k] = 0.0f;
         n_clear[k] = 0;
-        next_episode[k] = 0;
         done[k] = true;
         reload[k] = false;
         if (!live[k]) continue;                               // frozen: reward 0, done, state untouched
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         unpack_board(A[k], B[k], s);
         bool topout;
         n_clear[k] = move_board(s, s_shape, rot, loc, p.L, p.M, topout);
-        s.window = refill[k] ? word[k] : (s.window >> 3);     // the falling piece is consumed even on a top-out
+        if (refill[k]) set_window(s, word[k]); else pop_window(s);   // the falling piece is consumed even on a top-out
 
         reward[k] = step_reward(p, n_clear[k], s.state);
         done[k] = s.state != ST_RUNNING;
@@ -156,7 +166,6 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
             if (s.state == ST_LOST_TOPOUT) atomicAdd(&s_stat[3], 1u);
         }
         reload[k] = kAutoReset && done[k];
-        next_episode[k] = (s.episode + 1u) & 0xFFu;
         pack_board(s, A[k], B[k]);
     }
 
@@ -183,8 +192,9 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
 #pragma unroll
             for (int k = 0; k < kBpl; ++k) {
                 const int64_t i = base + (int64_t)k * kThreads;
-                const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, next_episode[k], p.seed_mix, p.n_cfg, p.assign_mode);
-                const uint4* rec = (const uint4*)pool_record(p.pool, p.stride_shift, reload[k] ? cfg : 0u);
+                // the new episode's first move is the next step: birth = clock + 1, from the current pool buffer
+                const uint32_t cfg = config_of(p, (uint32_t)i, clock[k] + 1u, p.cur_slot);
+                const uint4* rec = (const uint4*)pool_record(p, p.cur_slot, reload[k] ? cfg : 0u);
                 RA[k] = rec[0];
                 RB[k] = rec[1];
             }
@@ -192,8 +202,8 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
             for (int k = 0; k < kBpl; ++k) {
                 if (!reload[k]) continue;
                 A[k] = RA[k];
-                // the record carries episode 0: stamp the new one (as load_config does)
-                B[k] = make_uint4(RB[k].x, RB[k].y | ((next_episode[k] >> 4) << 28), RB[k].z | (next_episode[k] << 28), RB[k].w);
+                // the record carries slot 0: stamp the current one (as load_config does)
+                B[k] = make_uint4(RB[k].x, RB[k].y | (p.cur_slot << 30), RB[k].z, RB[k].w);
             }
         }
     }
@@ -208,6 +218,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
         const int64_t i = base + (int64_t)k * kThreads;
+        if ((threadIdx.x & (kClockGroup - 1)) == 0) p.clock[i >> kClockShift] = clock[k] + 1u;   // the group's next step
         if (!kAutoReset && !live[k]) continue;
         p.plane_a[i] = A[k];
         p.plane_b[i] = B[k];
@@ -256,10 +267,12 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
     const bool valid = i < p.n;
     uint4 A = make_uint4(0, 0, 0, 0), B = A;
     uint32_t act = 0;
+    unsigned long long clock = 0;
     if (valid) {
         A = p.plane_a[i];
         B = p.plane_b[i];
         act = q.actions[i];
+        clock = p.clock[i >> kClockShift];
     }
     if (threadIdx.x < 32) s_shape[threadIdx.x] = kShapeTable[threadIdx.x];
     if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
@@ -269,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
     if (valid) {
         Board s;
         unpack_board(A, B, s);
-        uint32_t cfg = current_config(s, p, (uint32_t)i);
+        uint32_t cfg = current_config(s, p, (uint32_t)i, clock);
         float rsum = 0.0f;
         // The first action must have ARRIVED before the loop is entered.  Otherwise its register is "possibly still
         // being loaded" at the loop header on one of the two ways in, and the compiler puts a full memory wait at
@@ -283,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
             uint32_t rot, loc;
             split_action(act, rot, loc);
             float reward;
-            const bool done = advance_board<kAutoReset>(s, cfg, rot, loc, p, (uint32_t)i, s_shape, reward, tally);
+            const bool done = advance_board<kAutoReset>(s, cfg, rot, loc, p, (uint32_t)i, clock + k, s_shape, reward, tally);
             rsum = rsum + reward;
             // (non-temporal: a trajectory is written once and consumed later, by someone else)
             if (q.reward_steps) __builtin_nontemporal_store(reward, q.reward_steps + (size_t)k * p.n + i);
@@ -293,36 +306,36 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
         pack_board(s, A, B);
         p.plane_a[i] = A;
         p.plane_b[i] = B;
+        if ((threadIdx.x & (kClockGroup - 1)) == 0) p.clock[i >> kClockShift] = clock + q.K;
         if (q.reward_sum) q.reward_sum[i] = rsum;
         if (q.finished) q.finished[i] = tally.episodes;
     }
     flush_tally(tally, s_stat, p.stats);
 }
 
-// Tetris.reset() (:438-443) for every board (mask == null, episode 0) or the masked ones (next episode).
+// Tetris.reset() (:438-443) for every board (mask == null: the host has zeroed the step clocks, every episode begins
+// at step 0) or the masked ones (their next episode begins at the group's next step).
 __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs p, const uint8_t* mask) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= p.n) return;
-    uint32_t ep = 0;
+    unsigned long long birth = 0;
     if (mask) {
         if (!mask[i]) return;
-        Board s;
-        unpack_board(p.plane_a[i], p.plane_b[i], s);
-        ep = (s.episode + 1u) & 0xFFu;
+        birth = p.clock[i >> kClockShift];
     }
-    const uint32_t cfg = assign_config(p.global_offset, p.offset_mod, (uint32_t)i, ep, p.seed_mix, p.n_cfg, p.assign_mode);
+    const uint32_t cfg = config_of(p, (uint32_t)i, birth, p.cur_slot);
     uint4 A, B;
-    load_config(p.pool, p.stride_shift, cfg, ep, A, B);
+    load_config(p, cfg, A, B);
     p.plane_a[i] = A;
     p.plane_b[i] = B;
 }
 
 // interchange (rows u16[20], pieces u8[M+1]) -> pool records in the resident layout
-__device__ __forceinline__ uint32_t piece_word(const uint8_t* pc, uint32_t M, uint32_t w) {
-    uint32_t word = 0;
+__device__ __forceinline__ uint64_t piece_word(const uint8_t* pc, uint32_t M, uint32_t w) {
+    uint64_t word = 0;
     for (uint32_t j = 0; j < (uint32_t)kWindowEntries; ++j) {
         const uint32_t idx = w * kWindowStride + j;
-        word |= (idx <= M ? (uint32_t)(pc[idx] & 7u) : 7u) << (3u * j);
+        word |= (uint64_t)(idx <= M ? (uint32_t)(pc[idx] & 7u) : 7u) << (3u * j);
     }
     return word;
 }
@@ -337,14 +350,14 @@ __global__ __launch_bounds__(kBlock) void pack_configs_kernel(const uint16_t* ro
     Board s;
     rows_to_cols(r, s.c);
     const uint8_t* pc = pieces + (size_t)i * (M + 1);
-    s.window = piece_word(pc, M, 0);
-    s.state = ST_RUNNING; s.lines = 0; s.moves = 0; s.episode = 0;
+    set_window(s, piece_word(pc, M, 0));
+    s.state = ST_RUNNING; s.lines = 0; s.moves = 0; s.slot = 0;
     uint4 A, B;
     pack_board(s, A, B);
     uint8_t* rec = pool + (size_t)i * stride;
     ((uint4*)rec)[0] = A;
     ((uint4*)rec)[1] = B;
-    for (uint32_t w = 1; w < words; ++w) ((uint32_t*)(rec + 32))[w - 1] = piece_word(pc, M, w);
+    for (uint32_t w = 1; w < words; ++w) ((uint64_t*)(rec + 32))[w - 1] = piece_word(pc, M, w);
 }
 
 // get_state (:435-436) + public attributes, resident layout -> interchange layout
@@ -531,10 +544,24 @@ static void launch_step_bpl(int threads, bool action_form, bool auto_reset, cons
     }
 }
 
+// what every board-advancing entry point checks before it launches, and the bookkeeping of the pool swap rule
+int check_can_advance(tpl_env* e) {
+    if (e->auto_reset && e->pool[e->cur_slot].n_cfg == 0) return fail_msg(TPL_ERR_STATE, "auto_reset needs tpl_load_configs first");
+    if (e->assign_dirty)
+        return fail_msg(TPL_ERR_STATE, "the assignment mode changed while boards were running: call tpl_reset(env, NULL, stream) first");
+    return TPL_OK;
+}
+
+void count_steps(tpl_env* e, int64_t steps) {
+    e->steps_since_swap += steps;
+    // every episode that began before the swap has ended (or frozen) after M + 1 steps
+    if (e->other_slot_live && e->steps_since_swap > (int64_t)e->M) e->other_slot_live = false;
+}
+
 static int launch_step(tpl_env* e, const void* act0, const void* act1, int32_t dtype, float* reward, uint8_t* done,
                        uint8_t* cleared, hipStream_t stream) {
     if (dtype != TPL_U8 && dtype != TPL_I32 && dtype != TPL_I64) return fail_msg(TPL_ERR_ARG, "unknown integer dtype %d", dtype);
-    if (e->auto_reset && e->pool.n_cfg == 0) return fail_msg(TPL_ERR_STATE, "auto_reset needs tpl_load_configs first");
+    if (int rc = check_can_advance(e)) return rc;
     StepArgs a = make_args(e);
     a.act0 = act0; a.act1 = act1; a.int_shift = dtype == TPL_U8 ? 0u : dtype == TPL_I32 ? 2u : 3u; a.reward = reward; a.done = done; a.cleared = cleared;
     const bool action_form = act1 == nullptr;
@@ -544,6 +571,7 @@ static int launch_step(tpl_env* e, const void* act0, const void* act1, int32_t d
         default: launch_step_bpl<4>(e->block_threads, action_form, e->auto_reset != 0, a, stream); break;
     }
     TPL_HIP(hipGetLastError());
+    count_steps(e, 1);
     return TPL_OK;
 }
 
@@ -560,7 +588,8 @@ const char* tpl_version(void) { return "tetris_piclim 0.1.0 (gfx950)"; }
 
 size_t tpl_workspace_bytes(int64_t num_envs, int32_t M) {
     if (num_envs <= 0 || M < 1) return 0;
-    return plane_bytes(num_envs) * 2 + align_up((size_t)kStatShards * kStatStride * sizeof(unsigned long long), 256);
+    return plane_bytes(num_envs) * 2 + align_up((size_t)kStatShards * kStatStride * sizeof(unsigned long long), 256) +
+           align_up(clock_bytes(num_envs), 256);
 }
 
 size_t tpl_pool_bytes(int64_t n_cfg, int32_t M) {
@@ -599,12 +628,16 @@ int tpl_create(tpl_env** out, int64_t num_envs, int32_t L, int32_t M, int32_t de
     const size_t n = (size_t)num_envs, padded = plane_bytes(num_envs) / sizeof(uint4);
     e->plane_a = (uint4*)base; base += plane_bytes(num_envs);
     e->plane_b = (uint4*)base; base += plane_bytes(num_envs);
-    e->stats = (unsigned long long*)base;
-    // every board: empty, running, no pieces; every padding board: lost.  Synchronised, because the caller's later
-    // work may run on a stream that does not order itself against the null stream.
+    e->stats = (unsigned long long*)base; base += align_up((size_t)kStatShards * kStatStride * sizeof(unsigned long long), 256);
+    e->clock = (unsigned long long*)base;
+    e->stride_shift = record_stride_shift(M);
+    // every board: empty, running, no pieces; every padding board: lost (the state field sits in the second word of
+    // a plane-B entry; the fill puts the same pattern in all four, which a padding board never looks at).  Step clocks
+    // zero.  Synchronised, because the caller's later work may run on a stream that does not order itself against the
+    // null stream.
     hipError_t err = hipMemset(e->plane_a, 0, need);
     if (err == hipSuccess && padded > n)
-        err = hipMemsetD32((hipDeviceptr_t)(e->plane_b + n), (int)((uint32_t)ST_LOST_LIMIT << 30), (padded - n) * 4);
+        err = hipMemsetD32((hipDeviceptr_t)(e->plane_b + n), (int)((uint32_t)ST_LOST_LIMIT << 28), (padded - n) * 4);
     if (err == hipSuccess) err = hipStreamSynchronize(nullptr);
     if (err != hipSuccess) {
         if (e->owned) (void)hipFree(e->owned);
@@ -619,7 +652,8 @@ int tpl_destroy(tpl_env* e) {
     if (!e) return TPL_OK;
     DeviceGuard guard(e->device);
     if (e->owned) (void)hipFree(e->owned);
-    if (e->pool.owned) (void)hipFree(e->pool.owned);
+    for (int k = 0; k < 2; ++k)
+        if (e->pool[k].owned) (void)hipFree(e->pool[k].owned);
     delete e;
     return TPL_OK;
 }
@@ -627,6 +661,9 @@ int tpl_destroy(tpl_env* e) {
 int tpl_set_options(tpl_env* e, int32_t auto_reset, int32_t assign_mode, float per_line, float win, float lose) {
     if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
     if (assign_mode != TPL_ASSIGN_HASH && assign_mode != TPL_ASSIGN_SEQUENTIAL) return fail_msg(TPL_ERR_ARG, "unknown assign_mode %d", assign_mode);
+    // a running board finds its pool entry again through the assignment function (tpl_device.h): changing the
+    // function under running boards would hand them the piece lists of other configurations
+    if (assign_mode != e->assign_mode && e->pool[e->cur_slot].n_cfg != 0) e->assign_dirty = true;
     e->auto_reset = auto_reset ? 1 : 0; e->assign_mode = assign_mode;
     e->r_line = per_line; e->r_win = win; e->r_lose = lose;
     return TPL_OK;
@@ -638,6 +675,15 @@ int tpl_load_configs(tpl_env* e, const uint16_t* rows, const uint8_t* pieces, in
     if (!rows || !pieces) return fail_msg(TPL_ERR_ARG, "rows/pieces is null");
     if (n_cfg <= 0 || n_cfg >= ((int64_t)1 << 32)) return fail_msg(TPL_ERR_ARG, "n_cfg %lld out of range", (long long)n_cfg);
     DeviceGuard guard(e->device);
+    // the first pool goes into the current slot; every later one into the OTHER slot, which then becomes current:
+    // boards that are mid-episode keep refilling their piece windows from the buffer their configuration lives in
+    const bool first = e->pool[e->cur_slot].n_cfg == 0;
+    const int target = first ? e->cur_slot : e->cur_slot ^ 1;
+    if (!first && e->other_slot_live)
+        return fail_msg(TPL_ERR_STATE,
+                        "boards that began before the previous tpl_load_configs may still be running on the buffer this call would "
+                        "overwrite: step %lld more time(s) (M + 1 after a swap) or call tpl_reset(env, NULL, stream) first",
+                        (long long)((int64_t)e->M + 1 - e->steps_since_swap));
     const size_t need = tpl_pool_bytes(n_cfg, e->M);
     char* base = (char*)pool_mem;
     void* newly_owned = nullptr;
@@ -649,30 +695,61 @@ int tpl_load_configs(tpl_env* e, const uint16_t* rows, const uint8_t* pieces, in
         if (err != hipSuccess) return fail_msg(TPL_ERR_NOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(err));
         newly_owned = base;
     }
-    if (e->pool.owned) {
-        // the previous pool may still be read by enqueued work
+    Pool& slot = e->pool[target];
+    if (slot.owned) {
+        // no board refers to it any more, but launches that read it may still be enqueued
         TPL_HIP(hipStreamSynchronize((hipStream_t)stream));
-        (void)hipFree(e->pool.owned);
+        (void)hipFree(slot.owned);
     }
-    e->pool.owned = newly_owned;
-    e->pool.rec = (uint8_t*)base;
-    e->pool.stride_shift = record_stride_shift(e->M);
-    e->pool.n_cfg = n_cfg;
+    slot.owned = newly_owned;
+    slot.rec = (uint8_t*)base;
+    slot.n_cfg = n_cfg;
     TPL_HIP(hipMemsetAsync(base, 0, need, (hipStream_t)stream));     // record padding reads as zero
     hipLaunchKernelGGL(pack_configs_kernel, dim3(blocks_for(n_cfg)), dim3(kBlock), 0, (hipStream_t)stream, rows, pieces,
-                       n_cfg, (uint32_t)e->M, (uint32_t)piece_words(e->M), e->pool.rec, (uint32_t)record_stride(e->M));
+                       n_cfg, (uint32_t)e->M, (uint32_t)piece_words(e->M), slot.rec, (uint32_t)record_stride(e->M));
     TPL_HIP(hipGetLastError());
+    if (!first) {
+        e->cur_slot = target;
+        e->steps_since_swap = 0;
+        e->other_slot_live = true;
+    }
+    return TPL_OK;
+}
+
+int tpl_pool_info(tpl_env* e, int32_t* current_slot, int64_t* n_cfg_current, int64_t* n_cfg_other, int64_t* steps_until_swap) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (current_slot) *current_slot = e->cur_slot;
+    if (n_cfg_current) *n_cfg_current = e->pool[e->cur_slot].n_cfg;
+    if (n_cfg_other) *n_cfg_other = e->pool[e->cur_slot ^ 1].n_cfg;
+    if (steps_until_swap) *steps_until_swap = e->other_slot_live ? (int64_t)e->M + 1 - e->steps_since_swap : 0;
+    return TPL_OK;
+}
+
+int tpl_pool_set_hold(tpl_env* e, int64_t steps_until_swap) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (steps_until_swap < 0 || steps_until_swap > (int64_t)e->M + 1) return fail_msg(TPL_ERR_ARG, "steps_until_swap out of [0, M + 1]");
+    e->other_slot_live = steps_until_swap > 0;
+    e->steps_since_swap = (int64_t)e->M + 1 - steps_until_swap;
     return TPL_OK;
 }
 
 int tpl_reset(tpl_env* e, const uint8_t* mask, void* stream) {
     if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
-    if (e->pool.n_cfg == 0) return fail_msg(TPL_ERR_STATE, "tpl_reset needs tpl_load_configs first");
+    if (e->pool[e->cur_slot].n_cfg == 0) return fail_msg(TPL_ERR_STATE, "tpl_reset needs tpl_load_configs first");
+    if (mask && e->assign_dirty)
+        return fail_msg(TPL_ERR_STATE, "the assignment mode changed while boards were running: a FULL reset (mask NULL) is due");
     DeviceGuard guard(e->device);
-    if (!mask)
+    if (!mask) {
         TPL_HIP(hipMemsetAsync(e->stats, 0, (size_t)kStatShards * kStatStride * sizeof(unsigned long long), (hipStream_t)stream));
+        TPL_HIP(hipMemsetAsync(e->clock, 0, clock_bytes(e->n), (hipStream_t)stream));
+    }
     hipLaunchKernelGGL(reset_kernel, dim3(blocks_for(e->n)), dim3(kBlock), 0, (hipStream_t)stream, make_args(e), mask);
     TPL_HIP(hipGetLastError());
+    if (!mask) {
+        // every board now lives in the current slot and starts from step 0 under the current assignment mode
+        e->other_slot_live = false;
+        e->assign_dirty = false;
+    }
     return TPL_OK;
 }
 
@@ -697,7 +774,7 @@ int tpl_rollout(tpl_env* e, const uint8_t* actions, int64_t action_stride, int32
     if (!actions) return fail_msg(TPL_ERR_ARG, "actions is null");
     if (num_steps < 1) return fail_msg(TPL_ERR_ARG, "num_steps must be >= 1");
     if (action_stride < e->n) return fail_msg(TPL_ERR_ARG, "action_stride %lld is smaller than num_envs", (long long)action_stride);
-    if (e->auto_reset && e->pool.n_cfg == 0) return fail_msg(TPL_ERR_STATE, "auto_reset needs tpl_load_configs first");
+    if (int rc = check_can_advance(e)) return rc;
     DeviceGuard guard(e->device);
     RolloutArgs q{};
     q.s = make_args(e);
@@ -707,6 +784,7 @@ int tpl_rollout(tpl_env* e, const uint8_t* actions, int64_t action_stride, int32
     if (e->auto_reset) hipLaunchKernelGGL(rollout_kernel<true>, grid, block, 0, (hipStream_t)stream, q);
     else hipLaunchKernelGGL(rollout_kernel<false>, grid, block, 0, (hipStream_t)stream, q);
     TPL_HIP(hipGetLastError());
+    count_steps(e, num_steps);
     return TPL_OK;
 }
 
@@ -808,6 +886,13 @@ int tpl_state_ptrs(tpl_env* e, void** plane_a, void** plane_b) {
     if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
     if (plane_a) *plane_a = e->plane_a;
     if (plane_b) *plane_b = e->plane_b;
+    return TPL_OK;
+}
+
+int tpl_clock_ptr(tpl_env* e, void** clock, int64_t* count) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (clock) *clock = e->clock;
+    if (count) *count = (e->n + kClockGroup - 1) / kClockGroup;
     return TPL_OK;
 }
 

@@ -5,19 +5,27 @@
 // v_ffbl on its word.  Citations "(:NNN)" are lines of the reference's game/tetris.py.
 //
 // Resident state, 32 B per board in two uint4 planes (SoA, plane[i] is board i -> 1 KiB per wave-load).
-// 200 board bits + 18 counter bits + a 30-bit window of the piece list + 8 episode bits = 256:
+// 200 board bits + 18 counter bits + a 36-bit window of the piece list + 1 pool-slot bit (+ 1 spare) = 256:
 //   A.x = col0 | col1<<20     A.y = col1>>12 | col2<<8 | moves[3:0]<<28     (three 20-bit columns per 64 bits)
 //   A.z = col3 | col4<<20     A.w = col4>>12 | col5<<8 | moves[7:4]<<28
-//   B.x = col6 | col7<<20     B.y = col7>>12 | col8<<8 | episode[7:4]<<28
-//   B.z = col9 | lines_cleared<<20 | episode[3:0]<<28
-//   B.w = piece window (ten 3-bit ids, entry 0 = pieces[0], entry 1 = pieces[1]) | state<<30
-//         (state: 0 run, 1 won, 2 lost@limit, 3 lost@top-out)
-// Piece list of a configuration, in the pool: 32-bit words of ten 3-bit ids with a stride of EIGHT entries,
-// word w = entries [8w, 8w+10), ids past the end of the list read 7.  A board carries one such word as its
-// window: every move shifts it down by one entry, and when the cursor reaches a multiple of eight the two
-// entries left in the window are exactly the first two of word cursor/8, which is then loaded whole.  So
+//   B.x = col6 | col7<<20     B.y = col7>>12 | col8<<8 | state<<28 | slot<<30
+//         (state: 0 run, 1 won, 2 lost@limit, 3 lost@top-out; slot: which of the two pool buffers the board's
+//          configuration lives in)
+//   B.z = col9 | lines_cleared<<20 | window[35:32]<<28
+//   B.w = window[31:0]        piece window: twelve 3-bit ids, entry 0 = pieces[0], entry 1 = pieces[1]
+// Piece list of a configuration, in the pool: 64-bit words of twelve 3-bit ids with a stride of TEN entries,
+// word w = entries [10w, 10w+12), ids past the end of the list read 7.  A board carries one such word as its
+// window: every move shifts it down by one entry, and when the cursor reaches a multiple of ten the two
+// entries left in the window are exactly the first two of word cursor/10, which is then loaded whole.  So
 // pieces[0] and pieces[1] are always in the state itself and the common step does one round trip to HBM.
-// Pool record (AoS, `stride` bytes, 64-B aligned): plane-A word, plane-B word (window = word 0), words 1..
+// Pool record (AoS, `stride` bytes, 64-B aligned): plane-A word, plane-B word (window = word 0), 64-bit words 1..
+//
+// A board does not store which pool entry it was started from, nor an episode number.  Every group of 32 boards
+// has a STEP CLOCK in memory (uint64, advanced by the wave that owns the group: +1 per step launch, +K per
+// K-step launch, zeroed by a full reset -- so every clock equals the number of steps since the last full reset).
+// A running board's episode began at step  birth = clock - moves_used  (a running board makes exactly one move
+// per step), and its pool entry is assign_config(global board index, birth, seed) in the slot it carries -- a
+// function of the 64-bit birth step, so a board's sequence of configurations never repeats.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -28,16 +36,32 @@ namespace tpl {
 constexpr int kRows = 20;
 constexpr int kCols = 10;
 constexpr uint32_t kColMask = 0xFFFFFu;
-constexpr int kWindowStride = 8;     // entries between the starts of consecutive piece words
-constexpr int kWindowEntries = 10;
+constexpr int kWindowStride = 10;    // entries between the starts of consecutive piece words
+constexpr int kWindowEntries = 12;
+constexpr int kClockGroup = 32;      // boards per step clock (log2 = kClockShift)
+constexpr int kClockShift = 5;
 
 enum : uint32_t { ST_RUNNING = 0, ST_WON = 1, ST_LOST_LIMIT = 2, ST_LOST_TOPOUT = 3 };
 
 struct Board {
     uint32_t c[kCols];   // column words
-    uint32_t window;     // piece window: entry 0 = the piece that falls next (pieces[0]), entry 1 = pieces[1]
-    uint32_t state, lines, moves, episode;
+    uint32_t window;     // piece window, entries 0..9 (+ 2 bits of entry 10): entry 0 = the piece that falls next
+    uint32_t window_hi;  //   bits 32..35 of the window (rest of entry 10, entry 11)
+    uint32_t state, lines, moves, slot;
 };
+
+// the window after pieces.pop(0): one entry down (a 36-bit shift)
+__device__ __forceinline__ void pop_window(Board& s) {
+    s.window = __builtin_amdgcn_alignbit(s.window_hi, s.window, 3);
+    s.window_hi >>= 3;
+}
+__device__ __forceinline__ void set_window(Board& s, uint64_t word) {
+    s.window = (uint32_t)word;
+    s.window_hi = (uint32_t)(word >> 32) & 0xFu;
+}
+// x / 10 and x % 10 for x < 1029 without an integer division (24-bit multiply: full rate)
+__device__ __forceinline__ uint32_t div10(uint32_t x) { return __umul24(x, 205u) >> 11; }
+__device__ __forceinline__ bool window_runs_out(uint32_t cursor) { return cursor - div10(cursor) * 10u == 0u; }
 
 // ---- shape table --------------------------------------------------------------------------------------
 // `tetrominos` (:23-57) re-encoded per (piece, rotations & 3) for the column layout.  Two words per entry:
@@ -113,10 +137,16 @@ __device__ __forceinline__ void unpack_board(const uint4& A, const uint4& B, Boa
     s.c[9] = B.z & kColMask;
     s.lines = (B.z >> 20) & 0xFFu;
     s.moves = (A.y >> 28) | ((A.w >> 28) << 4);
-    s.episode = (B.z >> 28) | ((B.y >> 28) << 4);
-    s.window = B.w & 0x3FFFFFFFu;
-    s.state = B.w >> 30;
+    s.window = B.w;
+    s.window_hi = B.z >> 28;
+    s.state = (B.y >> 28) & 3u;
+    s.slot = (B.y >> 30) & 1u;
 }
+
+// the fields a step needs before it unpacks the board
+__device__ __forceinline__ uint32_t packed_state(const uint4& B) { return (B.y >> 28) & 3u; }
+__device__ __forceinline__ uint32_t packed_slot(const uint4& B) { return (B.y >> 30) & 1u; }
+__device__ __forceinline__ uint32_t packed_moves(const uint4& A) { return (A.y >> 28) | ((A.w >> 28) << 4); }
 
 __device__ __forceinline__ void pack_board(const Board& s, uint4& A, uint4& B) {
     pack3(s.c[0], s.c[1], s.c[2], A.x, A.y);
@@ -124,9 +154,9 @@ __device__ __forceinline__ void pack_board(const Board& s, uint4& A, uint4& B) {
     pack3(s.c[6], s.c[7], s.c[8], B.x, B.y);
     A.y |= s.moves << 28;              // low nibble (the high one shifts out)
     A.w |= (s.moves >> 4) << 28;
-    B.y |= (s.episode >> 4) << 28;
-    B.z = s.c[9] | (s.lines << 20) | (s.episode << 28);
-    B.w = s.window | (s.state << 30);
+    B.y |= (s.state << 28) | (s.slot << 30);
+    B.z = s.c[9] | (s.lines << 20) | (s.window_hi << 28);
+    B.w = s.window;
 }
 
 // rows (interchange, u16[20], bit x = column x) <-> columns
@@ -256,25 +286,27 @@ __host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
     return h;
 }
 
-// which pool entry episode `episode` of global board `g` = global_offset + i starts from.
-// hash mode: (g, episode, seed) folded into 32 bits with 24-bit multiplies (full rate on the vector ALU), one round of
-// a 32-bit finaliser (a bijection, so boards 2^32 apart at most share a draw), range-reduced with a multiply-high.
-// `seed_mix` = assign_seed(seed), computed once on the host.
-// sequential mode: (g + episode) mod n_cfg, done with 32-bit remainders only (offset_mod = global_offset mod n_cfg
-// comes from the host) because a 64-bit remainder is a long software routine on the GPU.
+// which pool entry the episode of global board `g` = global_offset + i that begins at step `birth` starts from.
+// hash mode: (g, birth, seed) folded into 32 bits, one round of a 32-bit finaliser (a bijection), range-reduced with
+// a multiply-high.  For a fixed board the folded word is birth * odd + const, so distinct births (mod 2^32) give
+// distinct words: a board's configuration sequence has no period.  `seed_mix` = assign_seed(seed), computed once on the host.
+// sequential mode: (g + birth) mod n_cfg on the low 32 bits of birth, done with 32-bit remainders only (offset_mod =
+// global_offset mod n_cfg comes from the host) because a 64-bit remainder is a long software routine on the GPU;
+// boards that start together take adjacent entries.
 __host__ __device__ __forceinline__ uint32_t assign_seed(uint64_t seed) { return (uint32_t)(sm64(seed) >> 32); }
 
-__device__ __forceinline__ uint32_t assign_config(int64_t global_offset, uint32_t offset_mod, uint32_t i, uint32_t episode,
+__device__ __forceinline__ uint32_t assign_config(int64_t global_offset, uint32_t offset_mod, uint32_t i, uint64_t birth,
                                                   uint32_t seed_mix, uint32_t n_cfg, int mode) {
     if (mode == 1) {
         uint64_t t = (uint64_t)offset_mod + (uint64_t)(i % n_cfg);
         if (t >= n_cfg) t -= n_cfg;
-        t += episode % n_cfg;
+        t += (uint32_t)birth % n_cfg;
         if (t >= n_cfg) t -= n_cfg;
         return (uint32_t)t;
     }
     const uint64_t g = (uint64_t)global_offset + i;
-    const uint32_t x = ((uint32_t)g + __umul24(episode, 0x9E3779u)) ^ __umul24((uint32_t)(g >> 32), 0x85EBCBu) ^ seed_mix;
+    const uint32_t x = ((uint32_t)g + (uint32_t)birth * 0x9E3779B1u) ^ __umul24((uint32_t)(g >> 32), 0x85EBCBu) ^
+                       __umul24((uint32_t)(birth >> 32), 0xC2B2AFu) ^ seed_mix;
     return __umulhi(fmix32(x), n_cfg);
 }
 

@@ -11,8 +11,7 @@ constexpr int kStatShards = 256;
 constexpr int kStatStride = 16;   // uint64 per shard -> one 128-B line each
 
 struct Pool {
-    uint8_t* rec = nullptr;    // [n_cfg] records of 1 << stride_shift bytes: plane-A word, plane-B word, piece words 1..
-    uint32_t stride_shift = 0;
+    uint8_t* rec = nullptr;    // [n_cfg] records of 1 << stride_shift bytes: plane-A word, plane-B word, 64-bit piece words 1..
     int64_t n_cfg = 0;
     void* owned = nullptr;
 };
@@ -31,8 +30,18 @@ struct tpl_env {
     uint4* plane_a = nullptr;
     uint4* plane_b = nullptr;
     unsigned long long* stats = nullptr;// [kStatShards][kStatStride]
+    unsigned long long* clock = nullptr;// [padded boards / 32] step clocks (tpl_device.h)
     void* owned = nullptr;
-    tpl::Pool pool;
+    // Two pool buffers.  A board carries the slot its configuration lives in, so boards that are mid-episode when a new
+    // pool arrives finish on the old one; new episodes start from pool[cur_slot].  The other slot may be overwritten
+    // once no running board can still refer to it: after a full reset, or M+1 steps after the last swap.
+    tpl::Pool pool[2];
+    uint32_t stride_shift = 0;
+    int32_t cur_slot = 0;
+    int64_t steps_since_swap = 0;       // steps ENQUEUED THROUGH THE API since cur_slot last changed (graph replays are
+                                        //   not seen: the count errs on the side of refusing a swap)
+    bool other_slot_live = false;       // boards may still refer to pool[cur_slot ^ 1]
+    bool assign_dirty = false;          // the assignment mode changed under running boards: a full reset is due
 #ifdef TPL_DIAG_CLOCK
     unsigned long long* step_diag = nullptr;
 #endif
@@ -48,6 +57,11 @@ int fail_msg(int code, const char* fmt, ...);
         hipError_t e_ = (call);                                                                              \
         if (e_ != hipSuccess) return ::tpl::fail_msg(TPL_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
+
+// tetris_piclim.hip: what every board-advancing entry point checks before it launches (auto-reset needs a pool; a changed
+// assignment mode needs a full reset first), and the step count behind the pool-swap rule
+int check_can_advance(tpl_env* e);
+void count_steps(tpl_env* e, int64_t steps);
 
 // observe.hip: the [N,217] observation with 16-byte stores (needs a 16-byte aligned output)
 bool observe_fast_path(const void* out);

@@ -17,14 +17,17 @@ struct StepArgs {
     uint8_t* done;
     uint8_t* cleared;
     float r_line, r_win, r_lose;
-    // configuration pool (auto-reset, window refills)
-    const uint8_t* pool;
+    // configuration pools (auto-reset, window refills): new episodes start from pool[cur_slot], a running board
+    // refills its window from the slot it carries
+    const uint8_t* pool[2];
+    uint32_t n_cfg[2];
+    uint32_t offset_mod[2];    // global_offset mod n_cfg
     uint32_t stride_shift;     // records are 1 << stride_shift bytes apart
-    uint32_t n_cfg;
+    uint32_t cur_slot;
     int32_t assign_mode;
     uint32_t seed_mix;         // assign_seed(seed)
     int64_t global_offset;
-    uint32_t offset_mod;       // global_offset mod n_cfg
+    unsigned long long* clock; // step clocks, one per kClockGroup boards
     unsigned long long* stats;
 #ifdef TPL_DIAG_CLOCK
     unsigned long long* diag;  // diagnostic build: per-wave clock stamps of the step kernel
@@ -37,13 +40,17 @@ inline StepArgs make_args(const tpl_env* e) {
     a.plane_a = e->plane_a; a.plane_b = e->plane_b;
     a.n = e->n; a.L = (uint32_t)e->L; a.M = (uint32_t)e->M;
     a.r_line = e->r_line; a.r_win = e->r_win; a.r_lose = e->r_lose;
-    a.pool = e->pool.rec; a.stride_shift = e->pool.stride_shift;
-    a.n_cfg = (uint32_t)e->pool.n_cfg; a.assign_mode = e->assign_mode; a.seed_mix = assign_seed(e->seed);
-    a.global_offset = e->global_offset; a.stats = e->stats;
+    for (int k = 0; k < 2; ++k) {
+        a.pool[k] = e->pool[k].rec;
+        a.n_cfg[k] = (uint32_t)e->pool[k].n_cfg;
+        a.offset_mod[k] = e->pool[k].n_cfg ? (uint32_t)((uint64_t)e->global_offset % (uint64_t)e->pool[k].n_cfg) : 0u;
+    }
+    a.stride_shift = e->stride_shift; a.cur_slot = (uint32_t)e->cur_slot;
+    a.assign_mode = e->assign_mode; a.seed_mix = assign_seed(e->seed);
+    a.global_offset = e->global_offset; a.stats = e->stats; a.clock = e->clock;
 #ifdef TPL_DIAG_CLOCK
     a.diag = e->step_diag;
 #endif
-    a.offset_mod = e->pool.n_cfg ? (uint32_t)((uint64_t)e->global_offset % (uint64_t)e->pool.n_cfg) : 0u;
     return a;
 }
 
@@ -65,18 +72,31 @@ __device__ __forceinline__ void split_action(uint32_t action, uint32_t& rot, uin
     loc = action - ((rot << 3) + (rot << 1));
 }
 
-// (re)initialise a board from pool entry `cfg`.  reset()/load_warm_reset() (:438-449), with the counters
-// zeroed; the record's two state words are one 32-B read.
-__device__ __forceinline__ const uint8_t* pool_record(const uint8_t* pool, uint32_t stride_shift, uint32_t cfg) {
-    return pool + ((size_t)cfg << stride_shift);
+// A pool record's address.  `slot` is a per-lane value (0 / 1): the two bases are selected, not indexed.
+__device__ __forceinline__ const uint8_t* pool_record(const StepArgs& p, uint32_t slot, uint32_t cfg) {
+    const uint8_t* base = slot ? p.pool[1] : p.pool[0];
+    return base + ((size_t)cfg << p.stride_shift);
 }
 
-__device__ __forceinline__ void load_config(const uint8_t* pool, uint32_t stride_shift, uint32_t cfg, uint32_t episode,
-                                            uint4& A, uint4& B) {
-    const uint4* rec = (const uint4*)pool_record(pool, stride_shift, cfg);
+// pool entry of the episode of board i that begins at step `birth`, in pool buffer `slot`
+__device__ __forceinline__ uint32_t config_of(const StepArgs& p, uint32_t i, uint64_t birth, uint32_t slot) {
+    const uint32_t n_cfg = slot ? p.n_cfg[1] : p.n_cfg[0];
+    const uint32_t offset_mod = slot ? p.offset_mod[1] : p.offset_mod[0];
+    return n_cfg ? assign_config(p.global_offset, offset_mod, i, birth, p.seed_mix, n_cfg, p.assign_mode) : 0u;
+}
+
+// piece word `w` >= 1 of a record (the window refill)
+__device__ __forceinline__ uint64_t piece_word_at(const uint8_t* rec, uint32_t w) {
+    return *(const uint64_t*)(rec + 32u + 8u * (w - 1u));
+}
+
+// (re)initialise a board from pool entry `cfg` of the current slot.  reset()/load_warm_reset() (:438-449), with the
+// counters zeroed; the record's two state words are one 32-B read.
+__device__ __forceinline__ void load_config(const StepArgs& p, uint32_t cfg, uint4& A, uint4& B) {
+    const uint4* rec = (const uint4*)pool_record(p, p.cur_slot, cfg);
     A = rec[0];
     const uint4 pb = rec[1];
-    B = make_uint4(pb.x, pb.y | ((episode >> 4) << 28), pb.z | (episode << 28), pb.w);
+    B = make_uint4(pb.x, pb.y | (p.cur_slot << 30), pb.z, pb.w);     // the record carries slot 0: stamp the current one
 }
 
 // reward = per_line * rows_cleared (+ win when the move wins) (+ lose when the move loses): one rounded multiply,
@@ -92,29 +112,31 @@ __device__ __forceinline__ float step_reward(const StepArgs& p, uint32_t n_clear
 // episodes a lane finished, accumulated in registers across the steps of one launch
 struct Tally { uint32_t episodes = 0, lines = 0, wins = 0, topouts = 0; };
 
-// pool entry of the board's current episode (kept in a register by the multi-step kernels: the window refill needs
-// it every eighth move, and hashing it again each time costs more than the refill itself)
-__device__ __forceinline__ uint32_t current_config(const Board& s, const StepArgs& p, uint32_t i) {
-    return p.n_cfg ? assign_config(p.global_offset, p.offset_mod, i, s.episode, p.seed_mix, p.n_cfg, p.assign_mode) : 0u;
+// pool entry of the board's current episode at step `clock` (kept in a register by the multi-step kernels: the window
+// refill needs it every tenth move, and hashing it again each time costs more than the refill itself)
+__device__ __forceinline__ uint32_t current_config(const Board& s, const StepArgs& p, uint32_t i, uint64_t clock) {
+    return config_of(p, i, clock - s.moves, s.slot);
 }
 
 // One step of one unpacked board held in registers: Tetris.move (:354-422) + the window pop/refill + the
-// build's freeze / auto-reset rules + reward.  `cfg` = current_config() of the board, updated on a reset.
+// build's freeze / auto-reset rules + reward.  `cfg` = current_config() of the board, updated on a reset; `clock` = the
+// index of this step (the group's step clock on entry + the steps already done in this launch).
 // Returns done (state != running after the move, before a reset).
 template <bool kAutoReset>
 __device__ __forceinline__ bool advance_board(Board& s, uint32_t& cfg, uint32_t rot, uint32_t loc, const StepArgs& p,
-                                              uint32_t i, const ShapeWord* shape, float& reward, Tally& tally) {
+                                              uint32_t i, uint64_t clock, const ShapeWord* shape, float& reward, Tally& tally) {
     reward = 0.0f;
     if (s.state != ST_RUNNING) return true;      // frozen
-    // pieces.pop(0) (:356) moves the cursor to moves_used + 1 whatever the move does; at a multiple of eight the
-    // window is down to its last two entries and piece word cursor/8 replaces it (gather issued before the move)
+    // pieces.pop(0) (:356) moves the cursor to moves_used + 1 whatever the move does; at a multiple of ten the
+    // window is down to its last two entries and piece word cursor/10 replaces it (gather issued before the move)
     const uint32_t cursor = s.moves + 1u;
-    const bool refill = (cursor & (uint32_t)(kWindowStride - 1)) == 0u && p.n_cfg != 0u;
-    uint32_t word = 0;
-    if (refill) word = *(const uint32_t*)(pool_record(p.pool, p.stride_shift, cfg) + 32u + 4u * ((cursor >> 3) - 1u));
+    const uint32_t q = div10(cursor);
+    const bool refill = cursor - q * 10u == 0u && (p.n_cfg[0] | p.n_cfg[1]) != 0u;
+    uint64_t word = 0;
+    if (refill) word = piece_word_at(pool_record(p, s.slot, cfg), q);
     bool topout;
     const uint32_t n_clear = move_board(s, shape, rot, loc, p.L, p.M, topout);
-    s.window = refill ? word : (s.window >> 3);
+    if (refill) set_window(s, word); else pop_window(s);
     reward = step_reward(p, n_clear, s.state);
     const bool done = s.state != ST_RUNNING;
     if (done) {
@@ -123,10 +145,9 @@ __device__ __forceinline__ bool advance_board(Board& s, uint32_t& cfg, uint32_t 
         tally.wins += s.state == ST_WON ? 1u : 0u;
         tally.topouts += s.state == ST_LOST_TOPOUT ? 1u : 0u;
         if (kAutoReset) {
-            const uint32_t ep = (s.episode + 1u) & 0xFFu;
-            cfg = assign_config(p.global_offset, p.offset_mod, i, ep, p.seed_mix, p.n_cfg, p.assign_mode);
+            cfg = config_of(p, i, clock + 1u, p.cur_slot);       // the new episode's first move is the next step
             uint4 A2, B2;
-            load_config(p.pool, p.stride_shift, cfg, ep, A2, B2);
+            load_config(p, cfg, A2, B2);
             unpack_board(A2, B2, s);
         }
     }

@@ -38,6 +38,12 @@ class BatchedTetris:
     Parameters mirror `Tetris(L, M, ...)` (game/tetris.py:141); the warm-reset worker processes of the
     reference (:189-214) are replaced by a device-resident pool of prescribed configurations
     (`load_configs`), from which resets draw.
+
+    Which configuration an episode starts from is a function of (seed, global board index, the step at which the
+    episode begins): assign="hash" hashes the three, assign="sequential" takes entry (global index + step) mod pool
+    size.  Steps are counted on the device since the last full reset(), 64 bits wide, so a board's sequence of
+    configurations never repeats and does not depend on how many GPUs share the batch.  The pool can be replaced
+    while boards run (`load_configs` again): boards that are mid-episode finish on the pool they started from.
     """
 
     def __init__(self, L: int, M: int, num_envs: int, device="cuda:0", seed: int = 0, global_offset: int = 0,
@@ -60,9 +66,10 @@ class BatchedTetris:
         check(self._lib.tpl_create(C.byref(h), self.num_envs, self.L, self.M, idx, self.global_offset, self.seed,
                                    _ptr(self._workspace), nbytes))
         self._h = h
-        self._pool_mem = None
+        self._pool_mems = [None, None]       # the two pool buffers of the handle (device memory it borrows)
         self._pool = None
         self.n_configs = 0
+        self.pool_generation = 0             # bumped by every load_configs(): graphs captured before it are stale
         self.auto_reset = bool(auto_reset)
         self.assign = assign
         self.reward_params = tuple(float(x) for x in reward)
@@ -84,6 +91,8 @@ class BatchedTetris:
         check(self._lib.tpl_set_tuning(self._h, int(boards_per_lane), int(block_threads)))
 
     def set_options(self, auto_reset=None, assign=None, reward=None):
+        """Change the options.  A new `assign` mode takes effect with the next full reset(), which the library insists
+        on before it advances boards again (running boards find their piece lists through the assignment)."""
         if auto_reset is not None:
             self.auto_reset = bool(auto_reset)
         if assign is not None:
@@ -133,11 +142,32 @@ class BatchedTetris:
         nbytes = self._lib.tpl_pool_bytes(n_cfg, self.M)
         pool_mem = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         check(self._lib.tpl_load_configs(self._h, _ptr(rows), _ptr(pieces), n_cfg, _ptr(pool_mem), nbytes, self._stream()))
-        # the previous pool may still be in use by enqueued work: keep it until this stream has moved on
-        old = self._pool_mem
-        self._pool_mem, self._pool, self.n_configs = pool_mem, (rows, pieces), n_cfg
+        # the handle now reads this buffer as its current slot; what that slot held before is out of use (the library
+        # refused the call otherwise) but launches that read it may still be enqueued on this stream
+        slot = self.pool_info()["current_slot"]
+        old = self._pool_mems[slot]
+        self._pool_mems[slot], self._pool, self.n_configs = pool_mem, (rows, pieces), n_cfg
+        self.pool_generation += 1
         if old is not None:
             old.record_stream(torch.cuda.current_stream(self.device))
+
+    def pool_info(self) -> dict:
+        """Which of the handle's two pool buffers is current, their sizes, and how many more steps must be enqueued
+        before load_configs() may replace the other one (0: it may)."""
+        slot, cur, other, wait = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int64()
+        check(self._lib.tpl_pool_info(self._h, C.byref(slot), C.byref(cur), C.byref(other), C.byref(wait)))
+        return dict(current_slot=slot.value, n_configs=cur.value, n_configs_other=other.value, steps_until_swap=wait.value)
+
+    def step_clock(self) -> int:
+        """Steps since the last full reset(), as the device counts them (host sync)."""
+        ptr, count = C.c_void_p(), C.c_int64()
+        check(self._lib.tpl_clock_ptr(self._h, C.byref(ptr), C.byref(count)))
+        off = ptr.value - self._workspace.data_ptr()
+        clocks = self._workspace[off: off + 8 * count.value].view(torch.int64)
+        first = int(clocks[0])
+        if not bool((clocks == first).all()):
+            raise _lib.TplError("the step clocks of the board groups disagree")
+        return first
 
     def carved_configs(self, count: int, seed: Optional[int] = None, first: int = 0, with_solutions: bool = False,
                        max_iters: int = 0):
@@ -378,11 +408,22 @@ class BatchedTetris:
     state = property(lambda self: self._field("state"))
 
     def snapshot(self) -> torch.Tensor:
-        """Copy of the whole resident state (boards, counters, windows, statistics)."""
-        return self._workspace.clone()
+        """Copy of the whole resident state (boards, counters, piece windows, step clocks, statistics).  The boards
+        refer to the pool that is loaded now: the copy remembers which."""
+        saved = self._workspace.clone()
+        saved._tpl_pool = (self.pool_generation, self.assign)
+        saved._tpl_hold = self.pool_info()["steps_until_swap"]
+        return saved
 
     def restore(self, saved: torch.Tensor) -> None:
+        """Put a snapshot() back.  Refused if the pool or the assignment mode has changed since it was taken: the
+        running boards of the snapshot would continue with the piece lists of other configurations."""
+        tag = getattr(saved, "_tpl_pool", None)
+        if tag is not None and tag != (self.pool_generation, self.assign):
+            raise _lib.TplError("this snapshot was taken under another configuration pool or assignment mode")
         self._workspace.copy_(saved)
+        # the boards are as old again as they were then: so is the guard on the other pool buffer
+        check(self._lib.tpl_pool_set_hold(self._h, getattr(saved, "_tpl_hold", self.pool_info()["steps_until_swap"])))
 
     def stats(self) -> dict:
         """Episodes finished since the last full reset: counts for the episodic-return mean (host sync)."""
@@ -423,8 +464,13 @@ class Tetris:
     `solution` is the list of (rotations, location) that wins the current configuration (:155-156).  Like the
     reference's constructor it carves its own prescribed configurations -- with the native generator, a pool of
     `pool_size` at a time instead of two worker processes; `configs=(rows, pieces)` supplies them instead.
-    reset() moves on to the next configuration of the pool.  render=True (the pygame window, :158-182) is out of
-    scope and raises."""
+    reset() moves on to another configuration of the pool (entry `moves made so far` mod pool size: the sequential
+    assignment of the batched environment).  render=True (the pygame window, :158-182) is out of scope and raises.
+
+    One divergence from the reference: a FINISHED game is frozen.  The reference's move() keeps popping pieces and
+    changing board / moves_used / lines_cleared after `state` has been set (game/tetris.py:354-422 never looks at it);
+    here move() on a game whose state is not None raises RuntimeError, so that a ported caller fails loudly instead of
+    reading a board that no longer changes."""
 
     _STATE = {RUNNING: None, WON: True, LOST: False}
 
@@ -443,12 +489,14 @@ class Tetris:
             rows, pieces = configs
         self._pieces_host = np.asarray(pieces, dtype=np.uint8).reshape(-1, M + 1)
         self._env = BatchedTetris(L, M, 1, device=device, assign="sequential", config_pool=(rows, self._pieces_host))
-        self._episode = 0
+        self._steps = 0                    # step launches since construction = the device's step clock
+        self._birth = 0                    # the step at which the current episode began
+        self._finished = False
         self._board = None
         self._env.reset()
 
     def _config(self) -> int:
-        return (self._episode & 0xFF) % self._pieces_host.shape[0]        # the device keeps 8 episode bits
+        return self._birth % self._pieces_host.shape[0]                    # sequential assignment, board index 0
 
     @property
     def solution(self) -> list:
@@ -457,12 +505,18 @@ class Tetris:
         return self._solutions[self._config()]
 
     def move(self, rotations: int, location: int) -> None:
-        self._env.move(torch.tensor([rotations], dtype=torch.int64), torch.tensor([location], dtype=torch.int64))
+        if self._finished:
+            raise RuntimeError("move() on a finished game: this build freezes a game once state is set (the reference "
+                               "keeps mutating it); call reset() first")
+        _, done, _ = self._env.move(torch.tensor([rotations], dtype=torch.int64), torch.tensor([location], dtype=torch.int64))
+        self._finished = bool(done.item())
+        self._steps += 1
         self._board = None
 
     def reset(self) -> None:
-        self._episode += 1
+        self._birth = self._steps
         self._env.reset(mask=[1])
+        self._finished = False
         self._board = None
 
     def _s(self):

@@ -1,0 +1,288 @@
+"""Configuration assignment by birth step (no episode counter, no period) and the double-buffered pool.
+
+The reference feeds reset() from two live producers (game/tetris.py:195-211, 473-488): the supply never repeats and is
+replaced while games run.  Here: a board's pool entry is a function of (seed, global board index, the 64-bit step at
+which its episode began), and load_configs() on a live environment fills the handle's other pool buffer -- boards
+that are mid-episode finish on the buffer they started from.  CPU tests pin the rule on the oracle; GPU tests compare
+the HIP path with the oracle through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import ROOT  # noqa: F401
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def _state(env):
+    s = {k: _np(v) for k, v in env.packed_state().items()}
+    s["rows"] = s["rows"].view(np.uint16)
+    return s
+
+
+def _same(got, want, ctx):
+    for k in ("rows", "cur", "nxt", "lines", "moves", "state", "pieces_left"):
+        assert np.array_equal(got[k], want[k]), f"{ctx}: {k} differs at {np.argwhere(got[k] != want[k])[:5].tolist()}"
+
+
+# ------------------------------------------------------------------------------------------------- CPU: the rule
+def test_assignment_sequence_has_no_period_within_a_million_episodes(oracle):
+    """Round 1 kept 8 episode bits per board: every board replayed the same <= 256 configurations for ever.  Now the
+    entry is a function of the birth step.  10^6 episodes of one board under the shortest possible episodes (L=1, M=1:
+    one move each, so birth = episode number): the sequence of entries must not repeat with any lag up to 4096 (nor at
+    the old period), must visit the whole pool, and must look uniform."""
+    n_cfg, episodes = 4093, 1_000_000
+    env = oracle.Env(4, 1, 1, global_offset=123456789, seed=7)
+    env.set_pool(np.zeros((n_cfg, 20), np.uint16), np.zeros((n_cfg, 2), np.uint8))
+    env.set_options(auto_reset=True, assign_mode=0)
+    env.reset()
+    for board in (0, 3):
+        seq = np.array([env.assign(board, b) for b in range(episodes)], dtype=np.int64)
+        assert seq.min() >= 0 and seq.max() < n_cfg and len(np.unique(seq)) == n_cfg
+        for lag in list(range(1, 64)) + [255, 256, 257, 512, 1024, 4093, 4096, 65536]:
+            same = float(np.mean(seq[:-lag] == seq[lag:]))
+            assert same < 5.0 / n_cfg, (board, lag, same)                   # a period would make this 1.0
+        counts = np.bincount(seq, minlength=n_cfg)
+        chi2 = float(((counts - episodes / n_cfg) ** 2 / (episodes / n_cfg)).sum())
+        assert chi2 < n_cfg + 6 * np.sqrt(2 * n_cfg), chi2                  # chi-square, 4092 degrees of freedom
+    # two boards, and two seeds, do not share a sequence
+    a = np.array([env.assign(0, b) for b in range(4096)])
+    b = np.array([env.assign(1, b) for b in range(4096)])
+    assert np.mean(a == b) < 0.01
+    # births 2^32 apart differ too (the upper half of the 64-bit step enters the hash)
+    far = np.array([env.assign(0, b + (1 << 32)) for b in range(4096)])
+    assert np.mean(a == far) < 0.01
+
+
+def test_birth_step_bookkeeping_on_the_oracle(oracle):
+    """birth = the step of the episode's first move: 0 after a full reset, clock + 1 for a same-step auto-reset, the
+    current clock for a masked reset; a running board has made exactly clock - birth moves (or topped out)."""
+    L, M, n, seed = 3, 12, 256, 9
+    rows, pieces = oracle.synth_boards(seed, 0, 64, L), oracle.synth_pieces(seed, 0, 64, M)
+    env = oracle.Env(n, L, M, 0, seed)
+    env.set_pool(rows, pieces)
+    env.set_options(auto_reset=True, assign_mode=0)
+    env.reset()
+    assert env.clock == 0 and all(env.birth(b) == 0 for b in range(n))
+    for t in range(50):
+        _, done = env.step(oracle.synth_actions(seed, 0, n, t))
+        assert env.clock == t + 1
+        s = env.get_state()
+        for b in range(n):
+            if done[b]:
+                assert env.birth(b) == t + 1
+            assert s["moves"][b] == env.clock - env.birth(b)              # running boards only (auto-reset): no top-out left
+            assert np.array_equal(s["rows"][b], rows[env.assign(b, env.birth(b))]) or s["moves"][b] > 0
+    env.reset(np.ones(n, np.uint8))
+    assert all(env.birth(b) == 50 for b in range(n))
+    env.reset()
+    assert env.clock == 0
+
+
+def test_sequential_assignment_is_global_index_plus_birth(oracle):
+    n_cfg = 37
+    env = oracle.Env(8, 1, 1, global_offset=(1 << 33) + 5, seed=0)
+    env.set_pool(np.zeros((n_cfg, 20), np.uint16), np.zeros((n_cfg, 2), np.uint8))
+    env.set_options(auto_reset=True, assign_mode=1)
+    for board in range(8):
+        for birth in (0, 1, 36, 37, 1000, (1 << 32) - 1):
+            assert env.assign(board, birth) == ((1 << 33) + 5 + board + birth) % n_cfg
+    # the low 32 bits of the step enter (a 64-bit remainder is a software routine on the GPU)
+    assert env.assign(0, (1 << 32) + 3) == ((1 << 33) + 5 + 3) % n_cfg
+
+
+# ------------------------------------------------------------------------------------------------- GPU
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import tetris_piclim
+    return tetris_piclim
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("assign", ["hash", "sequential"])
+def test_device_assignment_equals_the_oracle_function(T, oracle, assign):
+    """After a full reset and after masked resets at several step counts, with a 64-bit global offset: every board sits on
+    the pool entry the oracle's assignment function names for (board, birth step), and the device's step clock is the
+    oracle's."""
+    L, M, n, n_cfg, seed, off = 2, 6, 3000, 997, 11, (1 << 35) + 12345
+    rng = np.random.default_rng(1)
+    rows = np.zeros((n_cfg, 20), np.uint16)
+    rows[:, 19] = np.arange(n_cfg) % 1023                                  # the entry is readable from the board itself
+    rows[:, 18] = np.arange(n_cfg) // 1023
+    pieces = rng.integers(0, 7, (n_cfg, M + 1)).astype(np.uint8)
+    gpu = T.BatchedTetris(L, M, n, seed=seed, global_offset=off, assign=assign, config_pool=(rows, pieces))
+    cpu = oracle.Env(n, L, M, off, seed)
+    cpu.set_pool(rows, pieces)
+    cpu.set_options(assign_mode=0 if assign == "hash" else 1)
+    gpu.reset(); cpu.reset()
+    entry = lambda s: s["rows"][:, 19].astype(np.int64) + 1023 * s["rows"][:, 18].astype(np.int64)
+    assert np.array_equal(entry(_state(gpu)), [cpu.assign(b, 0) for b in range(n)])
+    for t in range(23):
+        a = oracle.synth_actions(seed, off, n, t)
+        gpu.step(a, observe=False); cpu.step(a)
+        if t in (0, 6, 7, 22):
+            assert gpu.step_clock() == cpu.clock == t + 1
+            mask = (rng.random(n) < 0.3).astype(np.uint8)
+            gpu.reset(mask); cpu.reset(mask)
+            s = _state(gpu)
+            _same(s, cpu.get_state(), f"masked reset at {t}")
+            assert np.array_equal(entry(s)[mask == 1], [cpu.assign(b, t + 1) for b in np.flatnonzero(mask)])
+    gpu.terminate()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["step", "rollout", "mixed"])
+def test_pool_swap_mid_episode_matches_oracle(T, oracle, form):
+    """load_configs() on a LIVE environment with M >= 16 (every board refills its piece window at least once per full
+    episode): boards that are mid-episode must finish on the pool they started from -- piece words included -- while
+    new episodes draw from the new one.  Three pools, two swaps, against the oracle on every step."""
+    import torch
+    L, M, n, seed = 12, 33, 6000, 17
+    gpu = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True, assign="hash", reward=(1.0, 4.0, -1.0))
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_options(auto_reset=True, assign_mode=0, per_line=1.0, win=4.0, lose=-1.0)
+    pools = []
+    for k, size in enumerate((1500, 777, 2048)):
+        rows = oracle.synth_boards(seed + 100 * k, 0, size, 6)            # low stacks: episodes live long enough to refill
+        pieces = oracle.synth_pieces(seed + 100 * k, 0, size, M)
+        pools.append((rows, pieces))
+    gpu.load_configs(*pools[0]); cpu.set_pool(*pools[0])
+    gpu.reset(); cpu.reset()
+    t = 0
+
+    def run(steps):
+        nonlocal t
+        for _ in range(steps):
+            a = oracle.synth_actions(seed, 0, n, t)
+            # spread the pieces out so that boards survive past the first window refill
+            a = ((a // 10) * 10 + (np.arange(n) + 3 * t) % 10).astype(np.uint8)
+            use_rollout = form == "rollout" or (form == "mixed" and t % 2 == 1)
+            if use_rollout:
+                _, _, r_g, d_g = gpu.rollout(torch.from_numpy(a).to(gpu.device).unsqueeze(0), per_step=True)
+                r_g, d_g = r_g[0], d_g[0]
+            else:
+                _, r_g, d_g, _ = gpu.step(a, observe=False)
+            r_c, d_c = cpu.step(a)
+            assert np.array_equal(_np(r_g), r_c) and np.array_equal(_np(d_g).astype(np.uint8), d_c), t
+            _same(_state(gpu), cpu.get_state(), f"{form} step {t}")
+            t += 1
+
+    run(14)                                                               # boards are 14 moves into their first episode
+    assert (cpu.get_state()["moves"] >= 10).mean() > 0.3
+    gpu.load_configs(*pools[1]); cpu.set_pool(*pools[1])                  # swap while they run
+    assert gpu.pool_info()["steps_until_swap"] == M + 1
+    with pytest.raises(T.TplError, match="may still be running"):
+        gpu.load_configs(*pools[2])                                       # the buffer it would overwrite is still in use
+    run(M + 1)
+    assert gpu.pool_info()["steps_until_swap"] == 0
+    gpu.load_configs(*pools[2]); cpu.set_pool(*pools[2])
+    run(25)
+    assert gpu.stats() == cpu.stats() and gpu.stats()["episodes"] > n
+    # a full reset binds every board to the current buffer: the other one is free at once
+    gpu.reset(); cpu.reset()
+    assert gpu.pool_info()["steps_until_swap"] == 0
+    gpu.load_configs(*pools[0]); cpu.set_pool(*pools[0])
+    run(3)
+    gpu.terminate()
+
+
+@pytest.mark.gpu
+def test_pool_swap_under_the_actor_megakernel(T, oracle):
+    """The same swap with tpl_actor_rollout doing the stepping (boards stay in registers across the launch; the
+    recorded actions drive the oracle)."""
+    import torch
+    L, M, n, seed = 10, 40, 4000, 23
+    torch.manual_seed(2)
+    model = T.PolicyMLP()
+    image = T.actor.policy_image(model, "cuda:0")
+    gpu = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True)
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_options(auto_reset=True, assign_mode=0)
+    pool_a = (oracle.synth_boards(1, 0, 900, 4), oracle.synth_pieces(1, 0, 900, M))
+    pool_b = (oracle.synth_boards(2, 0, 1111, 4), oracle.synth_pieces(2, 0, 1111, M))
+    gpu.load_configs(*pool_a); cpu.set_pool(*pool_a)
+    gpu.reset(); cpu.reset()
+    for k, steps in enumerate((13, 30, 20)):
+        out = gpu.actor_rollout(image, steps, epsilon=0.5, seed=3, step0=100 * k)
+        for t in range(steps):
+            r_c, d_c = cpu.step(_np(out["actions"][t]))
+            assert np.array_equal(_np(out["rewards"][t]), r_c) and np.array_equal(_np(out["dones"][t]).astype(np.uint8), d_c), (k, t)
+        _same(_state(gpu), cpu.get_state(), f"launch {k}")
+        if k == 0:
+            gpu.load_configs(*pool_b); cpu.set_pool(*pool_b)
+    assert gpu.stats() == cpu.stats()
+    gpu.terminate()
+
+
+@pytest.mark.gpu
+def test_assign_mode_change_and_foreign_snapshots_are_refused(T, oracle):
+    L, M, n = 5, 20, 512
+    rows, pieces = oracle.synth_boards(3, 0, 128, L), oracle.synth_pieces(3, 0, 128, M)
+    env = T.BatchedTetris(L, M, n, seed=3, auto_reset=True, assign="hash", config_pool=(rows, pieces))
+    env.reset()
+    a = oracle.synth_actions(3, 0, n, 0)
+    env.step(a, observe=False)
+    saved = env.snapshot()
+    env.set_options(assign="sequential")
+    with pytest.raises(T.TplError, match="assignment mode changed"):
+        env.step(a, observe=False)
+    with pytest.raises(T.TplError, match="assignment mode changed"):
+        env.reset(np.ones(n, np.uint8))
+    with pytest.raises(T.TplError, match="another configuration pool or assignment mode"):
+        env.restore(saved)
+    env.set_options(assign="hash")                      # back to what the running boards were started under ...
+    env.reset()                                         # ... still needs the full reset the library asked for
+    env.step(a, observe=False)
+    saved = env.snapshot()
+    before = _state(env)
+    env.step(oracle.synth_actions(3, 0, n, 1), observe=False)
+    env.restore(saved)                                  # same pool, same mode: allowed, and the step clock comes back too
+    _same(_state(env), before, "restore")
+    assert env.step_clock() == 1
+    env.load_configs(rows, pieces)
+    with pytest.raises(T.TplError, match="another configuration pool"):
+        env.restore(saved)
+    env.terminate()
+
+
+@pytest.mark.gpu
+def test_actor_graph_is_recaptured_after_a_pool_swap(T, oracle):
+    """A captured HIP graph carries the pool pointers of its capture: Actor notices load_configs() and captures again."""
+    import torch
+    L, M, n, seed = 5, 20, 2048, 5
+    env = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True)
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_options(auto_reset=True, assign_mode=0)
+    pool_a = (oracle.synth_boards(1, 0, 300, L), oracle.synth_pieces(1, 0, 300, M))
+    pool_b = (oracle.synth_boards(2, 0, 200, L), oracle.synth_pieces(2, 0, 200, M))
+    env.load_configs(*pool_a); cpu.set_pool(*pool_a)
+    env.reset(); cpu.reset()
+    torch.manual_seed(0)
+    actor = T.Actor(env, T.PolicyMLP(), dtype=torch.float32, use_graph=True, fused=False)
+    for t in range(60):
+        if t == 25:
+            env.load_configs(*pool_b); cpu.set_pool(*pool_b)
+        actor.step()
+        r_c, d_c = cpu.step(_np(actor.action))
+        assert np.array_equal(_np(actor.reward), r_c) and np.array_equal(_np(actor.done), d_c), t
+    _same(_state(env), cpu.get_state(), "actor graph")
+    env.terminate()
+
+
+@pytest.mark.gpu
+def test_exploration_draw_is_uniform(T):
+    """epsilon = 1: every action is replaced by the exploration draw, which must be uniform on [0, 40) (it was
+    ((u & 255) * 40) >> 8: sixteen actions at 7/256, twenty-four at 6/256)."""
+    import torch
+    n = 1 << 20
+    env = T.BatchedTetris(5, 20, n, seed=1)
+    act = torch.zeros(n, dtype=torch.uint8, device=env.device)
+    env.explore_actions(act, 1.0, seed=9, step=4)
+    counts = np.bincount(_np(act), minlength=40).astype(np.float64)
+    assert counts.shape == (40,) and counts.sum() == n
+    chi2 = float(((counts - n / 40) ** 2 / (n / 40)).sum())
+    assert chi2 < 39 + 6 * np.sqrt(2 * 39), chi2                  # 39 degrees of freedom; the old draw scored > 4000
+    env.terminate()

@@ -59,7 +59,8 @@ def test_sizes_and_argument_errors_without_gpu():
     lib = T._lib.lib()
     n, M = 1 << 20, 40
     ws = lib.tpl_workspace_bytes(n, M)
-    assert n * 32 <= ws < n * 32 + (1 << 16)                          # 32 B of resident state per board
+    assert n * 32 + n // 4 <= ws < n * 32 + n // 4 + (1 << 16)        # 32 B of resident state per board + an 8-B step clock per 32
+    assert lib.tpl_pool_bytes(1000, 49) == 1000 * 64 and lib.tpl_pool_bytes(1000, 50) == 1000 * 128
     assert lib.tpl_pool_bytes(1000, M) == 1000 * 64                   # one 64-B record per configuration at M=40
     assert lib.tpl_pool_bytes(1000, 254) == 1000 * 256                 # record strides are powers of two
     assert lib.tpl_workspace_bytes(0, M) == 0

@@ -292,9 +292,9 @@ def test_auto_reset_rollout_matches_oracle(T, oracle, assign):
 
 
 @pytest.mark.parametrize("bpl", [1, 2, 4])
-def test_many_short_episodes_wrap_the_episode_counter(T, oracle, bpl):
-    """L=1, M=2: every episode lasts at most two moves, so 700 steps pass the 8-bit episode wrap; also runs
-    each boards-per-lane variant of the step kernel and a ragged batch size."""
+def test_many_short_episodes(T, oracle, bpl):
+    """L=1, M=2: every episode lasts at most two moves, so 700 steps are > 300 episodes per board, each assigned by
+    its birth step; also runs each boards-per-lane variant of the step kernel and a ragged batch size."""
     L, M, n, pool, seed = 1, 2, 5000, 777, 3
     gpu = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True, assign="hash")
     gpu.set_tuning(bpl)
@@ -316,7 +316,7 @@ def test_many_short_episodes_wrap_the_episode_counter(T, oracle, bpl):
     gpu.terminate()
 
 
-@pytest.mark.parametrize("M", [7, 8, 9, 15, 16, 17, 70, 71, 72, 199, 200, 254])      # 71|72, 199|200: record stride 64|128|256
+@pytest.mark.parametrize("M", [7, 9, 10, 11, 19, 20, 21, 40, 49, 50, 51, 129, 130, 131, 254])   # 49|50, 129|130: record stride 64|128|256
 def test_piece_window_refills_at_every_word_boundary(T, oracle, M):
     """Boards that survive all M moves (empty start, O pieces side by side never top out before M for small M;
     otherwise whatever happens) with random piece lists: checks cur/nxt against the oracle on every step."""
@@ -335,7 +335,7 @@ def test_piece_window_refills_at_every_word_boundary(T, oracle, M):
         loc = ((np.arange(n) + 3 * t) % 10).astype(np.uint8)
         gpu.move(rot, loc); cpu.move(rot, loc)
         _assert_state_equal(_state(gpu), cpu.get_state(), f"M={M} step {t}")
-    assert (cpu.get_state()["moves"] >= min(M, 8)).mean() > 0.2      # the refill path was really exercised
+    assert (cpu.get_state()["moves"] >= min(M, 10)).mean() > 0.2     # the refill path was really exercised
     gpu.terminate()
 
 
@@ -565,6 +565,63 @@ def test_full_size_run_properties_and_oracle_equality(T, oracle):
     # idempotence: every board is finished, one more step changes nothing
     gpu.step(gpu.synthetic_actions(M), observe=False)
     _assert_state_equal(_state(gpu), s, "frozen")
+    gpu.terminate()
+
+
+def test_benched_configuration_in_lockstep_with_the_oracle(T, oracle):
+    """Exactly what bench.py times (BASELINE configs[2]): 1,048,576 boards, one pool entry per board, auto-reset, hashed
+    assignment, tpl_step through step_into() with uint8 actions -- 60 lockstep steps against the oracle: rewards and
+    dones of every step, the whole state at the end, statistics.  (Reference semantics: game/tetris.py:354-449.)"""
+    import torch
+    L, M, n, seed, steps = 10, 40, 1 << 20, 0, 60
+    gpu = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True, assign="hash")
+    rows, pieces = gpu.synthetic_configs(n)
+    gpu.load_configs(rows, pieces)
+    gpu.reset()
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
+    cpu.set_options(auto_reset=True, assign_mode=0)
+    cpu.reset()
+    reward = torch.empty(n, dtype=torch.float32, device=gpu.device)
+    done = torch.empty(n, dtype=torch.uint8, device=gpu.device)
+    for t in range(steps):
+        a = gpu.synthetic_actions(t)
+        gpu.step_into(a, reward, done)
+        r_c, d_c = cpu.step(_np(a))
+        assert np.array_equal(_np(reward), r_c) and np.array_equal(_np(done), d_c), t
+    _assert_state_equal(_state(gpu), cpu.get_state(), "benched configuration")
+    st = gpu.stats()
+    assert st == cpu.stats() and st["episodes"] > 4 * n and gpu.step_clock() == cpu.clock == steps
+    gpu.terminate()
+
+
+def test_config1_shape_in_lockstep_with_the_oracle(T, oracle):
+    """BASELINE configs[1] as bench.py's config1_run drives it: 65,536 boards, L=5, M=20, pool = boards, auto-reset, hash,
+    fused rollouts of 50 steps and single steps interleaved."""
+    import torch
+    L, M, n, seed = 5, 20, 65536, 0
+    gpu = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True, assign="hash")
+    rows, pieces = gpu.synthetic_configs(n)
+    gpu.load_configs(rows, pieces)
+    gpu.reset()
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
+    cpu.set_options(auto_reset=True, assign_mode=0)
+    cpu.reset()
+    actions = torch.stack([gpu.synthetic_actions(t) for t in range(130)])
+    rsum, fin, rs, ds = gpu.rollout(actions[:50], per_step=True)
+    for t in range(50):
+        r_c, d_c = cpu.step(_np(actions[t]))
+        assert np.array_equal(_np(rs[t]), r_c) and np.array_equal(_np(ds[t]).astype(np.uint8), d_c), t
+    for t in range(50, 80):
+        _, r, d, _ = gpu.step(actions[t], observe=False)
+        r_c, d_c = cpu.step(_np(actions[t]))
+        assert np.array_equal(_np(r), r_c) and np.array_equal(_np(d).astype(np.uint8), d_c), t
+    gpu.rollout_into(actions[80:], 50)
+    for t in range(80, 130):
+        cpu.step(_np(actions[t]))
+    _assert_state_equal(_state(gpu), cpu.get_state(), "config 1")
+    assert gpu.stats() == cpu.stats()
     gpu.terminate()
 
 

@@ -152,7 +152,9 @@ def test_env_rules_freeze_autoreset_stats(oracle):
     frozen.reset(mask)
     s = frozen.get_state()
     assert np.all(s["state"][mask == 1] == 0) and np.all(s["state"][mask == 0] != 0)
-    want = np.array([frozen.assign(b, 1) for b in range(n)])
+    assert frozen.clock == 3 * M                                    # one tick per lockstep step since the full reset
+    want = np.array([frozen.assign(b, frozen.clock) for b in range(n)])   # the next episode begins at the next step
+    assert all(frozen.birth(b) == (frozen.clock if mask[b] else 0) for b in range(n))
     assert np.array_equal(s["rows"][mask == 1], rows[want[mask == 1]])
 
 

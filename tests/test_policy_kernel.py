@@ -214,3 +214,41 @@ def test_actor_rollout_megakernel_equals_the_step_by_step_loop(T, oracle, auto, 
     assert mega.stats() == ref.stats() == cpu.stats()
     for e in envs:
         e.terminate()
+
+
+def test_actor_megakernel_at_the_benched_size(T, oracle):
+    """BASELINE configs[4] at bench.py's size: 262,144 boards, L=10, M=40, auto-reset from a pool of one entry per board,
+    tpl_actor_rollout (25 iterations in one launch, epsilon-greedy) against the step-by-step loop on a twin handle and the
+    oracle fed with the recorded actions."""
+    import torch
+    L, M, n, seed, steps = 10, 40, 262144, 0, 25
+    torch.manual_seed(0)
+    model = T.PolicyMLP()
+    envs = []
+    for _ in range(2):
+        env = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True, assign="hash")
+        rows, pieces = env.synthetic_configs(n)
+        env.load_configs(rows, pieces)
+        env.reset()
+        envs.append(env)
+    mega, ref = envs
+    image = T.actor.policy_image(model, mega.device)
+    out = mega.actor_rollout(image, steps, epsilon=0.1, seed=7, step0=0)
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_pool(rows.cpu().numpy().view(np.uint16), pieces.cpu().numpy())
+    cpu.set_options(auto_reset=True, assign_mode=0)
+    cpu.reset()
+    for t in range(steps):
+        action = ref.explore_actions(ref.policy_act(image).clone(), 0.1, seed=7, step=t)
+        _, r, d, _ = ref.step(action, observe=False)
+        assert torch.equal(out["actions"][t], action), t
+        assert torch.equal(out["rewards"][t], r) and torch.equal(out["dones"][t], d), t
+        r_c, d_c = cpu.step(action.cpu().numpy())
+        assert np.array_equal(r.cpu().numpy(), r_c) and np.array_equal(d.cpu().numpy(), d_c), t
+    got = {k: v.cpu().numpy() for k, v in mega.packed_state().items()}
+    want = cpu.get_state()
+    for k, v in want.items():
+        assert np.array_equal(got[k].view(np.uint16) if k == "rows" else got[k], v), k
+    assert mega.stats() == ref.stats() == cpu.stats() and mega.stats()["episodes"] > n
+    for e in envs:
+        e.terminate()
