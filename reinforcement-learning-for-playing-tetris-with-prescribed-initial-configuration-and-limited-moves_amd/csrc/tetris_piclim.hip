@@ -75,6 +75,11 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
     uint32_t a0[kBpl], a1[kBpl];
     unsigned long long clock[kBpl];
     bool valid[kBpl];
+#ifdef TPL_X_CLKVEC
+    // (experiment) the clock as a vector load, requested ahead of the boards
+#pragma unroll
+    for (int k = 0; k < kBpl; ++k) clock[k] = p.clock[(base + (int64_t)k * kThreads) >> kClockShift];
+#endif
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
         // No branch around the loads, so all of a lane's requests leave before the first wait.  The planes are
@@ -89,7 +94,11 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         // of its groups' clocks and writes both back; all clocks are equal by construction)
         const int64_t wave_first = (int64_t)blockIdx.x * (kThreads * kBpl) + (int64_t)k * kThreads +
                                    (int64_t)(__builtin_amdgcn_readfirstlane((int)threadIdx.x) & ~63);
+#ifdef TPL_X_NOCLKLD
+        clock[k] = 0;
+#elif !defined(TPL_X_CLKVEC)
         clock[k] = p.clock[wave_first >> kClockShift];
+#endif
         a0[k] = load_int(p.act0, p.int_shift, j);
         a1[k] = kActionForm ? 0u : load_int(p.act1, p.int_shift, j);
     }
@@ -107,16 +116,23 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         // an empty statement that needs every phase-0 result: it pins the one wait for phase 0 here, ahead of all
         // the gathers (left alone, the compiler waits for board k only after the gather of board k-1 has left,
         // which then has to be waited for as well)
+#ifdef TPL_X_CLKVEC
+        asm volatile("" ::"v"(A[k].x), "v"(B[k].x), "v"(a0[k]), "v"(a1[k]), "v"(clock[k]));
+#else
         asm volatile("" ::"v"(A[k].x), "v"(B[k].x), "v"(a0[k]), "v"(a1[k]), "s"(clock[k]));
+#endif
     }
     TPL_STAMP(1);
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
         moves[k] = packed_moves(A[k]);
-        const uint32_t cursor = moves[k] + 1u;
-        refill_word[k] = div10(cursor);
+        const uint32_t tenth = tenths(moves[k] + 1u);
+        refill_word[k] = window_word(tenth);
         live[k] = packed_state(B[k]) == ST_RUNNING;
-        refill[k] = live[k] && cursor - refill_word[k] * 10u == 0u && (p.n_cfg[0] | p.n_cfg[1]) != 0u;
+        refill[k] = live[k] && window_runs_out(tenth) && (p.n_cfg[0] | p.n_cfg[1]) != 0u;
+#ifdef TPL_X_NOREFILL
+        refill[k] = false;
+#endif
     }
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
@@ -153,7 +169,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         unpack_board(A[k], B[k], s);
         bool topout;
         n_clear[k] = move_board(s, s_shape, rot, loc, p.L, p.M, topout);
-        if (refill[k]) set_window(s, word[k]); else pop_window(s);   // the falling piece is consumed even on a top-out
+        next_window(s, refill[k], word[k]);                    // the falling piece is consumed even on a top-out
 
         reward[k] = step_reward(p, n_clear[k], s.state);
         done[k] = s.state != ST_RUNNING;
@@ -218,11 +234,20 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
         const int64_t i = base + (int64_t)k * kThreads;
-        if ((threadIdx.x & (kClockGroup - 1)) == 0) p.clock[i >> kClockShift] = clock[k] + 1u;   // the group's next step
         if (!kAutoReset && !live[k]) continue;
         p.plane_a[i] = A[k];
         p.plane_b[i] = B[k];
     }
+    // the groups' next step.  Every lane stores (the 32 lanes of a group write the same value to the same word: one
+    // 16-byte write per wave): a branch on the lane index here would put a divergent region, and with it the
+    // compiler's full memory wait, between the state stores.
+#ifndef TPL_X_NOCLKST
+#pragma unroll
+    for (int k = 0; k < kBpl; ++k) {
+        const int64_t i = base + (int64_t)k * kThreads;
+        p.clock[i >> kClockShift] = clock[k] + 1u;
+    }
+#endif
 
     TPL_STAMP(4);
     // per-block statistics of the episodes that finished in this step -> one sharded 64-bit atomic per counter
@@ -272,8 +297,10 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
         A = p.plane_a[i];
         B = p.plane_b[i];
         act = q.actions[i];
-        clock = p.clock[i >> kClockShift];
     }
+    // the index of the first step: the clock of the wave's first group, through the scalar cache (as in step_kernel)
+    const int64_t wave_first = (int64_t)blockIdx.x * kBlock + (int64_t)(__builtin_amdgcn_readfirstlane((int)threadIdx.x) & ~63);
+    if (wave_first < p.n) clock = p.clock[wave_first >> kClockShift];
     if (threadIdx.x < 32) s_shape[threadIdx.x] = kShapeTable[threadIdx.x];
     if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
     __syncthreads();

@@ -50,18 +50,24 @@ struct Board {
     uint32_t state, lines, moves, slot;
 };
 
-// the window after pieces.pop(0): one entry down (a 36-bit shift)
-__device__ __forceinline__ void pop_window(Board& s) {
-    s.window = __builtin_amdgcn_alignbit(s.window_hi, s.window, 3);
-    s.window_hi >>= 3;
-}
 __device__ __forceinline__ void set_window(Board& s, uint64_t word) {
     s.window = (uint32_t)word;
     s.window_hi = (uint32_t)(word >> 32) & 0xFu;
 }
-// x / 10 and x % 10 for x < 1029 without an integer division (24-bit multiply: full rate)
-__device__ __forceinline__ uint32_t div10(uint32_t x) { return __umul24(x, 205u) >> 11; }
-__device__ __forceinline__ bool window_runs_out(uint32_t cursor) { return cursor - div10(cursor) * 10u == 0u; }
+// the window after pieces.pop(0): one entry down (a 36-bit shift), or -- when it has run out -- the piece word that was
+// fetched for it.  Selects, not a branch: a divergent region here costs every wave two exec-mask branches and the
+// compiler's full memory wait.
+__device__ __forceinline__ void next_window(Board& s, bool refill, uint64_t word) {
+    const uint32_t lo = __builtin_amdgcn_alignbit(s.window_hi, s.window, 3);
+    const uint32_t hi = s.window_hi >> 3;
+    s.window = refill ? (uint32_t)word : lo;
+    s.window_hi = refill ? ((uint32_t)(word >> 32) & 0xFu) : hi;
+}
+// cursor / 10 and cursor % 10 == 0 for cursor < 256 from one 24-bit multiply (full rate): cursor * 205 = 2048 * (cursor / 10)
+// + a remainder that is below 205 exactly when cursor is a multiple of ten (checked exhaustively in tests/test_boundary.py)
+__device__ __forceinline__ uint32_t tenths(uint32_t cursor) { return __umul24(cursor, 205u); }
+__device__ __forceinline__ bool window_runs_out(uint32_t t) { return (t & 2047u) < 205u; }
+__device__ __forceinline__ uint32_t window_word(uint32_t t) { return t >> 11; }
 
 // ---- shape table --------------------------------------------------------------------------------------
 // `tetrominos` (:23-57) re-encoded per (piece, rotations & 3) for the column layout.  Two words per entry:

@@ -8,6 +8,7 @@ namespace tpl {
 struct StepArgs {
     uint4* plane_a;
     uint4* plane_b;
+    unsigned long long* clock; // step clocks, one per kClockGroup boards (next to the planes: the kernels ask for it first)
     int64_t n;
     uint32_t L, M;
     const void* act0;          // action, or rot
@@ -27,7 +28,6 @@ struct StepArgs {
     int32_t assign_mode;
     uint32_t seed_mix;         // assign_seed(seed)
     int64_t global_offset;
-    unsigned long long* clock; // step clocks, one per kClockGroup boards
     unsigned long long* stats;
 #ifdef TPL_DIAG_CLOCK
     unsigned long long* diag;  // diagnostic build: per-wave clock stamps of the step kernel
@@ -129,14 +129,13 @@ __device__ __forceinline__ bool advance_board(Board& s, uint32_t& cfg, uint32_t 
     if (s.state != ST_RUNNING) return true;      // frozen
     // pieces.pop(0) (:356) moves the cursor to moves_used + 1 whatever the move does; at a multiple of ten the
     // window is down to its last two entries and piece word cursor/10 replaces it (gather issued before the move)
-    const uint32_t cursor = s.moves + 1u;
-    const uint32_t q = div10(cursor);
-    const bool refill = cursor - q * 10u == 0u && (p.n_cfg[0] | p.n_cfg[1]) != 0u;
+    const uint32_t tenth = tenths(s.moves + 1u);
+    const bool refill = window_runs_out(tenth) && (p.n_cfg[0] | p.n_cfg[1]) != 0u;
     uint64_t word = 0;
-    if (refill) word = piece_word_at(pool_record(p, s.slot, cfg), q);
+    if (refill) word = piece_word_at(pool_record(p, s.slot, cfg), window_word(tenth));
     bool topout;
     const uint32_t n_clear = move_board(s, shape, rot, loc, p.L, p.M, topout);
-    if (refill) set_window(s, word); else pop_window(s);
+    next_window(s, refill, word);
     reward = step_reward(p, n_clear, s.state);
     const bool done = s.state != ST_RUNNING;
     if (done) {
