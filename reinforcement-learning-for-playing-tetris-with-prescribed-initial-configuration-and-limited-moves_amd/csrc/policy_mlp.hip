@@ -436,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q
         }
         // the tile's 32 boards are one clock group
         const unsigned long long clock = valid ? p.clock[b >> kClockShift] : 0ull;
-        uint32_t cfg = current_config(s, p, (uint32_t)b, clock);
+        const uint8_t* rec = current_record(s, p, (uint32_t)b, clock);
         for (uint32_t t = 0; t < q.T; ++t) {
             if (q.states_a && valid && writer) {
                 uint4 A, B;
@@ -453,10 +453,10 @@ __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q
             uint32_t action = (g >> 1) ? act1 : act0;
             action = explore(action, q.explore_seed, (uint64_t)(p.global_offset + b), q.step0 + t, q.eps_q24);
             uint32_t rot, loc;
-            split_action(action, rot, loc);
+            split_small_action(action, rot, loc);
             float reward;
             Tally mine;
-            const bool done = advance_board<kAutoReset>(s, cfg, rot, loc, p, (uint32_t)b, clock + t, s_shape, reward, mine);
+            const bool done = advance_board<kAutoReset>(s, rec, rot, loc, p, (uint32_t)b, clock + t, s_shape, reward, mine);
             if (valid && writer) {
                 tally.episodes += mine.episodes; tally.lines += mine.lines;
                 tally.wins += mine.wins; tally.topouts += mine.topouts;

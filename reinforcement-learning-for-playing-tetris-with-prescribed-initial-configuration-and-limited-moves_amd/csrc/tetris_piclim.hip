@@ -308,9 +308,14 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
     Tally tally;
     if (valid) {
         Board s;
-        unpack_board(A, B, s);
-        uint32_t cfg = current_config(s, p, (uint32_t)i, clock);
+        unpack_board<true>(A, B, s);
+        const uint8_t* rec = current_record(s, p, (uint32_t)i, clock);
         float rsum = 0.0f;
+        // per-step streams are walked with running pointers (a 64-bit multiply-add per step and stream otherwise)
+        const uint8_t* act_next_ptr = q.actions + i;
+        float* reward_ptr = q.reward_steps + i;
+        uint8_t* done_ptr = q.done_steps + i;
+        const bool want_reward = q.reward_steps != nullptr, want_done = q.done_steps != nullptr;   // wave-uniform
         // The first action must have ARRIVED before the loop is entered.  Otherwise its register is "possibly still
         // being loaded" at the loop header on one of the two ways in, and the compiler puts a full memory wait at
         // the top of every iteration -- right behind the requests (next action, window word) that iteration has
@@ -319,18 +324,19 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
         for (uint32_t k = 0; k < q.K; ++k) {
             // next step's action is independent of the board: fetch it under this step's move
             uint32_t act_next = 0;
-            if (k + 1 < q.K) act_next = q.actions[(size_t)(k + 1) * q.action_stride + i];
+            act_next_ptr += q.action_stride;
+            if (k + 1 < q.K) act_next = *act_next_ptr;
             uint32_t rot, loc;
-            split_action(act, rot, loc);
+            split_small_action(act, rot, loc);
             float reward;
-            const bool done = advance_board<kAutoReset>(s, cfg, rot, loc, p, (uint32_t)i, clock + k, s_shape, reward, tally);
+            const bool done = advance_board<kAutoReset, true>(s, rec, rot, loc, p, (uint32_t)i, clock + k, s_shape, reward, tally);
             rsum = rsum + reward;
             // (non-temporal: a trajectory is written once and consumed later, by someone else)
-            if (q.reward_steps) __builtin_nontemporal_store(reward, q.reward_steps + (size_t)k * p.n + i);
-            if (q.done_steps) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), q.done_steps + (size_t)k * p.n + i);
+            if (want_reward) { __builtin_nontemporal_store(reward, reward_ptr); reward_ptr += p.n; }
+            if (want_done) { __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), done_ptr); done_ptr += p.n; }
             act = act_next;
         }
-        pack_board(s, A, B);
+        pack_board<true>(s, A, B);
         p.plane_a[i] = A;
         p.plane_b[i] = B;
         if ((threadIdx.x & (kClockGroup - 1)) == 0) p.clock[i >> kClockShift] = clock + q.K;

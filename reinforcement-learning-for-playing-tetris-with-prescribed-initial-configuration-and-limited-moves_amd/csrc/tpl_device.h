@@ -125,22 +125,50 @@ __device__ __constant__ const ShapeWord kShapeTable[32] = {TPL_SHAPE_LIST};
 constexpr ShapeWord kShapeTableHost[32] = {TPL_SHAPE_LIST};   // same entries, for tpl_shape_info on the host
 
 // ---- pack / unpack ------------------------------------------------------------------------------------
-__device__ __forceinline__ void unpack3(uint32_t lo, uint32_t hi, uint32_t& a, uint32_t& b, uint32_t& c) {
-    a = lo & kColMask;
-    b = __builtin_amdgcn_alignbit(hi, lo, 20) & kColMask;   // ({hi,lo} >> 20)
-    c = (hi >> 8) & kColMask;
-}
-
 __device__ __forceinline__ void pack3(uint32_t a, uint32_t b, uint32_t c, uint32_t& lo, uint32_t& hi) {
     lo = a | (b << 20);
     hi = (b >> 12) | (c << 8);
 }
 
+// kSentinel: the multi-step kernels keep every column word with bit 20 set while the board lives in registers (the top of
+// a column is then one v_ffbl with no preparation, and the `& mask` of the unpack becomes an and-or at the same cost);
+// move_board<true> expects that form and pack_board<true> strips it.
+constexpr uint32_t kSentinelBit = 1u << kRows;
+
+// (mask & x) | (~mask & y) as ONE v_bfi_b32.  With both constants written as literals the compiler emits an `and` and an
+// `or` (a VOP3 instruction takes one literal); handing them over in scalar registers it cannot see through gives the
+// bit-field insert.
+__device__ __forceinline__ uint32_t opaque_sgpr(uint32_t v) {
+    uint32_t r;
+    asm("s_mov_b32 %0, %1" : "=s"(r) : "i"(v));
+    return r;
+}
+
+template <bool kSentinel>
+__device__ __forceinline__ void unpack3(uint32_t lo, uint32_t hi, uint32_t& a, uint32_t& b, uint32_t& c) {
+    if (kSentinel) {
+        const uint32_t m = opaque_sgpr(kColMask), top = opaque_sgpr(kSentinelBit);
+        a = (m & lo) | (~m & top);
+        b = (m & __builtin_amdgcn_alignbit(hi, lo, 20)) | (~m & top);
+        c = (m & (hi >> 8)) | (~m & top);
+    } else {
+        a = lo & kColMask;
+        b = __builtin_amdgcn_alignbit(hi, lo, 20) & kColMask;   // ({hi,lo} >> 20)
+        c = (hi >> 8) & kColMask;
+    }
+}
+
+template <bool kSentinel = false>
 __device__ __forceinline__ void unpack_board(const uint4& A, const uint4& B, Board& s) {
-    unpack3(A.x, A.y, s.c[0], s.c[1], s.c[2]);
-    unpack3(A.z, A.w, s.c[3], s.c[4], s.c[5]);
-    unpack3(B.x, B.y, s.c[6], s.c[7], s.c[8]);
-    s.c[9] = B.z & kColMask;
+    unpack3<kSentinel>(A.x, A.y, s.c[0], s.c[1], s.c[2]);
+    unpack3<kSentinel>(A.z, A.w, s.c[3], s.c[4], s.c[5]);
+    unpack3<kSentinel>(B.x, B.y, s.c[6], s.c[7], s.c[8]);
+    if (kSentinel) {
+        const uint32_t m = opaque_sgpr(kColMask), top = opaque_sgpr(kSentinelBit);
+        s.c[9] = (m & B.z) | (~m & top);
+    } else {
+        s.c[9] = B.z & kColMask;
+    }
     s.lines = (B.z >> 20) & 0xFFu;
     s.moves = (A.y >> 28) | ((A.w >> 28) << 4);
     s.window = B.w;
@@ -154,14 +182,18 @@ __device__ __forceinline__ uint32_t packed_state(const uint4& B) { return (B.y >
 __device__ __forceinline__ uint32_t packed_slot(const uint4& B) { return (B.y >> 30) & 1u; }
 __device__ __forceinline__ uint32_t packed_moves(const uint4& A) { return (A.y >> 28) | ((A.w >> 28) << 4); }
 
+template <bool kSentinel = false>
 __device__ __forceinline__ void pack_board(const Board& s, uint4& A, uint4& B) {
-    pack3(s.c[0], s.c[1], s.c[2], A.x, A.y);
-    pack3(s.c[3], s.c[4], s.c[5], A.z, A.w);
-    pack3(s.c[6], s.c[7], s.c[8], B.x, B.y);
+    uint32_t c[kCols];
+#pragma unroll
+    for (int k = 0; k < kCols; ++k) c[k] = kSentinel ? (s.c[k] & kColMask) : s.c[k];
+    pack3(c[0], c[1], c[2], A.x, A.y);
+    pack3(c[3], c[4], c[5], A.z, A.w);
+    pack3(c[6], c[7], c[8], B.x, B.y);
     A.y |= s.moves << 28;              // low nibble (the high one shifts out)
     A.w |= (s.moves >> 4) << 28;
     B.y |= (s.state << 28) | (s.slot << 30);
-    B.z = s.c[9] | (s.lines << 20) | (s.window_hi << 28);
+    B.z = c[9] | (s.lines << 20) | (s.window_hi << 28);
     B.w = s.window;
 }
 
@@ -191,6 +223,7 @@ __device__ __forceinline__ uint32_t blend(uint32_t m, uint32_t x, uint32_t y) { 
 // Tetris.move(rotations, location) (:354-422) on the lane's board; the piece is entry 0 of the window, which the
 // caller pops (:356).  `shape` is the LDS-resident table.  Returns rows cleared (0..4); sets
 // `topout` when drop < 0 (:372-374), in which case the board and moves_used are left unchanged.
+template <bool kSentinel = false>
 __device__ __forceinline__ uint32_t move_board(Board& s, const ShapeWord* shape, uint32_t rot, uint32_t loc,
                                                uint32_t L, uint32_t M, bool& topout) {
     // get_tetromino (:60-61, :359-360)
@@ -209,7 +242,7 @@ __device__ __forceinline__ uint32_t move_board(Board& s, const ShapeWord* shape,
     // piece columns past its width, whose table bias of 64 keeps them out of the minimum.
     uint32_t t[kCols];
 #pragma unroll
-    for (int k = 0; k < kCols; ++k) t[k] = (uint32_t)__builtin_ctz(s.c[k] | (1u << kRows));
+    for (int k = 0; k < kCols; ++k) t[k] = (uint32_t)__builtin_ctz(kSentinel ? s.c[k] : (s.c[k] | kSentinelBit));
     uint32_t p0 = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
     uint32_t p1 = t[4] | (t[5] << 8) | (t[6] << 16) | (t[7] << 24);
     uint32_t p2 = t[8] | (t[9] << 8);

@@ -90,6 +90,13 @@ __device__ __forceinline__ uint64_t piece_word_at(const uint8_t* rec, uint32_t w
     return *(const uint64_t*)(rec + 32u + 8u * (w - 1u));
 }
 
+// the same for an action below 1029 (a uint8 action, a policy's action): one 24-bit multiply (full rate) instead of a
+// multiply-high (quarter rate)
+__device__ __forceinline__ void split_small_action(uint32_t action, uint32_t& rot, uint32_t& loc) {
+    rot = __umul24(action, 205u) >> 11;
+    loc = action - __umul24(rot, 10u);
+}
+
 // (re)initialise a board from pool entry `cfg` of the current slot.  reset()/load_warm_reset() (:438-449), with the
 // counters zeroed; the record's two state words are one 32-B read.
 __device__ __forceinline__ void load_config(const StepArgs& p, uint32_t cfg, uint4& A, uint4& B) {
@@ -112,18 +119,18 @@ __device__ __forceinline__ float step_reward(const StepArgs& p, uint32_t n_clear
 // episodes a lane finished, accumulated in registers across the steps of one launch
 struct Tally { uint32_t episodes = 0, lines = 0, wins = 0, topouts = 0; };
 
-// pool entry of the board's current episode at step `clock` (kept in a register by the multi-step kernels: the window
-// refill needs it every tenth move, and hashing it again each time costs more than the refill itself)
-__device__ __forceinline__ uint32_t current_config(const Board& s, const StepArgs& p, uint32_t i, uint64_t clock) {
-    return config_of(p, i, clock - s.moves, s.slot);
+// The pool record of the board's current episode at step `clock` (kept in registers by the multi-step kernels: the
+// window refill needs it every tenth move, and hashing the entry again each time costs more than the refill itself).
+__device__ __forceinline__ const uint8_t* current_record(const Board& s, const StepArgs& p, uint32_t i, uint64_t clock) {
+    return pool_record(p, s.slot, config_of(p, i, clock - s.moves, s.slot));
 }
 
 // One step of one unpacked board held in registers: Tetris.move (:354-422) + the window pop/refill + the
-// build's freeze / auto-reset rules + reward.  `cfg` = current_config() of the board, updated on a reset; `clock` = the
-// index of this step (the group's step clock on entry + the steps already done in this launch).
-// Returns done (state != running after the move, before a reset).
-template <bool kAutoReset>
-__device__ __forceinline__ bool advance_board(Board& s, uint32_t& cfg, uint32_t rot, uint32_t loc, const StepArgs& p,
+// build's freeze / auto-reset rules + reward.  `rec` = current_record() of the board, updated on a reset; `clock` = the
+// index of this step (the group's step clock on entry + the steps already done in this launch).  kSentinel: the board's
+// column words carry bit 20 (tpl_device.h).  Returns done (state != running after the move, before a reset).
+template <bool kAutoReset, bool kSentinel = false>
+__device__ __forceinline__ bool advance_board(Board& s, const uint8_t*& rec, uint32_t rot, uint32_t loc, const StepArgs& p,
                                               uint32_t i, uint64_t clock, const ShapeWord* shape, float& reward, Tally& tally) {
     reward = 0.0f;
     if (s.state != ST_RUNNING) return true;      // frozen
@@ -132,9 +139,9 @@ __device__ __forceinline__ bool advance_board(Board& s, uint32_t& cfg, uint32_t 
     const uint32_t tenth = tenths(s.moves + 1u);
     const bool refill = window_runs_out(tenth) && (p.n_cfg[0] | p.n_cfg[1]) != 0u;
     uint64_t word = 0;
-    if (refill) word = piece_word_at(pool_record(p, s.slot, cfg), window_word(tenth));
+    if (refill) word = piece_word_at(rec, window_word(tenth));
     bool topout;
-    const uint32_t n_clear = move_board(s, shape, rot, loc, p.L, p.M, topout);
+    const uint32_t n_clear = move_board<kSentinel>(s, shape, rot, loc, p.L, p.M, topout);
     next_window(s, refill, word);
     reward = step_reward(p, n_clear, s.state);
     const bool done = s.state != ST_RUNNING;
@@ -144,10 +151,10 @@ __device__ __forceinline__ bool advance_board(Board& s, uint32_t& cfg, uint32_t 
         tally.wins += s.state == ST_WON ? 1u : 0u;
         tally.topouts += s.state == ST_LOST_TOPOUT ? 1u : 0u;
         if (kAutoReset) {
-            cfg = config_of(p, i, clock + 1u, p.cur_slot);       // the new episode's first move is the next step
-            uint4 A2, B2;
-            load_config(p, cfg, A2, B2);
-            unpack_board(A2, B2, s);
+            // the new episode's first move is the next step; it starts from the current pool buffer
+            rec = pool_record(p, p.cur_slot, config_of(p, i, clock + 1u, p.cur_slot));
+            const uint4 A2 = ((const uint4*)rec)[0], pb = ((const uint4*)rec)[1];
+            unpack_board<kSentinel>(A2, make_uint4(pb.x, pb.y | (p.cur_slot << 30), pb.z, pb.w), s);
         }
     }
     return done;
