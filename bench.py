@@ -45,6 +45,7 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_BOARD_STEP = 96          # 46 B read + 49 B write, rounded
 HBM_PEAK_GBS = 8000.0                   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3            # f32-input MFMA = the f32 vector rate (MI355X_MICROARCH.md)
 
 
 def numpy_port_leg(L, M, seed, cores, seconds=3.0):
@@ -210,15 +211,19 @@ def measure_actor_loop(torch, T, dev, L, M, boards, seed):
     rows, pieces = env.synthetic_configs(boards)
     env.load_configs(rows, pieces)
     env.reset()
-    out = {"boards": boards, "unit": "env-steps/s",
-           "policy": "MLP 217-128-128-128-128-14, bf16 operands, greedy, random init"}
-    for name, use_fused in (("fused_mfma_kernel", True), ("torch_linear_layers", False)):
+    out = {"boards": boards, "unit": "env-steps/s", "policy": "MLP 217-128-128-128-128-14, greedy, random init",
+           "arithmetic": {"value": "bf16 operands, f32 accumulation (megakernel)", "fused_mfma_kernel": "bf16 operands, f32 accumulation",
+                          "fused_f32_kernel": "float32 operands and accumulation: the reference's nn.Linear width (model/model.py:9-20)",
+                          "torch_linear_layers": "torch bf16 Linear layers (hipBLASLt)",
+                          "torch_linear_layers_f32": "torch float32 Linear layers (hipBLASLt)"}}
+    for name, use_fused, dtype in (("fused_mfma_kernel", True, torch.bfloat16), ("fused_f32_kernel", True, torch.float32),
+                                   ("torch_linear_layers", False, torch.bfloat16), ("torch_linear_layers_f32", False, torch.float32)):
         torch.manual_seed(0)
         # two launches per iteration when fused: a graph replay costs more than it saves there
-        actor = T.Actor(env, T.PolicyMLP(), dtype=torch.bfloat16, use_graph=not use_fused, fused=use_fused)
+        actor = T.Actor(env, T.PolicyMLP(), dtype=dtype, use_graph=not use_fused, fused=use_fused)
         actor.run(20)
         torch.cuda.synchronize(dev)
-        ms = timed(torch, dev, actor.step, 300)
+        ms = timed(torch, dev, actor.step, 300 if dtype is torch.bfloat16 else 60)
         out[name] = {"value": boards / (ms * 1e-3), "ms_per_step": ms}
     # T iterations per launch (tpl_actor_rollout): weights stay in LDS, boards in registers; trajectory written
     torch.manual_seed(0)
@@ -239,6 +244,13 @@ def measure_actor_loop(torch, T, dev, L, M, boards, seed):
     tflops = 2.0 * (224 * 128 + 3 * 128 * 128 + 128 * 16) * boards / (ms * 1e-3) / 1e12
     out["policy_kernel"] = {"ms": ms, "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_PEAK_TFLOPS,
                                                    "unit": "TFLOP/s", "frac": tflops / MFMA_BF16_PEAK_TFLOPS}}
+    image32 = T.actor.policy_image(T.PolicyMLP(), dev, f32=True)
+    for _ in range(3):
+        env.policy_act(image32, out=act)
+    ms = timed(torch, dev, lambda: env.policy_act(image32, out=act), 20)
+    tflops = 2.0 * (224 * 128 + 3 * 128 * 128 + 128 * 16) * boards / (ms * 1e-3) / 1e12
+    out["policy_kernel_f32"] = {"ms": ms, "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS,
+                                                       "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS}}
     env.terminate()
     return out
 

@@ -173,6 +173,15 @@ size_t tpl_policy_image_bytes(void);
 int tpl_policy_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                     const float* b3, const float* w4, const float* b4, const float* w5, const float* b5, void* image);
 int tpl_policy_act(tpl_env* env, const void* image, uint8_t* action, float* logits, void* stream);
+/* The same policy with FLOAT32 operands -- the arithmetic width of the reference's own nn.Linear stack
+ * (model/model.py:9-20): weights, activations and accumulation in float32 on the matrix cores (each output is a
+ * k-ordered chain of fused multiply-adds), so logits differ from a float32 torch module only by summation order.
+ * tpl_policy_pack_f32 (host) takes the same ten arrays and fills an image of tpl_policy_image_bytes_f32() bytes;
+ * tpl_policy_act_f32 is tpl_policy_act for such an image.  About 1/8 of the bf16 kernel's rate. */
+size_t tpl_policy_image_bytes_f32(void);
+int tpl_policy_pack_f32(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                        const float* b3, const float* w4, const float* b4, const float* w5, const float* b5, void* image);
+int tpl_policy_act_f32(tpl_env* env, const void* image, uint8_t* action, float* logits, void* stream);
 /* Epsilon-greedy exploration on an action array: with probability epsilon action[i] is replaced by a uniform
  * action in [0, 40) (a 32-bit draw reduced by multiply-high), decided by a hash of (seed, global board index, step). */
 int tpl_explore_actions(tpl_env* env, uint8_t* action, float epsilon, uint64_t seed, uint32_t step, void* stream);

@@ -27,9 +27,9 @@ _LIBDIR = os.path.join(_ROOT, "lib")
 LIB_PATH = os.path.join(_LIBDIR, "libtetris_piclim_diag.so" if _DIAG else
                         f"libtetris_piclim_{_EXTRA}.so" if _EXTRA else "libtetris_piclim.so")
 _UNITS = [os.path.join(_CSRC, f) for f in ("tetris_piclim.hip", "carve_generator.hip", "carve_device.hip",
-                                           "forward_generator.hip", "policy_mlp.hip", "observe.hip")]
+                                           "forward_generator.hip", "policy_mlp.hip", "policy_f32.hip", "observe.hip")]
 _SOURCES = _UNITS + [os.path.join(_CSRC, "tpl_device.h"), os.path.join(_CSRC, "tpl_internal.h"),
-                     os.path.join(_CSRC, "tpl_step.h"), os.path.join(_CSRC, "py_random.h"),
+                     os.path.join(_CSRC, "tpl_step.h"), os.path.join(_CSRC, "tpl_policy.h"), os.path.join(_CSRC, "py_random.h"),
                      os.path.join(_ROOT, "include", "tetris_piclim.h")]
 
 # entry points declared in include/tetris_piclim.h (tests check that the .so exports every one of them)
@@ -40,6 +40,7 @@ SYMBOLS = [
     "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_decode_actions", "tpl_generate_configs", "tpl_generate_configs_pyseed", "tpl_forward_generate",
     "tpl_generate_configs_device_work_bytes", "tpl_generate_configs_device",
     "tpl_policy_image_bytes", "tpl_policy_pack", "tpl_policy_act",
+    "tpl_policy_image_bytes_f32", "tpl_policy_pack_f32", "tpl_policy_act_f32",
     "tpl_explore_actions", "tpl_actor_rollout", "tpl_pool_info", "tpl_pool_set_hold", "tpl_clock_ptr",
 ]
 
@@ -145,6 +146,10 @@ def lib() -> C.CDLL:
     L.tpl_policy_image_bytes.argtypes = []
     L.tpl_policy_pack.argtypes = [vp] * 11
     L.tpl_policy_act.argtypes = [vp, vp, vp, vp, vp]
+    L.tpl_policy_image_bytes_f32.restype = sz
+    L.tpl_policy_image_bytes_f32.argtypes = []
+    L.tpl_policy_pack_f32.argtypes = [vp] * 11
+    L.tpl_policy_act_f32.argtypes = [vp, vp, vp, vp, vp]
     L.tpl_explore_actions.argtypes = [vp, vp, f32, u64, C.c_uint32, vp]
     L.tpl_actor_rollout.argtypes = [vp, vp, i32, f32, u64, C.c_uint32, vp, vp, vp, vp, vp, vp]
     L.tpl_get_stats.argtypes = [vp, vp, vp]
@@ -245,8 +250,9 @@ def forward_generate(L: int, M: int, seeds, initial_height_max: int = 4, max_att
     return out
 
 
-def pack_policy(params):
-    """Five (weight, bias) pairs of Model(217, 14) (float32 numpy, torch layout) -> packed image (numpy uint8)."""
+def pack_policy(params, f32: bool = False):
+    """Five (weight, bias) pairs of Model(217, 14) (float32 numpy, torch layout) -> packed image (numpy uint8): for the
+    bf16 kernel (weights rounded to bf16) or, f32=True, for the float32 kernel (weights as they are)."""
     import numpy as np
     flat = []
     for w, b in params:
@@ -255,8 +261,9 @@ def pack_policy(params):
     want = [(128, 217), (128,), (128, 128), (128,), (128, 128), (128,), (128, 128), (128,), (14, 128), (14,)]
     if shapes != want:
         raise ValueError(f"policy parameters must have shapes {want}, got {shapes}")
-    image = np.empty(lib().tpl_policy_image_bytes(), np.uint8)
-    check(lib().tpl_policy_pack(*[a.ctypes.data_as(C.c_void_p) for a in flat], image.ctypes.data_as(C.c_void_p)))
+    size, pack = (lib().tpl_policy_image_bytes_f32(), lib().tpl_policy_pack_f32) if f32 else (lib().tpl_policy_image_bytes(), lib().tpl_policy_pack)
+    image = np.empty(size, np.uint8)
+    check(pack(*[a.ctypes.data_as(C.c_void_p) for a in flat], image.ctypes.data_as(C.c_void_p)))
     return image
 
 

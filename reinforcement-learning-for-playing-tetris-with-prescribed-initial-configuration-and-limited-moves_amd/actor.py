@@ -33,24 +33,26 @@ class PolicyMLP(nn.Module):
         return self.layer5(x)
 
 
-def policy_image(model: nn.Module, device) -> torch.Tensor:
-    """The packed LDS image of a PolicyMLP for the fused kernel (weights rounded to bf16), on `device`."""
+def policy_image(model: nn.Module, device, f32: bool = False) -> torch.Tensor:
+    """The packed image of a PolicyMLP for the fused kernels, on `device`: weights rounded to bf16, or (f32=True)
+    float32 as they are -- the reference's arithmetic width (model/model.py:9-20)."""
     from ._lib import pack_policy
     layers = [model.layer1, model.layer2, model.layer3, model.layer4, model.layer5]
     params = [(l.weight.detach().float().cpu().numpy(), l.bias.detach().float().cpu().numpy()) for l in layers]
-    return torch.from_numpy(pack_policy(params)).to(device)
+    return torch.from_numpy(pack_policy(params, f32=f32)).to(device)
 
 
 class Actor:
     """Greedy actor over a BatchedTetris: buffers are allocated once, the iteration is graph-captured.
 
     fused=False: observation kernel -> torch Linear layers -> decode kernel -> step kernel.
-    fused=True:  one MFMA kernel from the 32-B board state to the action (csrc/policy_mlp.hip) -> step kernel."""
+    fused=True:  one MFMA kernel from the 32-B board state to the action -> step kernel; with dtype=torch.float32 the
+                 float32 kernel (csrc/policy_f32.hip), otherwise the bf16 one (csrc/policy_mlp.hip)."""
 
     def __init__(self, env: BatchedTetris, model: nn.Module, dtype=torch.bfloat16, use_graph: bool = True,
                  fused: bool = False):
         self.env, self.dtype, self.fused = env, dtype, fused
-        self.image = policy_image(model, env.device) if fused else None
+        self.image = policy_image(model, env.device, f32=dtype is torch.float32) if fused else None
         self.model = model.to(device=env.device, dtype=dtype).eval()
         n, d = env.num_envs, env.device
         self.obs = torch.empty((n, OBS_DIM), dtype=dtype, device=d)

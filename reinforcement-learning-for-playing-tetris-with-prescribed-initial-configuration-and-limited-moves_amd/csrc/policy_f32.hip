@@ -1,0 +1,300 @@
+// policy_f32.hip -- obs -> MLP -> action with FLOAT32 operands (the reference's own arithmetic width).
+//
+// Model(217, 14) of the reference (model/model.py:9-20, model/train.py:26) is a float32 nn.Linear stack.  The fused
+// kernel of policy_mlp.hip rounds weights and hidden activations to bf16 (what a bf16 torch module does); this one
+// keeps everything in float32 on the matrix cores: v_mfma_f32_16x16x4_f32 -- f32 in, f32 accumulate, bit for bit a
+// k-ordered fmaf chain, 64 FLOP/clk/SIMD (157 TFLOP/s dense on the chip, 1/16 of the bf16 rate).
+//
+// Same transposed scheme as the bf16 kernel (boards on the MFMA's N dimension = the lane), and the hand-off between
+// layers is even simpler here: the B operand of this instruction is ONE f32 per lane, B[k = lane >> 4][col = lane & 15],
+// and a C/D tile leaves D[row = 4g + reg][col c] on lane (c, g) -- so register `reg` of output tile m IS the B operand
+// of the next layer's k-step {16m + 4g + reg : g = 0..3}.  No conversion, no lane movement; the weights are pre-packed
+// on the host in that k order.
+//
+// The f32 weights are 320 KB, twice the CU's LDS, so they stream through it: six chunks per pass (layer 1 in two
+// halves, layers 2-4, the head), double-buffered -- chunk j+1 arrives by LDS-DMA while the eight waves of the
+// workgroup multiply chunk j, one barrier per chunk.  Every wave needs every chunk for its 32 boards, so a pass costs
+// the CU 320 KB of L2 reads per 256 boards: noise beside 2496 MFMAs per wave.
+//
+// Fragment maps: A: lane holds A[row c][k = g] of the k-step; B: B[k = g][col c]; C/D: D[row = 4g + reg][col c].
+// Hidden layers: k-step q = 4m + reg takes k = 16m + 4g + reg on lane group g.  Layer 1 (free to choose, its B values are
+// made from the board's bits): k-step q takes internal feature 4q + g.
+#include "tpl_internal.h"
+#include "tpl_policy.h"
+
+#include <cstring>
+#include <vector>
+
+namespace tpl {
+namespace pf32 {
+
+using namespace tpl::p16;
+
+constexpr int kKs1 = 56;                   // k-steps of 4 in layer 1: 224 = 217 padded
+constexpr int kKsH = 32;                   // k-steps of a hidden layer
+constexpr int kMt = 8;                     // 16-row output tiles of a 128-wide layer
+constexpr int kStepBytes = 64 * 4;         // one A fragment: a float per lane
+
+// chunks, in the order they are used (and laid out in the image)
+constexpr int kChunks = 6;
+constexpr int kChunkBytes[kChunks] = {4 * kKs1 * kStepBytes, 4 * kKs1 * kStepBytes, kMt * kKsH * kStepBytes,
+                                      kMt * kKsH * kStepBytes, kMt * kKsH * kStepBytes, kKsH * kStepBytes};
+constexpr int kChunkOff[kChunks] = {0, 57344, 114688, 180224, 245760, 311296};
+constexpr int kOffB = 319488;
+constexpr int kImageBytes = kOffB + (4 * kHidden + 16) * 4;          // 321,600
+constexpr int kBufBytes = 65536;
+static_assert(kChunkOff[5] + kChunkBytes[5] == kOffB && kChunkBytes[2] == kBufBytes, "chunk table");
+
+// A fragments are stored four k-steps to a 16-byte piece per lane: [(tile, q4)][lane][q & 3]
+static inline size_t frag_index(int tile, int ks4, int q4, int lane, int r) { return (((size_t)tile * ks4 + q4) * 64 + lane) * 4 + r; }
+
+}  // namespace pf32
+}  // namespace tpl
+
+using namespace tpl;
+using namespace tpl::pf32;
+
+extern "C" size_t tpl_policy_image_bytes_f32(void) { return (size_t)kImageBytes; }
+
+extern "C" int tpl_policy_pack_f32(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                                   const float* b3, const float* w4, const float* b4, const float* w5, const float* b5,
+                                   void* image) {
+    if (!w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !w4 || !b4 || !w5 || !b5 || !image)
+        return fail_msg(TPL_ERR_ARG, "tpl_policy_pack_f32: null pointer");
+    std::vector<float> img((size_t)kImageBytes / 4, 0.0f);
+    // layer 1: tiles 0-3 in chunk 0, tiles 4-7 in chunk 1; k-step q of lane group g = internal feature 4q + g
+    for (int m = 0; m < kMt; ++m)
+        for (int q = 0; q < kKs1; ++q)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int c = lane & 15, g = lane >> 4;
+                const int k = std_feature(4 * q + g);
+                const float v = k >= 0 ? w1[(size_t)(16 * m + c) * kObs + k] : 0.0f;
+                img[kChunkOff[m >> 2] / 4 + frag_index(m & 3, kKs1 / 4, q >> 2, lane, q & 3)] = v;
+            }
+    // hidden layers and the head: k-step q = 4 * (input tile) + reg takes k = 16 * (input tile) + 4g + reg
+    auto pack_hidden = [&](int off, const float* w, int rows, int tiles) {
+        for (int m = 0; m < tiles; ++m)
+            for (int q = 0; q < kKsH; ++q)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int c = lane & 15, g = lane >> 4;
+                    const int k = 16 * (q >> 2) + 4 * g + (q & 3), row = 16 * m + c;
+                    img[off / 4 + frag_index(m, kKsH / 4, q >> 2, lane, q & 3)] = row < rows ? w[(size_t)row * kHidden + k] : 0.0f;
+                }
+    };
+    pack_hidden(kChunkOff[2], w2, kHidden, kMt);
+    pack_hidden(kChunkOff[3], w3, kHidden, kMt);
+    pack_hidden(kChunkOff[4], w4, kHidden, kMt);
+    pack_hidden(kChunkOff[5], w5, kOut, 1);
+    float* bias = img.data() + kOffB / 4;
+    const float* bs[4] = {b1, b2, b3, b4};
+    for (int l = 0; l < 4; ++l)
+        for (int k = 0; k < kHidden; ++k) bias[l * kHidden + k] = bs[l][k];
+    for (int k = 0; k < kOut; ++k) bias[4 * kHidden + k] = b5[k];
+    std::memcpy(image, img.data(), (size_t)kImageBytes);
+    return TPL_OK;
+}
+
+namespace tpl {
+namespace pf32 {
+
+// `bytes` of the image -> LDS by LDS-DMA, spread over the workgroup's waves (each instruction moves 64 consecutive
+// 16-byte pieces to a wave-uniform LDS base).  Completion is the caller's next barrier.
+template <int kThreads>
+__device__ __forceinline__ void start_chunk(uint4* dst, const uint4* src, int bytes) {
+    typedef __attribute__((address_space(1))) const void global_ptr;
+    typedef __attribute__((address_space(3))) void lds_ptr;
+    const int pieces = bytes / 16;
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    for (int chunk = wave; chunk * 64 < pieces; chunk += kThreads / 64) {
+        const int i = chunk * 64 + lane;
+        if (i < pieces) __builtin_amdgcn_global_load_lds((global_ptr*)(src + i), (lds_ptr*)(dst + chunk * 64), 16, 0, 0);
+    }
+}
+
+// kTiles output tiles of one layer from the chunk at `w`: acc = bias; acc += W[tile rows][k-step] x xin[k-step].
+// xin[t][q4] holds the four B values of k-steps 4 q4 .. 4 q4 + 3 for N tile t (for a hidden layer: the previous layer's
+// output tile q4 as it left the matrix core).
+template <int kTiles, int kKs4, bool kRelu>
+__device__ __forceinline__ void dense(const uint8_t* w, const float* bias, int lane, int g, const f32x4 (&xin)[2][kKs4],
+                                      f32x4* xout0, f32x4* xout1) {
+#pragma unroll
+    for (int m = 0; m < kTiles; ++m) {
+        const float4 b = *(const float4*)(bias + 16 * m + 4 * g);
+        f32x4 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w; }
+#pragma unroll
+        for (int q4 = 0; q4 < kKs4; ++q4) {
+            const float4 a = *(const float4*)(w + (size_t)((m * kKs4 + q4) * 64 + lane) * 16);     // one ds_read_b128
+            const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], xin[t][q4][r], acc[t], 0, 0, 0);
+            // (left alone the scheduler hoists dozens of fragment reads ahead of the multiplies and runs out of registers)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (kRelu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][r] = fmaxf(acc[t][r], 0.0f);
+            }
+        }
+        xout0[m] = acc[0];
+        xout1[m] = acc[1];
+    }
+}
+
+// kTiles output tiles of LAYER 1 from the chunk at `w`.  The B values are made from the boards' feature bits as they are
+// needed (k-step q of lane group g = bit 4 (q & 7) + g of feature word q >> 3; the two counters -- features 214, 215 =
+// k-step 53, groups 2 and 3 -- enter as numbers), so the k-steps run outermost and the tiles' accumulators stay live.
+template <int kTiles>
+__device__ __forceinline__ void dense_first(const uint8_t* w, const float* bias, int lane, int g, const uint32_t (&fb)[2][8],
+                                            f32x4* xout0, f32x4* xout1) {
+    f32x4 acc[2][kTiles];
+#pragma unroll
+    for (int m = 0; m < kTiles; ++m) {
+        const float4 b = *(const float4*)(bias + 16 * m + 4 * g);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { acc[t][m][0] = b.x; acc[t][m][1] = b.y; acc[t][m][2] = b.z; acc[t][m][3] = b.w; }
+    }
+    uint32_t u[2][7];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) u[t][k] = fb[t][k] >> g;
+#pragma unroll
+    for (int q4 = 0; q4 < kKs1 / 4; ++q4) {
+        float x[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 4 * q4 + r;
+                float v = (float)((u[t][q >> 3] >> (4 * (q & 7))) & 1u);
+                if (q == 53) {
+                    const float lrem = __uint_as_float(fb[t][7] << 16), mrem = __uint_as_float(fb[t][7] & 0xFFFF0000u);
+                    v = g == 2 ? lrem : g == 3 ? mrem : v;
+                }
+                x[t][r] = v;
+            }
+#pragma unroll
+        for (int m = 0; m < kTiles; ++m) {
+            const float4 a = *(const float4*)(w + (size_t)((m * (kKs1 / 4) + q4) * 64 + lane) * 16);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], x[t][r], acc[t][m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < kTiles; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc[0][m][r] = fmaxf(acc[0][m][r], 0.0f); acc[1][m][r] = fmaxf(acc[1][m][r], 0.0f); }
+        xout0[m] = acc[0][m];
+        xout1[m] = acc[1][m];
+    }
+}
+
+struct PolicyF32Args {
+    const uint4* plane_a;
+    const uint4* plane_b;
+    int64_t n;
+    int32_t L, M;
+    const uint4* image;
+    uint8_t* action;
+    float* logits;
+};
+
+constexpr int kWaves = 8;
+
+__global__ __launch_bounds__(64 * kWaves) void policy_f32_kernel(const PolicyF32Args p) {
+    __shared__ uint4 s_buf[2][kBufBytes / 16];
+    __shared__ float s_bias[4 * kHidden + 16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int64_t tiles = (p.n + 31) / 32;
+    const int64_t tile_step = (int64_t)gridDim.x * kWaves;
+    // every wave of the workgroup makes the same number of passes (the chunk barriers need all of them)
+    const int64_t passes = (tiles - (int64_t)blockIdx.x * kWaves + tile_step - 1) / tile_step;
+    const uint8_t* image = (const uint8_t*)p.image;
+
+    for (int k = threadIdx.x; k < 4 * kHidden + 16; k += 64 * kWaves) s_bias[k] = ((const float*)(image + kOffB))[k];
+    start_chunk<64 * kWaves>(s_buf[0], (const uint4*)(image + kChunkOff[0]), kChunkBytes[0]);
+    __syncthreads();                                             // (its fence waits for the transfers)
+
+    int buf = 0;
+    for (int64_t pass = 0; pass < passes; ++pass) {
+        const int64_t tile = (int64_t)blockIdx.x * kWaves + wave + pass * tile_step;
+        const int64_t b = tile * 32 + (g >> 1) * 16 + c;
+        const bool valid = b < p.n;
+        const int64_t j = valid ? b : p.n - 1;                    // a lane past the end holds the last real board
+        Board s;
+        unpack_board(p.plane_a[j], p.plane_b[j], s);
+        uint32_t own[8], fb[2][8];
+        board_features(s, p.L, p.M, own);
+        both_features(own, g, fb);
+
+        f32x4 xa[2][kMt], xb[2][kMt];
+        // chunk 0: layer 1, tiles 0-3
+        start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[1]), kChunkBytes[1]);
+        dense_first<4>((const uint8_t*)s_buf[buf], s_bias, lane, g, fb, &xa[0][0], &xa[1][0]);
+        __syncthreads(); buf ^= 1;
+        // chunk 1: layer 1, tiles 4-7
+        start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[2]), kChunkBytes[2]);
+        dense_first<4>((const uint8_t*)s_buf[buf], s_bias + 64, lane, g, fb, &xa[0][4], &xa[1][4]);
+        __syncthreads(); buf ^= 1;
+        // chunks 2-4: the hidden layers
+        start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[3]), kChunkBytes[3]);
+        dense<kMt, kMt, true>((const uint8_t*)s_buf[buf], s_bias + 1 * kHidden, lane, g, xa, &xb[0][0], &xb[1][0]);
+        __syncthreads(); buf ^= 1;
+        start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[4]), kChunkBytes[4]);
+        dense<kMt, kMt, true>((const uint8_t*)s_buf[buf], s_bias + 2 * kHidden, lane, g, xb, &xa[0][0], &xa[1][0]);
+        __syncthreads(); buf ^= 1;
+        start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[5]), kChunkBytes[5]);
+        dense<kMt, kMt, true>((const uint8_t*)s_buf[buf], s_bias + 3 * kHidden, lane, g, xa, &xb[0][0], &xb[1][0]);
+        __syncthreads(); buf ^= 1;
+        // chunk 5: the head; the next pass's first chunk arrives under it
+        if (pass + 1 < passes) start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[0]), kChunkBytes[0]);
+        f32x4 lg[2];
+        dense<1, kMt, false>((const uint8_t*)s_buf[buf], s_bias + 4 * kHidden, lane, g, xb, &lg[0], &lg[1]);
+        __syncthreads(); buf ^= 1;
+
+        const uint32_t act0 = pick_action(lg[0], g, lane), act1 = pick_action(lg[1], g, lane);
+        const uint32_t action = (g >> 1) ? act1 : act0;
+        if (p.logits) {
+            // rows 4g + reg of board (t, c) live on lane (c, g) for both t
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int64_t bt = tile * 32 + t * 16 + c;
+                if (bt < p.n) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (4 * g + k < kOut) p.logits[bt * kOut + 4 * g + k] = lg[t][k];
+                }
+            }
+        }
+        if (valid && (g & 1) == 0) p.action[b] = (uint8_t)action;
+    }
+}
+
+}  // namespace pf32
+}  // namespace tpl
+
+extern "C" int tpl_policy_act_f32(tpl_env* e, const void* image, uint8_t* action, float* logits, void* stream) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!image || !action) return fail_msg(TPL_ERR_ARG, "image/action is null");
+    if (((uintptr_t)image & 15u) != 0) return fail_msg(TPL_ERR_ARG, "image must be 16-byte aligned");
+    DeviceGuard guard(e->device);
+    PolicyF32Args p{};
+    p.plane_a = e->plane_a; p.plane_b = e->plane_b; p.n = e->n; p.L = e->L; p.M = e->M;
+    p.image = (const uint4*)image; p.action = action; p.logits = logits;
+    // one resident workgroup per CU, eight waves of 32 boards, looping over board tiles
+    const int64_t groups = ((e->n + 31) / 32 + kWaves - 1) / kWaves;
+    hipLaunchKernelGGL(policy_f32_kernel, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(64 * kWaves), 0, (hipStream_t)stream, p);
+    TPL_HIP(hipGetLastError());
+    return TPL_OK;
+}

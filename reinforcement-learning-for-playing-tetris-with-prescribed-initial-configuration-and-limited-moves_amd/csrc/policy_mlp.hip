@@ -30,6 +30,7 @@
 // on lane (c, g); two consecutive tiles give the eight values a B fragment of the next layer needs, in the
 // permuted order k = 32s + 16(j >> 2) + 4g + (j & 3) -- which is the order the weights are pre-packed in.
 #include "tpl_internal.h"
+#include "tpl_policy.h"
 #include "tpl_step.h"
 
 #include <cstring>
@@ -39,12 +40,8 @@ namespace tpl {
 namespace p16 {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) short i16x2;
 
-constexpr int kHidden = 128, kObs = 217, kOut = 14;
 constexpr int kKs1 = 7;        // k-steps of 32 in layer 1: 224 = 217 padded
 constexpr int kKsH = 4;        // k-steps of a hidden layer
 constexpr int kMt = 8;         // 16-row output tiles of a 128-wide layer
@@ -70,11 +67,6 @@ static inline int frag_k(int s, int g, int j) { return 32 * s + 16 * (j >> 2) + 
 // Layer 1 is free to choose, because its B fragments are made from bits: the two elements of register i come from
 // bits 4g + i and 16 + 4g + i of feature word s, so that one shift and one mask turn the word into the register.
 static inline int frag_k1(int s, int g, int j) { return 32 * s + 4 * g + (j >> 1) + 16 * (j & 1); }
-
-static inline int std_feature(int k) {     // internal layer-1 feature -> tpl_expand_obs index, -1 for a pad
-    if (k < 200) return (k % 20) * 10 + (k / 20);
-    return k < kObs ? k : -1;
-}
 
 }  // namespace p16
 }  // namespace tpl
@@ -124,11 +116,6 @@ extern "C" int tpl_policy_pack(const float* w1, const float* b1, const float* w2
 namespace tpl {
 namespace p16 {
 
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-    f32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-
 // ReLU on two packed bf16 values: a negative bf16 is a negative int16, so one v_pk_max_i16 clears it
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
     const i16x2 zero = {0, 0};
@@ -152,21 +139,6 @@ __device__ __forceinline__ void load_image(uint4* s_image, const uint4* image) {
             __builtin_amdgcn_global_load_lds((global_ptr*)(image + i), (lds_ptr*)(s_image + chunk * 64), 16, 0, 0);
     }
     __syncthreads();                                            // (its fence waits for the transfers)
-}
-
-// a board -> its cell bit vector in the internal order (bit 20x + y; extras as bits 200..213 and 216) and the two
-// numeric features (L_rem, M_rem) as a packed bf16 pair; f[7] = that pair
-__device__ __forceinline__ void board_features(const Board& s, int L, int M, uint32_t (&f)[8]) {
-    f[0] = s.c[0] | (s.c[1] << 20);
-    f[1] = (s.c[1] >> 12) | (s.c[2] << 8) | (s.c[3] << 28);
-    f[2] = (s.c[3] >> 4) | (s.c[4] << 16);
-    f[3] = (s.c[4] >> 16) | (s.c[5] << 4) | (s.c[6] << 24);
-    f[4] = (s.c[6] >> 8) | (s.c[7] << 12);
-    f[5] = s.c[8] | (s.c[9] << 20);
-    const uint32_t cur = s.window & 7u, nxt = (s.window >> 3) & 7u;
-    f[6] = (s.c[9] >> 12) | ((1u << (8 + cur)) & 0x7F00u) | ((1u << (15 + nxt)) & 0x3F8000u) |
-           (s.state != ST_RUNNING ? 1u << 24 : 0u);
-    f[7] = pack_bf16((float)(L - (int)s.lines), (float)(M - (int)s.moves));   // features 214, 215
 }
 
 __device__ __forceinline__ bf16x8 a_frag(const uint8_t* lds, int w_off, int q, int lane) {
@@ -263,29 +235,6 @@ __device__ __forceinline__ void policy_logits(const uint8_t* lds, int lane, int 
     dense<1, kKsH, false>(lds, kOffW5, bias + 4 * kHidden, lane, g, xb, none, logits);
 }
 
-// argmax of outputs 0..3 (rotation, on the g = 0 lane) and of outputs 4..13 (location, spread over g = 1, 2, 3),
-// lowest index on ties, NaN never wins.  All four lanes of a board return its action.
-__device__ __forceinline__ uint32_t pick_action(const f32x4& c, int g, int lane) {
-    float rv = -INFINITY; int ri = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (c[k] > rv) { rv = c[k]; ri = k; }
-    float lv = -INFINITY; int li = 99;
-    const int first = 4 * g - 4;                         // location index of c[0] on this lane (g >= 1)
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (g >= 1 && first + k < 10 && c[k] > lv) { lv = c[k]; li = first + k; }
-#pragma unroll
-    for (int step = 16; step <= 32; step <<= 1) {
-        const float ov = __shfl_xor(lv, step);
-        const int oi = __shfl_xor(li, step);
-        if (ov > lv || (ov == lv && oi < li)) { lv = ov; li = oi; }
-    }
-    if (li == 99) li = 0;
-    const int rot = __shfl(ri, lane & 15);               // the g = 0 lane of this column
-    return (uint32_t)(rot * 10 + li);
-}
-
 struct PolicyArgs {
     const uint4* plane_a;
     const uint4* plane_b;
@@ -296,16 +245,6 @@ struct PolicyArgs {
     float* logits;
     unsigned long long* diag;   // diagnostic build only
 };
-
-// features of both boards of column c: the lane's own board (t = g >> 1) and the one held by lane ^ 32
-__device__ __forceinline__ void both_features(const uint32_t (&own)[8], int g, uint32_t (&fb)[2][8]) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const uint32_t other = __shfl_xor(own[k], 32);
-        fb[0][k] = (g >> 1) == 0 ? own[k] : other;
-        fb[1][k] = (g >> 1) == 1 ? own[k] : other;
-    }
-}
 
 // two waves per SIMD.  (Twelve waves -- three per SIMD, the kernel fits 168 registers -- measured 6 % slower; halving
 // the A-fragment LDS reads, as a timing experiment, gained 3 %: the kernel is bound by neither occupancy nor LDS
@@ -435,7 +374,10 @@ __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q
             s.window = 0xFFFFFFFFu; s.window_hi = 0xFu; s.state = ST_LOST_LIMIT; s.lines = 0; s.moves = 0; s.slot = 0;   // frozen filler
         }
         // the tile's 32 boards are one clock group
-        const unsigned long long clock = valid ? p.clock[b >> kClockShift] : 0ull;
+        // (wave-uniform: kept in scalar registers)
+        unsigned long long clock = p.clock[tile];
+        clock = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(clock >> 32)) << 32) |
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)clock);
         const uint8_t* rec = current_record(s, p, (uint32_t)b, clock);
         for (uint32_t t = 0; t < q.T; ++t) {
             if (q.states_a && valid && writer) {

@@ -307,18 +307,26 @@ class BatchedTetris:
 
     def policy_act(self, image: torch.Tensor, out: Optional[torch.Tensor] = None, logits: Optional[torch.Tensor] = None):
         """Fused observation -> Model(217, 14) -> action on the matrix cores.  `image` is the device copy of
-        pack_policy(...).  Returns the uint8 actions; fills `logits` ([N, 14] float32) when given."""
+        pack_policy(...): the bf16 image (weights and hidden activations rounded to bf16) or the float32 one
+        (pack_policy(..., f32=True): the reference's arithmetic width, about 1/8 of the rate) -- told apart by size.
+        Returns the uint8 actions; fills `logits` ([N, 14] float32) when given."""
         if out is None:
             out = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
         self._own(out, torch.uint8, "out")
-        self._image(image)
+        f32 = self._image(image, either=True)
         if logits is not None:
             self._own(logits, torch.float32, "logits", (self.num_envs, 14))
-        check(self._lib.tpl_policy_act(self._h, _ptr(image), _ptr(out), _ptr(logits), self._stream()))
+        act = self._lib.tpl_policy_act_f32 if f32 else self._lib.tpl_policy_act
+        check(act(self._h, _ptr(image), _ptr(out), _ptr(logits), self._stream()))
         return out
 
-    def _image(self, image: torch.Tensor) -> torch.Tensor:
-        return self._own(image, torch.uint8, "image (the device copy of pack_policy(...))", (self._lib.tpl_policy_image_bytes(),))
+    def _image(self, image: torch.Tensor, either: bool = False) -> bool:
+        """Checks a policy image; returns True for the float32 kind (accepted only where `either`)."""
+        if either and isinstance(image, torch.Tensor) and image.numel() == self._lib.tpl_policy_image_bytes_f32():
+            self._own(image, torch.uint8, "image (the device copy of pack_policy(..., f32=True))", (image.numel(),))
+            return True
+        self._own(image, torch.uint8, "image (the device copy of pack_policy(...))", (self._lib.tpl_policy_image_bytes(),))
+        return False
 
     def explore_actions(self, action: torch.Tensor, epsilon: float, seed: int = 0, step: int = 0) -> torch.Tensor:
         """Epsilon-greedy in place: action[i] becomes uniform in [0, 40) with probability epsilon."""

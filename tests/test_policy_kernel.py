@@ -252,3 +252,106 @@ def test_actor_megakernel_at_the_benched_size(T, oracle):
     assert mega.stats() == ref.stats() == cpu.stats() and mega.stats()["episodes"] > n
     for e in envs:
         e.terminate()
+
+
+# ------------------------------------------------------------------------------------------------- float32 operands
+@pytest.mark.parametrize("n", [1, 31, 64, 1000, 70000])
+def test_f32_kernel_exact_integer_weights(T, n):
+    """The float32 kernel (csrc/policy_f32.hip) on the same exact construction: every intermediate value is a small
+    integer, so the logits must equal the integer reference bit for bit -- this pins its own wiring (k order of the
+    accumulator hand-off, weight packing, chunk streaming through LDS, features from the packed state)."""
+    import torch
+    rng = np.random.default_rng(100 + n)
+
+    def sparse(out, inn, nnz):
+        w = np.zeros((out, inn), np.float32)
+        for r in range(out):
+            w[r, rng.choice(inn, nnz, replace=False)] = rng.choice([-1, 1], nnz)
+        return w
+    w1 = np.concatenate([sparse(128, 214, 3), np.zeros((128, 3), np.float32)], 1)
+    w1[::5, 216] = 1
+    w1[3, 214] = 1; w1[7, 215] = -1
+    params = [(w1, rng.integers(0, 2, 128).astype(np.float32)),
+              (sparse(128, 128, 2), rng.integers(-1, 2, 128).astype(np.float32)),
+              (sparse(128, 128, 2), rng.integers(-1, 2, 128).astype(np.float32)),
+              (sparse(128, 128, 2), rng.integers(-1, 2, 128).astype(np.float32)),
+              (sparse(14, 128, 2), rng.integers(-2, 3, 14).astype(np.float32))]
+    env = _env(T, n)
+    obs = env.observe().cpu().numpy()
+    want = _reference(obs, params, round_hidden=False)
+    assert np.all(want == np.round(want))
+    image = torch.from_numpy(T.pack_policy(params, f32=True)).to(env.device)
+    logits = torch.full((n, 14), float("nan"), device=env.device)
+    action = env.policy_act(image, logits=logits)
+    assert np.array_equal(logits.cpu().numpy(), want.astype(np.float32))
+    assert np.array_equal(action.cpu().numpy(), _decode(want))
+    env.terminate()
+
+
+def test_f32_kernel_against_a_float32_torch_module(T):
+    """The reference's policy is a float32 nn.Linear stack (model/model.py:9-20).  The float32 kernel against that
+    very module in torch float32 AND a float64 evaluation of the same weights: what separates them is the order of
+    float32 summation only.  Tolerance: |logit - ref64| <= 2e-5 * (1 + max|ref64|); the torch float32 result must sit
+    inside the same band (it is no closer to float64 than the kernel is), and the chosen actions agree wherever the
+    float64 margin between best and runner-up exceeds twice the tolerance.  The bf16 kernel on the same weights misses
+    this band by three orders of magnitude."""
+    import torch
+    n = 30000
+    torch.manual_seed(3)
+    model = T.PolicyMLP()                                        # torch's default initialisation, as the reference would
+    with torch.no_grad():
+        model.layer5.weight.mul_(8.0)                            # spread the logits out
+    env = _env(T, n)
+    obs = env.observe()
+    with torch.no_grad():
+        ref32 = model.to(env.device)(obs).cpu().numpy().astype(np.float64)
+        ref64 = model.double()(obs.double()).cpu().numpy()
+    model = model.float().cpu()
+    logits = torch.empty((n, 14), device=env.device)
+    action = env.policy_act(T.actor.policy_image(model, env.device, f32=True), logits=logits).cpu().numpy()
+    got = logits.cpu().numpy().astype(np.float64)
+    tol = 2e-5 * (1.0 + np.abs(ref64).max())
+    assert np.abs(got - ref64).max() <= tol, (np.abs(got - ref64).max(), tol)
+    assert np.abs(ref32 - ref64).max() <= tol
+    def margin(block):
+        srt = np.sort(block, axis=1)
+        return srt[:, -1] - srt[:, -2]
+    clear = (margin(ref64[:, :4]) > 2 * tol) & (margin(ref64[:, 4:]) > 2 * tol)
+    assert clear.mean() > 0.99 and np.array_equal(action[clear], _decode(ref64)[clear])
+    lg16 = torch.empty((n, 14), device=env.device)
+    env.policy_act(T.actor.policy_image(model, env.device), logits=lg16)
+    assert np.abs(lg16.cpu().numpy() - ref64).max() > 100 * tol            # bf16 operands are not "the same arithmetic"
+    env.terminate()
+
+
+def test_f32_actor_drives_the_environment(T, oracle):
+    """Actor(fused=True, dtype=float32): float32 policy kernel -> step kernel; the recorded actions replayed through the
+    oracle give the same rewards, dones and boards, and equal what the float32 torch module decides where its margin is
+    clear."""
+    import torch
+    L, M, n, seed = 10, 40, 8192, 23
+    torch.manual_seed(2)
+    model = T.PolicyMLP()
+    env = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True)
+    rows, pieces = env.synthetic_configs(1024)
+    env.load_configs(rows, pieces)
+    env.reset()
+    actor = T.Actor(env, model, dtype=torch.float32, use_graph=False, fused=True)
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_pool(rows.cpu().numpy().view(np.uint16), pieces.cpu().numpy())
+    cpu.set_options(auto_reset=True, assign_mode=0)
+    cpu.reset()
+    agree = []
+    for t in range(30):
+        with torch.no_grad():
+            lg = actor.model(env.observe()).cpu().numpy()
+        actor.step()
+        a = actor.action.cpu().numpy()
+        agree.append((a == _decode(lg)).mean())
+        r_c, d_c = cpu.step(a)
+        assert np.array_equal(actor.reward.cpu().numpy(), r_c) and np.array_equal(actor.done.cpu().numpy(), d_c), t
+    assert min(agree) > 0.995
+    got = {k: v.cpu().numpy() for k, v in env.packed_state().items()}
+    for k, v in cpu.get_state().items():
+        assert np.array_equal(got[k].view(np.uint16) if k == "rows" else got[k], v), k
+    env.terminate()
