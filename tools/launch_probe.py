@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--boards", type=int, default=1 << 20)
     ap.add_argument("--launches", type=int, default=400)
     ap.add_argument("--idle", type=float, default=1.0)
+    ap.add_argument("--d2h", type=int, default=0, help="read the statistics back (a device-to-host copy) right before each round")
     args = ap.parse_args()
     import torch
     import tetris_piclim as T
@@ -40,6 +41,9 @@ def main():
     out = {"boards": n, "launches": K}
     for name, idle in (("after_idle", args.idle), ("back_to_back", 0.0), ("after_idle_again", args.idle)):
         time.sleep(idle)
+        if args.d2h:
+            env.stats()
+            torch.cuda.synchronize(dev)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
         ev[0].record()
         for t in range(K):
