@@ -288,6 +288,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
     const StepArgs& p = q.s;
     __shared__ ShapeWord s_shape[32];
     __shared__ uint32_t s_stat[4];
+    __shared__ uint32_t s_cols[kBlock / 64][kLdsCols][kLdsStride];      // the boards' column words between moves (tpl_device.h)
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool valid = i < p.n;
     uint4 A = make_uint4(0, 0, 0, 0), B = A;
@@ -309,6 +310,10 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
     if (valid) {
         Board s;
         unpack_board<true>(A, B, s);
+        uint32_t* cols = &s_cols[threadIdx.x >> 6][0][threadIdx.x & 63];
+        lds_store_cols(cols, s.c);
+#pragma unroll
+        for (int k = kCols; k < kLdsCols; ++k) cols[k * kLdsStride] = kSentinelBit;
         const uint8_t* rec = current_record(s, p, (uint32_t)i, clock);
         float rsum = 0.0f;
         // per-step streams are walked with running pointers (a 64-bit multiply-add per step and stream otherwise)
@@ -329,13 +334,14 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
             uint32_t rot, loc;
             split_small_action(act, rot, loc);
             float reward;
-            const bool done = advance_board<kAutoReset, true>(s, rec, rot, loc, p, (uint32_t)i, clock + k, s_shape, reward, tally);
+            const bool done = advance_board_lds<kAutoReset>(s, cols, rec, rot, loc, p, (uint32_t)i, clock + k, s_shape, reward, tally);
             rsum = rsum + reward;
             // (non-temporal: a trajectory is written once and consumed later, by someone else)
             if (want_reward) { __builtin_nontemporal_store(reward, reward_ptr); reward_ptr += p.n; }
             if (want_done) { __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), done_ptr); done_ptr += p.n; }
             act = act_next;
         }
+        lds_load_cols(cols, s.c);
         pack_board<true>(s, A, B);
         p.plane_a[i] = A;
         p.plane_b[i] = B;

@@ -299,6 +299,82 @@ __device__ __forceinline__ uint32_t move_board(Board& s, const ShapeWord* shape,
     return n;
 }
 
+// ---- the move with the board's columns in LDS (the K-steps-per-launch kernel) ----------------------------------
+// move_board pays for the fact that a lane cannot index its registers: the tops of all ten columns are taken and packed
+// so that the piece's four can be picked out, and the piece is ORed into all ten columns through ten nibble extracts.
+// LDS is memory a lane CAN index.  The multi-step kernel keeps the column words in LDS between moves, lane-major
+// (column k of lane l at word k * 64 + l: whatever column a lane asks for, its bank is its lane number -- no
+// conflicts): a move reads the four columns under the piece, takes four tops, writes the four columns back with the
+// piece in, then reads all ten for the full-row test.  The words carry the sentinel bit; three pad columns (holding
+// only the sentinel) sit behind column 9 for pieces narrower than four at the right edge.
+constexpr int kLdsCols = kCols + 3;
+constexpr int kLdsStride = 64;            // words between consecutive columns of a lane
+
+__device__ __forceinline__ void lds_store_cols(uint32_t* cols, const uint32_t (&c)[kCols]) {
+#pragma unroll
+    for (int k = 0; k < kCols; ++k) cols[k * kLdsStride] = c[k];
+}
+__device__ __forceinline__ void lds_load_cols(const uint32_t* cols, uint32_t (&c)[kCols]) {
+#pragma unroll
+    for (int k = 0; k < kCols; ++k) c[k] = cols[k * kLdsStride];
+}
+
+// Tetris.move (:354-422) as move_board<true>, on the column words at `cols` (this lane's column 0).  `s.c` is not used.
+__device__ __forceinline__ uint32_t move_board_lds(Board& s, uint32_t* cols, const ShapeWord* shape, uint32_t rot, uint32_t loc,
+                                                   uint32_t L, uint32_t M, bool& topout) {
+    const ShapeWord sh = shape[(s.window & 7u) * 4u + (rot & 3u)];                 // get_tetromino (:60-61, :359-360)
+    const uint32_t w = (sh.x >> 16) & 7u;
+    const uint32_t h = (sh.x >> 19) & 7u;
+    loc = min(loc, (uint32_t)kCols - w);                                           // right clamp only (:363-364)
+
+    // calculate_drop_deltas (:427-433) on the piece's own columns
+    uint32_t* under = cols + loc * kLdsStride;
+    uint32_t c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = under[j * kLdsStride];
+    uint32_t best = 0xFFu;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) best = min(best, (uint32_t)__builtin_ctz(c[j]) + ((sh.y >> (8 * j)) & 0xFFu));
+    const int drop = (int)best - 4;                                                // calculate_drop (:424-425)
+    topout = drop < 0;                                                             // (:372-374)
+    const uint32_t dshift = topout ? 0u : (uint32_t)drop;
+
+    // lock (:377-378): the four columns go back with the piece's column patterns ORed in (nothing on a top-out)
+    const uint32_t pattern = topout ? 0u : sh.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) under[j * kLdsStride] = c[j] | (((pattern >> (4 * j)) & 0xFu) << dshift);
+    s.moves += topout ? 0u : 1u;                                                   // (:379)
+
+    // full rows among the piece's rows only (:382-386)
+    uint32_t b[kCols];
+    lds_load_cols(cols, b);
+    uint32_t full = b[0];
+#pragma unroll
+    for (int k = 1; k < kCols; ++k) full &= b[k];
+    uint32_t clear = topout ? 0u : (full & (((1u << h) - 1u) << dshift));
+    const uint32_t n = (uint32_t)__builtin_popcount(clear);
+
+    // compaction (:397-407), on the registers, written back when it ran
+    if (clear) {
+        do {
+            const uint32_t r = (uint32_t)__builtin_ctz(clear);
+            clear &= clear - 1u;
+            const uint32_t above = (1u << r) - 1u;          // rows 0..r-1
+            const uint32_t keep = ~((above << 1) | 1u);     // rows r+1.. (and the sentinel)
+#pragma unroll
+            for (int k = 0; k < kCols; ++k) b[k] = (b[k] & keep) | ((b[k] & above) << 1);
+        } while (clear);
+        lds_store_cols(cols, b);
+    }
+    s.lines += n;                                                                  // (:409)
+
+    // terminal tests: no-clear exit (:389-394), win before move limit (:415-422)
+    const bool won = !topout && n != 0u && s.lines >= L;
+    const bool limit = !topout && !won && s.moves >= M;
+    s.state = topout ? ST_LOST_TOPOUT : won ? ST_WON : limit ? ST_LOST_LIMIT : ST_RUNNING;
+    return n;
+}
+
 // ---- counter-based generator (the synthetic workload of SURVEY 8d; DESIGN.md states the function) --------
 __host__ __device__ __forceinline__ uint64_t sm64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ULL;

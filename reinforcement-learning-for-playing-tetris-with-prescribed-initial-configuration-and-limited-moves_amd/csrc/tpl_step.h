@@ -160,6 +160,37 @@ __device__ __forceinline__ bool advance_board(Board& s, const uint8_t*& rec, uin
     return done;
 }
 
+// advance_board with the board's column words in LDS (move_board_lds); everything else as above.
+template <bool kAutoReset>
+__device__ __forceinline__ bool advance_board_lds(Board& s, uint32_t* cols, const uint8_t*& rec, uint32_t rot, uint32_t loc,
+                                                  const StepArgs& p, uint32_t i, uint64_t clock, const ShapeWord* shape,
+                                                  float& reward, Tally& tally) {
+    reward = 0.0f;
+    if (s.state != ST_RUNNING) return true;      // frozen
+    const uint32_t tenth = tenths(s.moves + 1u);
+    const bool refill = window_runs_out(tenth) && (p.n_cfg[0] | p.n_cfg[1]) != 0u;
+    uint64_t word = 0;
+    if (refill) word = piece_word_at(rec, window_word(tenth));
+    bool topout;
+    const uint32_t n_clear = move_board_lds(s, cols, shape, rot, loc, p.L, p.M, topout);
+    next_window(s, refill, word);
+    reward = step_reward(p, n_clear, s.state);
+    const bool done = s.state != ST_RUNNING;
+    if (done) {
+        tally.episodes += 1u;
+        tally.lines += s.lines;
+        tally.wins += s.state == ST_WON ? 1u : 0u;
+        tally.topouts += s.state == ST_LOST_TOPOUT ? 1u : 0u;
+        if (kAutoReset) {
+            rec = pool_record(p, p.cur_slot, config_of(p, i, clock + 1u, p.cur_slot));
+            const uint4 A2 = ((const uint4*)rec)[0], pb = ((const uint4*)rec)[1];
+            unpack_board<true>(A2, make_uint4(pb.x, pb.y | (p.cur_slot << 30), pb.z, pb.w), s);
+            lds_store_cols(cols, s.c);
+        }
+    }
+    return done;
+}
+
 // block-level flush of the lanes' tallies: LDS atomics, then one sharded 64-bit global atomic per counter.
 // Every thread of the block must call it (it contains a barrier); s_stat[4] must have been zeroed before.
 __device__ __forceinline__ void flush_tally(const Tally& t, uint32_t* s_stat, unsigned long long* stats) {
