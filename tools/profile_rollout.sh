@@ -1,10 +1,10 @@
 #!/bin/bash
 # rocprofv3 kernel stats + PMC for the fused rollout kernel and the policy kernels (separate passes).
 set -u
-OUT=gpurun_out/prof_final
+OUT=gpurun_out/prof_${1:-r02_final}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-B="python3 bench.py --steps 200 --warmup 10 --no-cpu-baseline --chunk 50"
+B="python3 bench.py --steps 200 --warmup 10 --no-cpu-baseline --chunk 50 --carved-pool 0 --no-config1 --sustained 0"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $B > $OUT/kt.log 2>&1 || echo "kt failed"
 for P in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
          "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
@@ -20,7 +20,7 @@ for f in sorted(glob.glob(os.path.join(d, "pmc_*", "*", "*_counter_collection.cs
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
-        if "tpl::" in name and any(k in name for k in ("step_kernel", "rollout_kernel", "policy_kernel")):
+        if "tpl::" in name and any(k in name for k in ("step_kernel", "rollout_kernel", "policy_kernel", "policy_f32_kernel")):
             acc[name.split("(")[0][-60:]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, cs in acc.items():
         for c, v in cs.items():
