@@ -120,7 +120,11 @@ class BatchedTetris:
     def load_configs(self, rows, pieces) -> None:
         """Upload a pool of prescribed (board, pieces) configurations (the supply behind reset()).
 
-        rows: [n_cfg, 20] uint16 (bit x = column x) or [n_cfg, 20, 10] bool; pieces: [n_cfg, M+1] uint8."""
+        rows: [n_cfg, 20] uint16 (bit x = column x) or [n_cfg, 20, 10] bool; pieces: [n_cfg, M+1] uint8.
+        On a live environment this REPLACES the supply without disturbing running boards: the pool goes into the
+        handle's other buffer and becomes current; boards that are mid-episode finish on the one they started from.
+        Raises (TPL_ERR_STATE) if that other buffer may still be in use -- see pool_info().  The work is enqueued on
+        the current stream (PoolRefresher shows the side-stream form)."""
         if not isinstance(rows, torch.Tensor):
             rows = np.asarray(rows)
             if rows.ndim == 3:
@@ -486,13 +490,26 @@ class Tetris:
                  debug: bool = False, configs=None, device="cuda:0", seed: Optional[int] = None, pool_size: int = 64):
         if render:
             raise NotImplementedError("the pygame window of the reference is not part of this build")
-        del warm_reset, framerate                      # the warm-reset workers are replaced by the configuration pool
+        del framerate
         self.L, self.M, self.debug = L, M, debug
         self._solutions = None
         if configs is None:
             seed = int.from_bytes(__import__("os").urandom(4), "little") if seed is None else seed
             rows, pieces, sol, sol_len = _lib.generate_configs(L, M, pool_size, seed=seed, with_solutions=True)
             self._solutions = [[(int(r), int(c)) for r, c in sol[k, : sol_len[k]]] for k in range(pool_size)]
+            if warm_reset and not debug:
+                # the reference's warm-reset queue has a SECOND producer (game/tetris.py:205-211, 482-488): the forward
+                # generator + solver over seeds 0..99 (tetris_algo_main/main.py:39-40), whose winnable games enter the
+                # same queue through translate() -- one random piece put in FRONT of the sequence (:19-20).  Same here:
+                # the winnable ones join the pool.  (With debug=True the pool stays carved-only: only carved
+                # configurations have a recorded `solution`.)
+                fw = _lib.forward_generate(L, M, np.arange(100))
+                win = fw["winnable"]
+                if win.any():
+                    lead = np.random.default_rng(seed).integers(0, 7, (int(win.sum()), 1)).astype(np.uint8)
+                    rows = np.concatenate([rows, fw["rows"][win]])
+                    pieces = np.concatenate([pieces, np.concatenate([lead, fw["sequence"][win]], axis=1)])
+                    self._solutions = None
         else:
             rows, pieces = configs
         self._pieces_host = np.asarray(pieces, dtype=np.uint8).reshape(-1, M + 1)
@@ -501,6 +518,7 @@ class Tetris:
         self._birth = 0                    # the step at which the current episode began
         self._finished = False
         self._board = None
+        self._cache = None                 # packed_state() of the current position (one export per move, not per read)
         self._env.reset()
 
     def _config(self) -> int:
@@ -519,16 +537,18 @@ class Tetris:
         _, done, _ = self._env.move(torch.tensor([rotations], dtype=torch.int64), torch.tensor([location], dtype=torch.int64))
         self._finished = bool(done.item())
         self._steps += 1
-        self._board = None
+        self._board = self._cache = None
 
     def reset(self) -> None:
         self._birth = self._steps
         self._env.reset(mask=[1])
         self._finished = False
-        self._board = None
+        self._board = self._cache = None
 
     def _s(self):
-        return {k: v.cpu().numpy() for k, v in self._env.packed_state().items()}
+        if self._cache is None:
+            self._cache = {k: v.cpu().numpy() for k, v in self._env.packed_state().items()}
+        return self._cache
 
     @property
     def board(self) -> np.ndarray:

@@ -9,6 +9,75 @@ from __future__ import annotations
 import numpy as np
 
 
+class PoolRefresher:
+    """Keeps a running BatchedTetris supplied with FRESH prescribed configurations -- the analogue of the reference's
+    two producer processes feeding the reset queue while games are played (game/tetris.py:195-211, 473-488).
+
+    Carved (solvable) configurations are generated on the device (`tpl_generate_configs_device`, one configuration per
+    lane) on a SIDE stream while the environment steps on its own stream; when a batch is finished and the handle's
+    other pool buffer is out of use, poll() packs the batch into that buffer (still on the side stream), makes the
+    stepping stream wait for exactly that, and the buffer becomes current: episodes that begin afterwards draw from
+    it, boards that are mid-episode finish on the old one.  Batches never repeat: batch b is configurations
+    [b * count, (b + 1) * count) of the generator's counter-based stream.
+
+        feeder = PoolRefresher(env, count=1 << 20)
+        while training:
+            env.step_into(...)
+            feeder.poll()            # cheap: an event query; swaps at most once per M + 1 steps
+    """
+
+    def __init__(self, env, count: int, seed: int = 0, first: int = 0):
+        import torch
+        self.env, self.count, self.seed, self.next_first = env, int(count), int(seed), int(first)
+        self.side = torch.cuda.Stream(env.device)
+        self._ready = None            # event recorded behind the batch being generated
+        self._batch = None
+        self.swaps = 0
+        self.start()
+
+    def start(self) -> None:
+        """Begin generating the next batch on the side stream (returns at once)."""
+        import ctypes as C
+        import torch
+        from ._lib import check
+        env, d, n = self.env, self.env.device, self.count
+        with torch.cuda.stream(self.side):
+            rows = torch.empty((n, 20), dtype=torch.int16, device=d)
+            pieces = torch.empty((n, env.M + 1), dtype=torch.uint8, device=d)
+            status = torch.empty(n, dtype=torch.int32, device=d)
+            nbytes = env._lib.tpl_generate_configs_device_work_bytes(env.M, n)
+            work = torch.empty(nbytes, dtype=torch.uint8, device=d)
+            check(env._lib.tpl_generate_configs_device(env.L, env.M, self.seed, self.next_first, n, 0, C.c_void_p(rows.data_ptr()),
+                                                       C.c_void_p(pieces.data_ptr()), None, None, C.c_void_p(status.data_ptr()),
+                                                       C.c_void_p(work.data_ptr()), nbytes, self.side.cuda_stream))
+            bad = status.sum()                                     # stays on the device until poll() looks at it
+            self._ready = torch.cuda.Event()
+            self._ready.record(self.side)
+        self._batch = (rows, pieces, bad, work, self.next_first)
+        self.next_first += n
+
+    def poll(self) -> bool:
+        """Swap the finished batch in if it is ready and the handle can take it; True when a swap happened."""
+        import torch
+        if self._ready is None or not self._ready.query() or self.env.pool_info()["steps_until_swap"] > 0:
+            return False
+        rows, pieces, bad, _, first = self._batch
+        if int(bad):                                               # the batch is complete: this read does not wait
+            raise RuntimeError(f"{int(bad)} configuration(s) of the batch at {first} hit the generator's iteration cap")
+        main = torch.cuda.current_stream(self.env.device)
+        self.side.wait_stream(main)                                # launches that still read the buffer being replaced
+        with torch.cuda.stream(self.side):
+            self.env.load_configs(rows, pieces)
+        main.wait_stream(self.side)                                # the next step sees the packed pool
+        for mem in self.env._pool_mems:                            # allocated on the side stream, read on the stepping one
+            if mem is not None:
+                mem.record_stream(main)
+        self.last_batch = (rows, pieces, first)
+        self.swaps += 1
+        self.start()
+        return True
+
+
 def save_pool(path: str, L: int, M: int, rows, pieces, solution=None, solution_len=None) -> None:
     rows = np.ascontiguousarray(rows, dtype=np.uint16)
     pieces = np.ascontiguousarray(pieces, dtype=np.uint8)

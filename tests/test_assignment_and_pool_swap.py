@@ -286,3 +286,38 @@ def test_exploration_draw_is_uniform(T):
     chi2 = float(((counts - n / 40) ** 2 / (n / 40)).sum())
     assert chi2 < 39 + 6 * np.sqrt(2 * 39), chi2                  # 39 degrees of freedom; the old draw scored > 4000
     env.terminate()
+
+
+@pytest.mark.gpu
+def test_pool_refresher_feeds_a_running_environment_from_a_side_stream(T, oracle):
+    """PoolRefresher: carved configurations generated on the device on a side stream while the environment steps; each
+    finished batch becomes the current pool.  The oracle is handed the same batches at the same steps and must agree on
+    every reward and done and on the final state; batches are disjoint slices of the generator's stream and equal what the
+    host generator builds for the same indices."""
+    L, M, n, count, seed = 4, 16, 8192, 4096, 9
+    env = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True)
+    first_rows, first_pieces = T.generate_configs(L, M, count, seed=seed, first=0)
+    env.load_configs(first_rows, first_pieces)
+    env.reset()
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_pool(first_rows, first_pieces)
+    cpu.set_options(auto_reset=True, assign_mode=0)
+    cpu.reset()
+    feeder = T.PoolRefresher(env, count, seed=seed, first=count)
+    firsts = []
+    for t in range(150):
+        a = oracle.synth_actions(seed, 0, n, t)
+        _, r_g, d_g, _ = env.step(a, observe=False)
+        r_c, d_c = cpu.step(a)
+        assert np.array_equal(_np(r_g), r_c) and np.array_equal(_np(d_g).astype(np.uint8), d_c), t
+        if t % 5 == 4 and feeder.poll():
+            rows, pieces, first = feeder.last_batch
+            firsts.append(first)
+            rows, pieces = _np(rows).view(np.uint16), _np(pieces)
+            want_rows, want_pieces = T.generate_configs(L, M, count, seed=seed, first=first)
+            assert np.array_equal(rows, want_rows) and np.array_equal(pieces, want_pieces)
+            cpu.set_pool(rows, pieces)
+    _same(_state(env), cpu.get_state(), "refreshed")
+    assert env.stats() == cpu.stats()
+    assert feeder.swaps >= 3 and firsts == [count * (k + 1) for k in range(len(firsts))]
+    env.terminate()

@@ -389,6 +389,45 @@ def _argmax_first(vals):
     return idx
 
 
+def test_compat_tetris_pool_walk_freeze_and_forward_supplier(T):
+    """The single-board `Tetris`: (a) after any number of moves and resets, `pieces` (host list of the entry the wrapper
+    believes it is on) agrees with what the device shows as current / next piece and with the board of that entry --
+    i.e. the wrapper follows the device's sequential assignment by birth step; (b) a finished game is frozen and
+    move() on it raises (the reference keeps mutating: documented divergence); (c) with warm_reset=True the pool also
+    holds the winnable games of the reference's second producer, the forward generator + solver over seeds 0..99,
+    with one random piece in front (game/tetris.py:19-20, 205-211)."""
+    L, M = 5, 20
+    game = T.Tetris(L, M, warm_reset=True, seed=11, pool_size=8)
+    rows_host = np.asarray(game._env._pool[0].cpu().numpy()).view(np.uint16)
+    fw = T.forward_generate(L, M, np.arange(100))
+    n_fw = int(fw["winnable"].sum())
+    assert n_fw > 0 and game._pieces_host.shape[0] == 8 + n_fw
+    assert np.array_equal(rows_host[8:], fw["rows"][fw["winnable"]])
+    assert np.array_equal(game._pieces_host[8:, 1:], fw["sequence"][fw["winnable"]])
+    rng = np.random.default_rng(0)
+    seen = set()
+    for episode in range(12):
+        k = game._config()
+        seen.add(k)
+        board0 = ((rows_host[k][:, None] >> np.arange(10)) & 1).astype(bool)
+        assert np.array_equal(game.board, board0) and game.pieces == game._pieces_host[k].tolist()
+        for _ in range(int(rng.integers(1, 9))):
+            if game.state is not None:
+                break
+            game.move(int(rng.integers(0, 4)), int(rng.integers(0, 10)))
+            st = game.get_state()
+            assert (st[1], st[2]) == tuple(game.pieces[:2])
+        if game.state is not None:
+            frozen = game.board.copy()
+            with pytest.raises(RuntimeError, match="finished game"):
+                game.move(0, 0)
+            assert np.array_equal(game.board, frozen)
+        game.reset()
+        assert game.state is None and game.moves_used == 0 and game.lines_cleared == 0
+    assert len(seen) > 3
+    game.terminate()
+
+
 def test_decode_actions(T):
     import torch
     n = 5000
