@@ -16,9 +16,11 @@ data-path collective; one RCCL all-reduce of the episodic-return counters closes
 Timing: `value` and `ms_per_step` come from a HIP-event pair on the launch stream around EXACTLY K step
 launches (max over ranks), the region bracketed by barrier + synchronize on both sides; the job's one collective (the
 all-reduce of the return counters) closes the region and is reported apart as `collective_ms`, the host's wall clock
-over region + collective as `wall_ms_per_step`.  A third event after the first launch separates what the first
-launch after a synchronize costs (the queue has run dry: the GPU wakes up) from the launch period of the other K-1,
-which is `roofline.kernel_ms`; `roofline.sustained` is the same loop over 2000 launches right after.
+over region + collective as `wall_ms_per_step`.  The last of the W warm-up steps is enqueued after the synchronize,
+directly ahead of the first timed launch ("excluding one warm-up"): a launch into a queue that has run dry
+pays the GPU's wake-up, 20-160 us by how long it idled (tools/launch_probe.py), which is not a property of a step.
+A third event after the first timed launch shows it beside the launch period of the other K-1, which is
+`roofline.kernel_ms`; `roofline.sustained` is the same loop over 2000 launches right after.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the step kernel against HBM with the canonical
 96 B/board-step of SURVEY 8(d); `cpu_baseline` is the CPU oracle (a scalar C port of the reference's move)
@@ -404,8 +406,11 @@ def main():
     done = torch.empty(n, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize(dev)
 
-    # ---- the timed region: W untimed + exactly K timed steps, barrier + synchronize on both sides
-    for t in range(W):
+    # ---- the timed region: W untimed + exactly K timed steps, barrier + synchronize on both sides.  The LAST of the W
+    # warm-up steps is enqueued after the synchronize, directly ahead of the first timed launch ("between two
+    # stream-synchronised hipEvents, excluding one warm-up"): a launch into a queue that has run dry pays the GPU's
+    # wake-up (20-160 us by how long it idled, tools/launch_probe.py), which is not a property of a step.
+    for t in range(max(W - 1, 0)):
         env.step_into(actions[t % S], reward, done)
     T.sharding.mean_episodic_return(env.stats_tensor(), env.reward_params)   # load the reduction kernels / RCCL rings
     torch.cuda.synchronize(dev)
@@ -414,6 +419,8 @@ def main():
 
     ev_a, ev_b, ev_c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     t0 = time.perf_counter()
+    if W >= 1:
+        env.step_into(actions[(W - 1) % S], reward, done)        # warm-up step W of W
     ev_a.record()                                                 # same stream as the kernel launches
     env.step_into(actions[W % S], reward, done)
     ev_b.record()                                                 # (one marker inside the region: it sits in `value`)
@@ -495,10 +502,12 @@ def main():
                                    "(BASELINE configs[2])",
                        "boards_per_gpu": n, "L": L, "M": M, "parallelism": f"batch-shard x{world}"},
             "timing": {"clock": "HIP events on the launch stream around the K launches, max over ranks",
+                       "warmup_placement": f"{max(W - 1, 0)} warm-up step(s) before the synchronize, {min(W, 1)} after it directly "
+                                           "ahead of the first timed launch (it takes the wake-up of the idle queue)",
                        "per_rank_ms_per_step": per_rank_ms, "wall_ms_per_step": wall_ms / K, "collective_ms": collective_ms,
                        "first_launch_ms": first_ms, "other_launches_ms": steady_ms,
-                       "note": "the first launch after a synchronize finds an empty queue and pays the GPU's wake-up; "
-                               "the other K-1 run back to back"},
+                       "note": "first_launch_ms = the first TIMED launch (behind the last warm-up launch), "
+                               "other_launches_ms = the launch period of timed launches 2..K"},
             "ranks_seen": ranks_seen,
             "backend": (backend if world > 1 else None),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
