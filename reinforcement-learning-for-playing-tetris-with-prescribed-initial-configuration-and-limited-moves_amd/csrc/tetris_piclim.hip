@@ -75,11 +75,6 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
     uint32_t a0[kBpl], a1[kBpl];
     unsigned long long clock[kBpl];
     bool valid[kBpl];
-#ifdef TPL_X_CLKVEC
-    // (experiment) the clock as a vector load, requested ahead of the boards
-#pragma unroll
-    for (int k = 0; k < kBpl; ++k) clock[k] = p.clock[(base + (int64_t)k * kThreads) >> kClockShift];
-#endif
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
         // No branch around the loads, so all of a lane's requests leave before the first wait.  The planes are
@@ -94,11 +89,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         // of its groups' clocks and writes both back; all clocks are equal by construction)
         const int64_t wave_first = (int64_t)blockIdx.x * (kThreads * kBpl) + (int64_t)k * kThreads +
                                    (int64_t)(__builtin_amdgcn_readfirstlane((int)threadIdx.x) & ~63);
-#ifdef TPL_X_NOCLKLD
-        clock[k] = 0;
-#elif !defined(TPL_X_CLKVEC)
         clock[k] = p.clock[wave_first >> kClockShift];
-#endif
         a0[k] = load_int(p.act0, p.int_shift, j);
         a1[k] = kActionForm ? 0u : load_int(p.act1, p.int_shift, j);
     }
@@ -116,11 +107,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         // an empty statement that needs every phase-0 result: it pins the one wait for phase 0 here, ahead of all
         // the gathers (left alone, the compiler waits for board k only after the gather of board k-1 has left,
         // which then has to be waited for as well)
-#ifdef TPL_X_CLKVEC
-        asm volatile("" ::"v"(A[k].x), "v"(B[k].x), "v"(a0[k]), "v"(a1[k]), "v"(clock[k]));
-#else
         asm volatile("" ::"v"(A[k].x), "v"(B[k].x), "v"(a0[k]), "v"(a1[k]), "s"(clock[k]));
-#endif
     }
     TPL_STAMP(1);
 #pragma unroll
@@ -130,9 +117,6 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         refill_word[k] = window_word(tenth);
         live[k] = packed_state(B[k]) == ST_RUNNING;
         refill[k] = live[k] && window_runs_out(tenth) && (p.n_cfg[0] | p.n_cfg[1]) != 0u;
-#ifdef TPL_X_NOREFILL
-        refill[k] = false;
-#endif
     }
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
@@ -241,13 +225,11 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
     // the groups' next step.  Every lane stores (the 32 lanes of a group write the same value to the same word: one
     // 16-byte write per wave): a branch on the lane index here would put a divergent region, and with it the
     // compiler's full memory wait, between the state stores.
-#ifndef TPL_X_NOCLKST
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
         const int64_t i = base + (int64_t)k * kThreads;
         p.clock[i >> kClockShift] = clock[k] + 1u;
     }
-#endif
 
     TPL_STAMP(4);
     // per-block statistics of the episodes that finished in this step -> one sharded 64-bit atomic per counter

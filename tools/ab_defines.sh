@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B on ONE box of source variants of the working tree: tools/ab_defines.sh "" TPL_X_FOO TPL_X_BAR ...  (each name is a
 # -D define; _lib.py builds lib/libtetris_piclim_<NAME>.so for it).  "old" = the tree in _ab/old.  Alternating rounds.
-ARGS="--no-cpu-baseline --actor-boards 0 --carved-pool 0 --no-config1 --steps 500 --warmup 50"
+ARGS=${AB_ARGS:-"--no-cpu-baseline --actor-boards 0 --carved-pool 0 --no-config1 --steps 500 --warmup 50"}
 for round in 1 2 3; do
   for v in "$@"; do
     tree=.; def=$v
