@@ -308,7 +308,18 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
         // the top of every iteration -- right behind the requests (next action, window word) that iteration has
         // just issued to ride under the move.
         asm volatile("" ::"v"(act));
+        // A step's reward / done are STORED AT THE TOP OF THE NEXT ITERATION.  The compiler cannot count what is in flight
+        // across the divergent regions of a move, so wherever a load is waited for it waits for everything -- stores
+        // included.  Issued at the end of a step they would be waited for (their acknowledgement comes from memory) a few
+        // instructions later, at the loop's bottom; issued here they have a whole move to complete under.
+        float reward_prev = 0.0f;
+        bool done_prev = false;
         for (uint32_t k = 0; k < q.K; ++k) {
+            if (k > 0) {
+                // (non-temporal: a trajectory is written once and consumed later, by someone else)
+                if (want_reward) { __builtin_nontemporal_store(reward_prev, reward_ptr); reward_ptr += p.n; }
+                if (want_done) { __builtin_nontemporal_store((uint8_t)(done_prev ? 1 : 0), done_ptr); done_ptr += p.n; }
+            }
             // next step's action is independent of the board: fetch it under this step's move
             uint32_t act_next = 0;
             act_next_ptr += q.action_stride;
@@ -318,11 +329,12 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
             float reward;
             const bool done = advance_board_lds<kAutoReset>(s, cols, rec, rot, loc, p, (uint32_t)i, clock + k, s_shape, reward, tally);
             rsum = rsum + reward;
-            // (non-temporal: a trajectory is written once and consumed later, by someone else)
-            if (want_reward) { __builtin_nontemporal_store(reward, reward_ptr); reward_ptr += p.n; }
-            if (want_done) { __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), done_ptr); done_ptr += p.n; }
+            reward_prev = reward;
+            done_prev = done;
             act = act_next;
         }
+        if (want_reward) __builtin_nontemporal_store(reward_prev, reward_ptr);
+        if (want_done) __builtin_nontemporal_store((uint8_t)(done_prev ? 1 : 0), done_ptr);
         lds_load_cols(cols, s.c);
         pack_board<true>(s, A, B);
         p.plane_a[i] = A;
