@@ -374,7 +374,8 @@ __device__ __forceinline__ uint64_t piece_word(const uint8_t* pc, uint32_t M, ui
 }
 
 __global__ __launch_bounds__(kBlock) void pack_configs_kernel(const uint16_t* rows, const uint8_t* pieces, int64_t n_cfg,
-                                                             uint32_t M, uint32_t words, uint8_t* pool, uint32_t stride) {
+                                                             uint32_t M, uint32_t words, uint8_t* pool, uint32_t stride,
+                                                             uint8_t* side) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_cfg) return;
     uint16_t r[kRows];
@@ -391,6 +392,12 @@ __global__ __launch_bounds__(kBlock) void pack_configs_kernel(const uint16_t* ro
     ((uint4*)rec)[0] = A;
     ((uint4*)rec)[1] = B;
     for (uint32_t w = 1; w < words; ++w) ((uint64_t*)(rec + 32))[w - 1] = piece_word(pc, M, w);
+    // the side record: the board unpacked, column words with the sentinel bit (tpl_device.h)
+    uint4* sr = (uint4*)(side + ((size_t)i << kSideShift));
+    sr[0] = make_uint4(s.c[0] | kSentinelBit, s.c[1] | kSentinelBit, s.c[2] | kSentinelBit, s.c[3] | kSentinelBit);
+    sr[1] = make_uint4(s.c[4] | kSentinelBit, s.c[5] | kSentinelBit, s.c[6] | kSentinelBit, s.c[7] | kSentinelBit);
+    sr[2] = make_uint4(s.c[8] | kSentinelBit, s.c[9] | kSentinelBit, s.window, s.window_hi);
+    sr[3] = make_uint4(0, 0, 0, 0);
 }
 
 // get_state (:435-436) + public attributes, resident layout -> interchange layout
@@ -627,7 +634,7 @@ size_t tpl_workspace_bytes(int64_t num_envs, int32_t M) {
 
 size_t tpl_pool_bytes(int64_t n_cfg, int32_t M) {
     if (n_cfg <= 0 || M < 1) return 0;
-    return (size_t)n_cfg * record_stride(M);
+    return (size_t)n_cfg * (record_stride(M) + ((size_t)1 << kSideShift));   // records, then the side records
 }
 
 int tpl_create(tpl_env** out, int64_t num_envs, int32_t L, int32_t M, int32_t device_id, int64_t global_offset,
@@ -736,10 +743,11 @@ int tpl_load_configs(tpl_env* e, const uint16_t* rows, const uint8_t* pieces, in
     }
     slot.owned = newly_owned;
     slot.rec = (uint8_t*)base;
+    slot.side = (uint8_t*)base + (size_t)n_cfg * record_stride(e->M);
     slot.n_cfg = n_cfg;
     TPL_HIP(hipMemsetAsync(base, 0, need, (hipStream_t)stream));     // record padding reads as zero
     hipLaunchKernelGGL(pack_configs_kernel, dim3(blocks_for(n_cfg)), dim3(kBlock), 0, (hipStream_t)stream, rows, pieces,
-                       n_cfg, (uint32_t)e->M, (uint32_t)piece_words(e->M), slot.rec, (uint32_t)record_stride(e->M));
+                       n_cfg, (uint32_t)e->M, (uint32_t)piece_words(e->M), slot.rec, (uint32_t)record_stride(e->M), slot.side);
     TPL_HIP(hipGetLastError());
     if (!first) {
         e->cur_slot = target;

@@ -20,6 +20,11 @@
 // pieces[0] and pieces[1] are always in the state itself and the common step does one round trip to HBM.
 // Pool record (AoS, `stride` bytes, 64-B aligned): plane-A word, plane-B word (window = word 0), 64-bit words 1..
 //
+// Side record (64 B per configuration, behind the records): the ten column words as the multi-step kernel keeps them
+// (bit 20 set), then the piece window (low word, high 4 bits), zero padding.  A reset in that kernel is three 16-byte
+// loads and five LDS writes -- no unpacking (the packed record costs it sixteen instructions per reset, and in a wave of
+// 64 some lane resets at almost every step).  The step kernel never touches it.
+//
 // A board does not store which pool entry it was started from, nor an episode number.  Every group of 32 boards
 // has a STEP CLOCK in memory (uint64, advanced by the wave that owns the group: +1 per step launch, +K per
 // K-step launch, zeroed by a full reset -- so every clock equals the number of steps since the last full reset).
@@ -38,6 +43,7 @@ constexpr int kCols = 10;
 constexpr uint32_t kColMask = 0xFFFFFu;
 constexpr int kWindowStride = 10;    // entries between the starts of consecutive piece words
 constexpr int kWindowEntries = 12;
+constexpr int kSideShift = 6;        // side records are 64 bytes
 constexpr int kClockGroup = 32;      // boards per step clock (log2 = kClockShift)
 constexpr int kClockShift = 5;
 

@@ -21,6 +21,7 @@ struct StepArgs {
     // configuration pools (auto-reset, window refills): new episodes start from pool[cur_slot], a running board
     // refills its window from the slot it carries
     const uint8_t* pool[2];
+    const uint8_t* side[2];    // the pools' side records (unpacked boards, for the multi-step kernel's resets)
     uint32_t n_cfg[2];
     uint32_t offset_mod[2];    // global_offset mod n_cfg
     uint32_t stride_shift;     // records are 1 << stride_shift bytes apart
@@ -42,6 +43,7 @@ inline StepArgs make_args(const tpl_env* e) {
     a.r_line = e->r_line; a.r_win = e->r_win; a.r_lose = e->r_lose;
     for (int k = 0; k < 2; ++k) {
         a.pool[k] = e->pool[k].rec;
+        a.side[k] = e->pool[k].side;
         a.n_cfg[k] = (uint32_t)e->pool[k].n_cfg;
         a.offset_mod[k] = e->pool[k].n_cfg ? (uint32_t)((uint64_t)e->global_offset % (uint64_t)e->pool[k].n_cfg) : 0u;
     }
@@ -182,10 +184,15 @@ __device__ __forceinline__ bool advance_board_lds(Board& s, uint32_t* cols, cons
         tally.wins += s.state == ST_WON ? 1u : 0u;
         tally.topouts += s.state == ST_LOST_TOPOUT ? 1u : 0u;
         if (kAutoReset) {
-            rec = pool_record(p, p.cur_slot, config_of(p, i, clock + 1u, p.cur_slot));
-            const uint4 A2 = ((const uint4*)rec)[0], pb = ((const uint4*)rec)[1];
-            unpack_board<true>(A2, make_uint4(pb.x, pb.y | (p.cur_slot << 30), pb.z, pb.w), s);
-            lds_store_cols(cols, s.c);
+            // the new episode's first move is the next step; the board comes from the side record, already unpacked
+            const uint32_t cfg = config_of(p, i, clock + 1u, p.cur_slot);
+            rec = pool_record(p, p.cur_slot, cfg);
+            const uint4* side = (const uint4*)((p.cur_slot ? p.side[1] : p.side[0]) + ((size_t)cfg << kSideShift));
+            const uint4 s0 = side[0], s1 = side[1], s2 = side[2];
+            const uint32_t c[kCols] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y};
+            lds_store_cols(cols, c);
+            s.window = s2.z; s.window_hi = s2.w;
+            s.moves = 0; s.lines = 0; s.state = ST_RUNNING; s.slot = p.cur_slot;
         }
     }
     return done;

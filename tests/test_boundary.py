@@ -60,9 +60,9 @@ def test_sizes_and_argument_errors_without_gpu():
     n, M = 1 << 20, 40
     ws = lib.tpl_workspace_bytes(n, M)
     assert n * 32 + n // 4 <= ws < n * 32 + n // 4 + (1 << 16)        # 32 B of resident state per board + an 8-B step clock per 32
-    assert lib.tpl_pool_bytes(1000, 49) == 1000 * 64 and lib.tpl_pool_bytes(1000, 50) == 1000 * 128
-    assert lib.tpl_pool_bytes(1000, M) == 1000 * 64                   # one 64-B record per configuration at M=40
-    assert lib.tpl_pool_bytes(1000, 254) == 1000 * 256                 # record strides are powers of two
+    assert lib.tpl_pool_bytes(1000, 49) == 1000 * 128 and lib.tpl_pool_bytes(1000, 50) == 1000 * 192
+    assert lib.tpl_pool_bytes(1000, M) == 1000 * (64 + 64)            # a 64-B record + a 64-B side record per configuration at M=40
+    assert lib.tpl_pool_bytes(1000, 254) == 1000 * (256 + 64)          # record strides are powers of two
     assert lib.tpl_workspace_bytes(0, M) == 0
     h = ctypes.c_void_p()
     assert lib.tpl_create(ctypes.byref(h), 0, 10, 40, 0, 0, 0, None, 0) < 0        # bad num_envs
