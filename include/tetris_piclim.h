@@ -57,7 +57,8 @@ const char* tpl_version(void);
 
 /* Bytes of device memory a handle needs for `num_envs` boards with move limit M. */
 size_t tpl_workspace_bytes(int64_t num_envs, int32_t M);
-/* Bytes of device memory a pool of `n_cfg` prescribed configurations needs. */
+/* Bytes of device memory a pool of `n_cfg` prescribed configurations needs (a packed record of 64 / 128 / 256 bytes by M
+ * and a 64-byte side record -- the same board unpacked, for the multi-step kernel -- per configuration). */
 size_t tpl_pool_bytes(int64_t n_cfg, int32_t M);
 
 /* Replaces Tetris.__init__(L, M, ...) (game/tetris.py:141-214) for `num_envs` boards on GPU `device_id`.
