@@ -374,8 +374,7 @@ __device__ __forceinline__ uint64_t piece_word(const uint8_t* pc, uint32_t M, ui
 }
 
 __global__ __launch_bounds__(kBlock) void pack_configs_kernel(const uint16_t* rows, const uint8_t* pieces, int64_t n_cfg,
-                                                             uint32_t M, uint32_t words, uint8_t* pool, uint32_t stride,
-                                                             uint8_t* side) {
+                                                             uint32_t M, uint32_t words, uint8_t* pool, uint32_t stride) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_cfg) return;
     uint16_t r[kRows];
@@ -392,11 +391,19 @@ __global__ __launch_bounds__(kBlock) void pack_configs_kernel(const uint16_t* ro
     ((uint4*)rec)[0] = A;
     ((uint4*)rec)[1] = B;
     for (uint32_t w = 1; w < words; ++w) ((uint64_t*)(rec + 32))[w - 1] = piece_word(pc, M, w);
-    // the side record: the board unpacked, column words with the sentinel bit (tpl_device.h)
+}
+
+// packed records -> side records (the board unpacked, column words with the sentinel bit: tpl_device.h)
+__global__ __launch_bounds__(kBlock) void build_side_kernel(const uint8_t* pool, uint32_t stride_shift, int64_t n_cfg, uint8_t* side) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_cfg) return;
+    const uint4* rec = (const uint4*)(pool + ((size_t)i << stride_shift));
+    Board s;
+    unpack_board<true>(rec[0], rec[1], s);
     uint4* sr = (uint4*)(side + ((size_t)i << kSideShift));
-    sr[0] = make_uint4(s.c[0] | kSentinelBit, s.c[1] | kSentinelBit, s.c[2] | kSentinelBit, s.c[3] | kSentinelBit);
-    sr[1] = make_uint4(s.c[4] | kSentinelBit, s.c[5] | kSentinelBit, s.c[6] | kSentinelBit, s.c[7] | kSentinelBit);
-    sr[2] = make_uint4(s.c[8] | kSentinelBit, s.c[9] | kSentinelBit, s.window, s.window_hi);
+    sr[0] = make_uint4(s.c[0], s.c[1], s.c[2], s.c[3]);
+    sr[1] = make_uint4(s.c[4], s.c[5], s.c[6], s.c[7]);
+    sr[2] = make_uint4(s.c[8], s.c[9], s.window, s.window_hi);
     sr[3] = make_uint4(0, 0, 0, 0);
 }
 
@@ -744,10 +751,11 @@ int tpl_load_configs(tpl_env* e, const uint16_t* rows, const uint8_t* pieces, in
     slot.owned = newly_owned;
     slot.rec = (uint8_t*)base;
     slot.side = (uint8_t*)base + (size_t)n_cfg * record_stride(e->M);
+    slot.side_ready = false;
     slot.n_cfg = n_cfg;
-    TPL_HIP(hipMemsetAsync(base, 0, need, (hipStream_t)stream));     // record padding reads as zero
+    TPL_HIP(hipMemsetAsync(base, 0, (size_t)n_cfg * record_stride(e->M), (hipStream_t)stream));     // record padding reads as zero
     hipLaunchKernelGGL(pack_configs_kernel, dim3(blocks_for(n_cfg)), dim3(kBlock), 0, (hipStream_t)stream, rows, pieces,
-                       n_cfg, (uint32_t)e->M, (uint32_t)piece_words(e->M), slot.rec, (uint32_t)record_stride(e->M), slot.side);
+                       n_cfg, (uint32_t)e->M, (uint32_t)piece_words(e->M), slot.rec, (uint32_t)record_stride(e->M));
     TPL_HIP(hipGetLastError());
     if (!first) {
         e->cur_slot = target;
@@ -817,6 +825,14 @@ int tpl_rollout(tpl_env* e, const uint8_t* actions, int64_t action_stride, int32
     if (action_stride < e->n) return fail_msg(TPL_ERR_ARG, "action_stride %lld is smaller than num_envs", (long long)action_stride);
     if (int rc = check_can_advance(e)) return rc;
     DeviceGuard guard(e->device);
+    // the resets of this kernel read the current pool's side records: written here, once per pool, on first use
+    Pool& cur = e->pool[e->cur_slot];
+    if (cur.n_cfg != 0 && !cur.side_ready) {
+        hipLaunchKernelGGL(build_side_kernel, dim3(blocks_for(cur.n_cfg)), dim3(kBlock), 0, (hipStream_t)stream, cur.rec,
+                           e->stride_shift, cur.n_cfg, cur.side);
+        TPL_HIP(hipGetLastError());
+        cur.side_ready = true;
+    }
     RolloutArgs q{};
     q.s = make_args(e);
     q.actions = actions; q.action_stride = action_stride; q.K = (uint32_t)num_steps;

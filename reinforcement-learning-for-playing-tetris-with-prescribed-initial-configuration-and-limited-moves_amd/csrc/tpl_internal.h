@@ -13,6 +13,8 @@ constexpr int kStatStride = 16;   // uint64 per shard -> one 128-B line each
 struct Pool {
     uint8_t* rec = nullptr;    // [n_cfg] records of 1 << stride_shift bytes: plane-A word, plane-B word, 64-bit piece words 1..
     uint8_t* side = nullptr;   // [n_cfg] 64-byte side records behind them: the same board UNPACKED (tpl_device.h)
+    bool side_ready = false;   // the side records are written on first use (tpl_rollout): a caller that only steps never
+                               //   pays for them, nor has 64 bytes per configuration pushed through the caches
     int64_t n_cfg = 0;
     void* owned = nullptr;
 };

@@ -1,0 +1,6 @@
+for r in 1 2 3; do for args in "--no-cpu-baseline --actor-boards 0 --carved-pool 0 --no-config1" "--no-cpu-baseline"; do python bench.py --steps 20 --warmup 5 $args 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('$args'[:40].ljust(40), 'timed %.3f first %.3f others %.3f sustained %.3f' % (d['ms_per_step']*1e3, d['timing']['first_launch_ms']*1e3, d['timing']['other_launches_ms']*1e3, d['roofline']['sustained']['kernel_ms_median_of_50s']*1e3))
+"; done; done
