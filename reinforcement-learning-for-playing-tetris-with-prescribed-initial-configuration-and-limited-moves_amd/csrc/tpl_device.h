@@ -136,9 +136,9 @@ __device__ __forceinline__ void pack3(uint32_t a, uint32_t b, uint32_t c, uint32
     hi = (b >> 12) | (c << 8);
 }
 
-// kSentinel: the multi-step kernels keep every column word with bit 20 set while the board lives in registers (the top of
-// a column is then one v_ffbl with no preparation, and the `& mask` of the unpack becomes an and-or at the same cost);
-// move_board<true> expects that form and pack_board<true> strips it.
+// kSentinel: the multi-step kernel keeps every column word with bit 20 set (the top of a column, 20 when it is empty, is
+// then one v_ffbl with no preparation); unpack_board<true> produces that form at no extra cost -- a bit-field insert
+// where the plain form has an `and` -- move_board_lds expects it and pack_board<true> strips it.
 constexpr uint32_t kSentinelBit = 1u << kRows;
 
 // (mask & x) | (~mask & y) as ONE v_bfi_b32.  With both constants written as literals the compiler emits an `and` and an
@@ -229,7 +229,6 @@ __device__ __forceinline__ uint32_t blend(uint32_t m, uint32_t x, uint32_t y) { 
 // Tetris.move(rotations, location) (:354-422) on the lane's board; the piece is entry 0 of the window, which the
 // caller pops (:356).  `shape` is the LDS-resident table.  Returns rows cleared (0..4); sets
 // `topout` when drop < 0 (:372-374), in which case the board and moves_used are left unchanged.
-template <bool kSentinel = false>
 __device__ __forceinline__ uint32_t move_board(Board& s, const ShapeWord* shape, uint32_t rot, uint32_t loc,
                                                uint32_t L, uint32_t M, bool& topout) {
     // get_tetromino (:60-61, :359-360)
@@ -248,7 +247,7 @@ __device__ __forceinline__ uint32_t move_board(Board& s, const ShapeWord* shape,
     // piece columns past its width, whose table bias of 64 keeps them out of the minimum.
     uint32_t t[kCols];
 #pragma unroll
-    for (int k = 0; k < kCols; ++k) t[k] = (uint32_t)__builtin_ctz(kSentinel ? s.c[k] : (s.c[k] | kSentinelBit));
+    for (int k = 0; k < kCols; ++k) t[k] = (uint32_t)__builtin_ctz(s.c[k] | kSentinelBit);
     uint32_t p0 = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
     uint32_t p1 = t[4] | (t[5] << 8) | (t[6] << 16) | (t[7] << 24);
     uint32_t p2 = t[8] | (t[9] << 8);
@@ -325,7 +324,7 @@ __device__ __forceinline__ void lds_load_cols(const uint32_t* cols, uint32_t (&c
     for (int k = 0; k < kCols; ++k) c[k] = cols[k * kLdsStride];
 }
 
-// Tetris.move (:354-422) as move_board<true>, on the column words at `cols` (this lane's column 0).  `s.c` is not used.
+// Tetris.move (:354-422) as move_board, on the column words at `cols` (this lane's column 0).  `s.c` is not used.
 __device__ __forceinline__ uint32_t move_board_lds(Board& s, uint32_t* cols, const ShapeWord* shape, uint32_t rot, uint32_t loc,
                                                    uint32_t L, uint32_t M, bool& topout) {
     const ShapeWord sh = shape[(s.window & 7u) * 4u + (rot & 3u)];                 // get_tetromino (:60-61, :359-360)

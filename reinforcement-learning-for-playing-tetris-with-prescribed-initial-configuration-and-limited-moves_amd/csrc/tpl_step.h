@@ -129,9 +129,9 @@ __device__ __forceinline__ const uint8_t* current_record(const Board& s, const S
 
 // One step of one unpacked board held in registers: Tetris.move (:354-422) + the window pop/refill + the
 // build's freeze / auto-reset rules + reward.  `rec` = current_record() of the board, updated on a reset; `clock` = the
-// index of this step (the group's step clock on entry + the steps already done in this launch).  kSentinel: the board's
-// column words carry bit 20 (tpl_device.h).  Returns done (state != running after the move, before a reset).
-template <bool kAutoReset, bool kSentinel = false>
+// index of this step (the group's step clock on entry + the steps already done in this launch).  Returns done (state !=
+// running after the move, before a reset).
+template <bool kAutoReset>
 __device__ __forceinline__ bool advance_board(Board& s, const uint8_t*& rec, uint32_t rot, uint32_t loc, const StepArgs& p,
                                               uint32_t i, uint64_t clock, const ShapeWord* shape, float& reward, Tally& tally) {
     reward = 0.0f;
@@ -143,7 +143,7 @@ __device__ __forceinline__ bool advance_board(Board& s, const uint8_t*& rec, uin
     uint64_t word = 0;
     if (refill) word = piece_word_at(rec, window_word(tenth));
     bool topout;
-    const uint32_t n_clear = move_board<kSentinel>(s, shape, rot, loc, p.L, p.M, topout);
+    const uint32_t n_clear = move_board(s, shape, rot, loc, p.L, p.M, topout);
     next_window(s, refill, word);
     reward = step_reward(p, n_clear, s.state);
     const bool done = s.state != ST_RUNNING;
@@ -156,7 +156,7 @@ __device__ __forceinline__ bool advance_board(Board& s, const uint8_t*& rec, uin
             // the new episode's first move is the next step; it starts from the current pool buffer
             rec = pool_record(p, p.cur_slot, config_of(p, i, clock + 1u, p.cur_slot));
             const uint4 A2 = ((const uint4*)rec)[0], pb = ((const uint4*)rec)[1];
-            unpack_board<kSentinel>(A2, make_uint4(pb.x, pb.y | (p.cur_slot << 30), pb.z, pb.w), s);
+            unpack_board(A2, make_uint4(pb.x, pb.y | (p.cur_slot << 30), pb.z, pb.w), s);
         }
     }
     return done;
