@@ -321,3 +321,65 @@ def test_pool_refresher_feeds_a_running_environment_from_a_side_stream(T, oracle
     assert env.stats() == cpu.stats()
     assert feeder.swaps >= 3 and firsts == [count * (k + 1) for k in range(len(firsts))]
     env.terminate()
+
+
+@pytest.mark.gpu
+def test_randomised_mix_of_steps_rollouts_resets_and_pool_swaps(T, oracle):
+    """Random draws of (L, M, batch, pools, assignment, geometry), each driven by a random interleaving of single steps,
+    fused rollouts of random length, masked resets, full resets and pool swaps (whenever the handle can take one), and
+    compared with the oracle after every operation.  TPL_CHAOS_CASES=300 for a one-off longer run."""
+    import os
+    import torch
+    rng = np.random.default_rng(77)
+    for case in range(int(os.environ.get("TPL_CHAOS_CASES", "12"))):
+        L = int(rng.integers(1, 9))
+        M = int(rng.choice([1, 2, 5, 9, 10, 11, 19, 20, 21, 33, 40, 50, 100]))
+        n = int(rng.choice([1, 31, 32, 33, 64, 100, 513, 3000]))
+        assign = ["hash", "sequential"][int(rng.integers(0, 2))]
+        auto = bool(rng.integers(0, 4))                              # mostly auto-reset
+        seed, offset = int(rng.integers(0, 1 << 30)), int(rng.integers(0, 1 << 40))
+        tag = f"case {case}: L={L} M={M} n={n} {assign} auto={auto} seed={seed} offset={offset}"
+        gpu = T.BatchedTetris(L, M, n, seed=seed, global_offset=offset, auto_reset=auto, assign=assign, reward=(1.0, 3.0, -0.5))
+        gpu.set_tuning(int(rng.choice([1, 2, 4])), int(rng.choice([64, 128, 256, 512])))
+        cpu = oracle.Env(n, L, M, offset, seed)
+        cpu.set_options(auto_reset=auto, assign_mode=0 if assign == "hash" else 1, per_line=1.0, win=3.0, lose=-0.5)
+
+        def new_pool():
+            size, low = int(rng.integers(1, 300)), int(rng.integers(0, L + 1))
+            k = int(rng.integers(0, 1 << 30))
+            return oracle.synth_boards(k, 0, size, low), oracle.synth_pieces(k, 0, size, M)
+
+        pool = new_pool()
+        gpu.load_configs(*pool); cpu.set_pool(*pool)
+        gpu.reset(); cpu.reset()
+        t, swaps = 0, 0
+        for op in range(40):
+            what = rng.choice(["step", "rollout", "mask", "full", "swap"], p=[0.4, 0.3, 0.1, 0.05, 0.15])
+            if what == "step":
+                a = rng.integers(0, 40, n).astype(np.uint8)
+                _, r_g, d_g, _ = gpu.step(a, observe=False)
+                r_c, d_c = cpu.step(a)
+                assert np.array_equal(_np(r_g), r_c) and np.array_equal(_np(d_g).astype(np.uint8), d_c), (tag, op)
+                t += 1
+            elif what == "rollout":
+                K = int(rng.integers(1, 8))
+                acts = rng.integers(0, 40, (K, n)).astype(np.uint8)
+                _, _, rs, ds = gpu.rollout(torch.from_numpy(acts).to(gpu.device), per_step=True)
+                for k in range(K):
+                    r_c, d_c = cpu.step(acts[k])
+                    assert np.array_equal(_np(rs[k]), r_c) and np.array_equal(_np(ds[k]).astype(np.uint8), d_c), (tag, op, k)
+                t += K
+            elif what == "mask":
+                mask = (rng.random(n) < 0.4).astype(np.uint8)
+                gpu.reset(mask); cpu.reset(mask)
+            elif what == "full":
+                gpu.reset(); cpu.reset()
+                t = 0
+            elif gpu.pool_info()["steps_until_swap"] == 0:
+                pool = new_pool()
+                gpu.load_configs(*pool); cpu.set_pool(*pool)
+                swaps += 1
+            _same(_state(gpu), cpu.get_state(), f"{tag} op {op} ({what})")
+            assert gpu.step_clock() == cpu.clock == t, (tag, op)
+        assert gpu.stats() == cpu.stats(), tag
+        gpu.terminate()
