@@ -96,8 +96,10 @@ int tpl_set_options(tpl_env* env, int32_t auto_reset, int32_t assign_mode,
  * their configuration lives in (a board carries one bit for it).  A caller-owned `pool_mem` must therefore stay
  * alive until the call after next.  The buffer a call would overwrite must be out of use: the call fails with
  * TPL_ERR_STATE unless a full reset, or at least M + 1 steps enqueued through this API, have followed the previous
- * swap (tpl_pool_info tells).  Work that was captured into a hipGraph keeps the pool pointers it was captured with:
- * capture again after a swap. */
+ * swap (tpl_pool_info tells).  The guard counts steps as they are ENQUEUED: when `stream` is not the stream the steps
+ * run on, make it wait (an event) for the steps enqueued so far before this call, and make the stepping stream wait
+ * for this call's work before the next step -- pool.py's PoolRefresher does exactly that.  Work that was captured
+ * into a hipGraph keeps the pool pointers it was captured with: capture again after a swap. */
 int tpl_load_configs(tpl_env* env, const uint16_t* rows, const uint8_t* pieces, int64_t n_cfg,
                      void* pool_mem, size_t pool_bytes, void* stream);
 
