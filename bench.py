@@ -280,6 +280,15 @@ def measure_config1(torch, T, dev, seed, chunk):
            "roofline": {"bound": "hbm", "achieved": ALGO_BYTES_PER_BOARD_STEP * n / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": ALGO_BYTES_PER_BOARD_STEP * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "kernel": "step_kernel<action, auto_reset>", "kernel_ms": ms}}
+    # the same steps as one replayed HIP graph of 50: at this size the host's few microseconds per call are the limit
+    G = 50
+    rs = torch.empty((G, n), dtype=torch.float32, device=dev)
+    ds = torch.empty((G, n), dtype=torch.uint8, device=dev)
+    replay = env.capture_steps(actions[:G], rs, ds)
+    replay()
+    torch.cuda.synchronize(dev)
+    ms_g = timed(torch, dev, replay, 8) / G
+    out["graph_replay"] = {"value": float(n) / (ms_g * 1e-3), "ms_per_step": ms_g, "steps_per_graph": G}
     if chunk > 0:
         ms_f = measure_fused_rollout(torch, T, env, actions, 0, K // chunk * chunk, chunk)
         out["fused_rollout"] = {"value": float(n) / (ms_f * 1e-3), "ms_per_step": ms_f, "steps_per_launch": chunk}

@@ -256,6 +256,47 @@ class BatchedTetris:
         if rc:
             check(rc)
 
+    def capture_steps(self, actions: torch.Tensor, rewards: torch.Tensor, dones: torch.Tensor):
+        """K consecutive step() calls captured into ONE HIP graph: actions uint8/int32/int64 [K, N], rewards f32 [K, N],
+        dones uint8 [K, N], all caller-owned and reused by every replay.  Returns a callable: each call replays the K
+        steps (the boards move on; refill the action rows in between).  For batches small enough that the host's few
+        microseconds per step_into() call are the limit (65,536 boards: 6.3 -> 5.0 us per step); at 2^20 boards it
+        changes nothing.  The graph carries the pool pointers of the moment of capture: the callable captures again by
+        itself after a load_configs()."""
+        K = actions.shape[0]
+        for t in range(K):
+            self._own(actions[t], _INT_CODES, "actions[t]")
+            self._own(rewards[t], torch.float32, "rewards[t]")
+            self._own(dones[t], torch.uint8, "dones[t]")
+        state = {"graph": None, "pool": -1}
+
+        def capture():
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                saved = self.snapshot()
+                self.step_into(actions[0], rewards[0], dones[0])          # load the kernel outside the capture
+                self.restore(saved)
+                torch.cuda.synchronize(self.device)
+                with torch.cuda.graph(graph, stream=side):
+                    for t in range(K):
+                        self.step_into(actions[t], rewards[t], dones[t])
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            self.restore(saved)                                           # capture does not execute; the swap guard saw K + 1 calls
+            state["graph"], state["pool"] = graph, self.pool_generation
+
+        def replay():
+            if state["pool"] != self.pool_generation:
+                capture()
+            state["graph"].replay()
+            # the library counts steps as they pass through its API (the pool-swap guard); a replay does not: tell it
+            hold = self.pool_info()["steps_until_swap"]
+            if hold:
+                check(self._lib.tpl_pool_set_hold(self._h, max(0, hold - K)))
+
+        return replay
+
     def step(self, action, observe: bool = True, obs_dtype=torch.float32):
         """step(action) with action = rot*10 + loc.  Returns (obs [N,217] or None, reward, done, info)."""
         act, code = self._int_arg(action)

@@ -773,6 +773,41 @@ def test_step_is_graph_capturable_and_replays_exactly(T, oracle):
     gpu.terminate()
 
 
+def test_capture_steps_replays_and_recaptures_after_a_pool_swap(T, oracle):
+    """BatchedTetris.capture_steps: K steps in one HIP graph, replayed; after load_configs() the callable captures again
+    (the old graph would read the old pool buffer).  Against the oracle throughout."""
+    import torch
+    L, M, n, seed, K = 5, 20, 7000, 41, 6
+    gpu = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True)
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_options(auto_reset=True, assign_mode=0)
+    pool_a = (oracle.synth_boards(1, 0, 500, L), oracle.synth_pieces(1, 0, 500, M))
+    pool_b = (oracle.synth_boards(2, 0, 300, L), oracle.synth_pieces(2, 0, 300, M))
+    gpu.load_configs(*pool_a); cpu.set_pool(*pool_a)
+    gpu.reset(); cpu.reset()
+    actions = torch.empty((K, n), dtype=torch.uint8, device=gpu.device)
+    rewards = torch.empty((K, n), dtype=torch.float32, device=gpu.device)
+    dones = torch.empty((K, n), dtype=torch.uint8, device=gpu.device)
+    replay = gpu.capture_steps(actions, rewards, dones)
+    t = 0
+    for block in range(12):
+        if block == 5:
+            gpu.load_configs(*pool_b); cpu.set_pool(*pool_b)
+        if block == 10:                                            # 30 replayed steps later (M + 1 = 21): the guard has been told
+            assert gpu.pool_info()["steps_until_swap"] == 0
+            gpu.load_configs(*pool_a); cpu.set_pool(*pool_a)
+        for k in range(K):
+            gpu.synthetic_actions(t + k, out=actions[k])
+        replay()
+        for k in range(K):
+            r_c, d_c = cpu.step(_np(actions[k]))
+            assert np.array_equal(_np(rewards[k]), r_c) and np.array_equal(_np(dones[k]), d_c), (block, k)
+        t += K
+    _assert_state_equal(_state(gpu), cpu.get_state(), "capture_steps")
+    assert gpu.stats() == cpu.stats() and gpu.step_clock() == cpu.clock == t
+    gpu.terminate()
+
+
 @pytest.mark.parametrize("n", [1, 63, 1000, 2049, 5000])
 def test_ragged_batches_match_oracle_in_every_geometry(T, oracle, n):
     """Batch sizes that do not fill the last block: the step kernel reads and writes back the padding boards behind
