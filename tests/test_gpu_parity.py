@@ -611,8 +611,10 @@ def test_benched_configuration_in_lockstep_with_the_oracle(T, oracle):
     """Exactly what bench.py times (BASELINE configs[2]): 1,048,576 boards, one pool entry per board, auto-reset, hashed
     assignment, tpl_step through step_into() with uint8 actions -- 60 lockstep steps against the oracle: rewards and
     dones of every step, the whole state at the end, statistics.  (Reference semantics: game/tetris.py:354-449.)"""
+    import os
     import torch
-    L, M, n, seed, steps = 10, 40, 1 << 20, 0, 60
+    L, M, n, seed = 10, 40, 1 << 20, 0
+    steps = int(os.environ.get("TPL_BENCH_PARITY_STEPS", "60"))     # a one-off longer run: TPL_BENCH_PARITY_STEPS=1500
     gpu = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True, assign="hash")
     rows, pieces = gpu.synthetic_configs(n)
     gpu.load_configs(rows, pieces)
