@@ -64,6 +64,7 @@ template <bool kActionForm, bool kAutoReset, int kBpl, int kThreads>
 __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
     __shared__ ShapeWord s_shape[32];
     __shared__ uint32_t s_stat[4];
+    __shared__ uint32_t s_cols[kThreads / 64][kLdsCols][kLdsStride];    // a board's column words while it moves (tpl_device.h)
 #ifdef TPL_DIAG_CLOCK
     unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -150,9 +151,18 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
             loc = a1[k];
         }
         Board s;
-        unpack_board(A[k], B[k], s);
         bool topout;
-        n_clear[k] = move_board(s, s_shape, rot, loc, p.L, p.M, topout);
+        // the move indexes the board's columns by the piece's position: through LDS, where a lane can (tpl_device.h;
+        // 0.1 us on the launch against the all-registers form, profiles/r02_step/ab_lds_move.log)
+        unpack_board<true>(A[k], B[k], s);
+        uint32_t* cols = &s_cols[threadIdx.x >> 6][0][threadIdx.x & 63];
+        lds_store_cols(cols, s.c);
+        if (k == 0) {
+#pragma unroll
+            for (int c = kCols; c < kLdsCols; ++c) cols[c * kLdsStride] = kSentinelBit;
+        }
+        n_clear[k] = move_board_lds(s, cols, s_shape, rot, loc, p.L, p.M, topout);
+        lds_load_cols(cols, s.c);
         next_window(s, refill[k], word[k]);                    // the falling piece is consumed even on a top-out
 
         reward[k] = step_reward(p, n_clear[k], s.state);
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
             if (s.state == ST_LOST_TOPOUT) atomicAdd(&s_stat[3], 1u);
         }
         reload[k] = kAutoReset && done[k];
-        pack_board(s, A[k], B[k]);
+        pack_board<true>(s, A[k], B[k]);
     }
 
     TPL_STAMP(2);
