@@ -18,9 +18,9 @@ launches (max over ranks), the region bracketed by barrier + synchronize on both
 all-reduce of the return counters) closes the region and is reported apart as `collective_ms`, the host's wall clock
 over region + collective as `wall_ms_per_step`.  The last of the W warm-up steps is enqueued after the synchronize,
 directly ahead of the first timed launch ("excluding one warm-up"): a launch into a queue that has run dry
-pays the GPU's wake-up, 20-160 us by how long it idled (tools/launch_probe.py), which is not a property of a step.
-A third event after the first timed launch shows it beside the launch period of the other K-1, which is
-`roofline.kernel_ms`; `roofline.sustained` is the same loop over 2000 launches right after.
+pays the GPU's wake-up, 20-160 us by how long it idled (tools/launch_probe.py), which is not a property of a step; an
+event ahead of that launch puts its duration in the line (`timing.launch_after_synchronize_ms`).  `roofline.kernel_ms`
+is the launch period over the K timed launches; `roofline.sustained` is the same loop over 2000 launches right after.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the step kernel against HBM with the canonical
 96 B/board-step of SURVEY 8(d); `cpu_baseline` is the CPU oracle (a scalar C port of the reference's move)
@@ -427,14 +427,13 @@ def main():
     barrier()
     torch.cuda.synchronize(dev)
 
-    ev_a, ev_b, ev_c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    ev_w, ev_a, ev_c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     t0 = time.perf_counter()
+    ev_w.record()                                                 # same stream as the kernel launches
     if W >= 1:
-        env.step_into(actions[(W - 1) % S], reward, done)        # warm-up step W of W
-    ev_a.record()                                                 # same stream as the kernel launches
-    env.step_into(actions[W % S], reward, done)
-    ev_b.record()                                                 # (one marker inside the region: it sits in `value`)
-    for t in range(W + 1, W + K):
+        env.step_into(actions[(W - 1) % S], reward, done)        # warm-up step W of W: takes the idle queue's wake-up
+    ev_a.record()
+    for t in range(W, W + K):
         env.step_into(actions[t % S], reward, done)
     ev_c.record()
     torch.cuda.synchronize(dev)
@@ -448,8 +447,8 @@ def main():
     region_ms_rank = ev_a.elapsed_time(ev_c)
     per_rank_ms = every_rank(region_ms_rank / K)
     region_ms = max(per_rank_ms) * K                              # max over ranks
-    first_ms = max_over_ranks(ev_a.elapsed_time(ev_b))
-    steady_ms = max_over_ranks(ev_b.elapsed_time(ev_c) / (K - 1)) if K > 1 else first_ms
+    wake_ms = max_over_ranks(ev_w.elapsed_time(ev_a)) if W >= 1 else None    # the warm-up launch behind the synchronize
+    steady_ms = region_ms / K
     wall_ms = max_over_ranks((t3 - t0) * 1e3)
     collective_ms = max_over_ranks((t2 - t1) * 1e3)
 
@@ -520,17 +519,16 @@ def main():
                        "warmup_placement": f"{max(W - 1, 0)} warm-up step(s) before the synchronize, {min(W, 1)} after it directly "
                                            "ahead of the first timed launch (it takes the wake-up of the idle queue)",
                        "per_rank_ms_per_step": per_rank_ms, "wall_ms_per_step": wall_ms / K, "collective_ms": collective_ms,
-                       "first_launch_ms": first_ms, "other_launches_ms": steady_ms,
-                       "note": "first_launch_ms = the first TIMED launch (behind the last warm-up launch), "
-                               "other_launches_ms = the launch period of timed launches 2..K"},
+                       "launch_after_synchronize_ms": wake_ms,
+                       "note": "launch_after_synchronize_ms = the last warm-up launch, the one that finds the queue empty "
+                               "(outside the timed region); the K timed launches follow it back to back"},
             "ranks_seen": ranks_seen,
             "backend": (backend if world > 1 else None),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "step_kernel<action, auto_reset>", "kernel_ms": steady_ms,
-                         "kernel_ms_source": "launch period of launches 2..K of the timed region (HIP events)",
-                         "kernel_ms_first_launch": first_ms, "kernel_ms_timed_mean": region_ms / K,
-                         "frac_timed_mean": ALGO_BYTES_PER_BOARD_STEP * n / (region_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "kernel_ms_source": "launch period over the K timed launches (HIP events on the launch stream)",
+                         "launch_after_synchronize_ms": wake_ms,
                          "sustained": sustained,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BOARD_STEP * n},
             "fused_rollout": fused,
