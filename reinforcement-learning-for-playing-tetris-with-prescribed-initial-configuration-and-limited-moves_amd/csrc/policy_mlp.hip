@@ -378,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q
         unsigned long long clock = p.clock[tile];
         clock = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(clock >> 32)) << 32) |
                 (uint32_t)__builtin_amdgcn_readfirstlane((int)clock);
-        const uint8_t* rec = current_record(s, p, (uint32_t)b, clock);
+        uint32_t cfg = current_config(s, p, (uint32_t)b, clock);
         for (uint32_t t = 0; t < q.T; ++t) {
             if (q.states_a && valid && writer) {
                 uint4 A, B;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q
             split_small_action(action, rot, loc);
             float reward;
             Tally mine;
-            const bool done = advance_board<kAutoReset>(s, rec, rot, loc, p, (uint32_t)b, clock + t, s_shape, reward, mine);
+            const bool done = advance_board<kAutoReset>(s, cfg, rot, loc, p, (uint32_t)b, clock + t, s_shape, reward, mine);
             if (valid && writer) {
                 tally.episodes += mine.episodes; tally.lines += mine.lines;
                 tally.wins += mine.wins; tally.topouts += mine.topouts;

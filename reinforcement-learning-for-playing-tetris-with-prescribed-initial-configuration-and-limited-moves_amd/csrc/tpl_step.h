@@ -127,12 +127,18 @@ __device__ __forceinline__ const uint8_t* current_record(const Board& s, const S
     return pool_record(p, s.slot, config_of(p, i, clock - s.moves, s.slot));
 }
 
+// pool entry of the board's current episode at step `clock` (the actor kernel keeps this index, one register, where the
+// K-step kernel keeps the record's address: its registers are the scarcer)
+__device__ __forceinline__ uint32_t current_config(const Board& s, const StepArgs& p, uint32_t i, uint64_t clock) {
+    return config_of(p, i, clock - s.moves, s.slot);
+}
+
 // One step of one unpacked board held in registers: Tetris.move (:354-422) + the window pop/refill + the
-// build's freeze / auto-reset rules + reward.  `rec` = current_record() of the board, updated on a reset; `clock` = the
+// build's freeze / auto-reset rules + reward.  `cfg` = current_config() of the board, updated on a reset; `clock` = the
 // index of this step (the group's step clock on entry + the steps already done in this launch).  Returns done (state !=
 // running after the move, before a reset).
 template <bool kAutoReset>
-__device__ __forceinline__ bool advance_board(Board& s, const uint8_t*& rec, uint32_t rot, uint32_t loc, const StepArgs& p,
+__device__ __forceinline__ bool advance_board(Board& s, uint32_t& cfg, uint32_t rot, uint32_t loc, const StepArgs& p,
                                               uint32_t i, uint64_t clock, const ShapeWord* shape, float& reward, Tally& tally) {
     reward = 0.0f;
     if (s.state != ST_RUNNING) return true;      // frozen
@@ -141,7 +147,7 @@ __device__ __forceinline__ bool advance_board(Board& s, const uint8_t*& rec, uin
     const uint32_t tenth = tenths(s.moves + 1u);
     const bool refill = window_runs_out(tenth) && (p.n_cfg[0] | p.n_cfg[1]) != 0u;
     uint64_t word = 0;
-    if (refill) word = piece_word_at(rec, window_word(tenth));
+    if (refill) word = piece_word_at(pool_record(p, s.slot, cfg), window_word(tenth));
     bool topout;
     const uint32_t n_clear = move_board(s, shape, rot, loc, p.L, p.M, topout);
     next_window(s, refill, word);
@@ -154,9 +160,10 @@ __device__ __forceinline__ bool advance_board(Board& s, const uint8_t*& rec, uin
         tally.topouts += s.state == ST_LOST_TOPOUT ? 1u : 0u;
         if (kAutoReset) {
             // the new episode's first move is the next step; it starts from the current pool buffer
-            rec = pool_record(p, p.cur_slot, config_of(p, i, clock + 1u, p.cur_slot));
-            const uint4 A2 = ((const uint4*)rec)[0], pb = ((const uint4*)rec)[1];
-            unpack_board(A2, make_uint4(pb.x, pb.y | (p.cur_slot << 30), pb.z, pb.w), s);
+            cfg = config_of(p, i, clock + 1u, p.cur_slot);
+            uint4 A2, B2;
+            load_config(p, cfg, A2, B2);
+            unpack_board(A2, B2, s);
         }
     }
     return done;
