@@ -528,6 +528,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "step_kernel<action, auto_reset>", "kernel_ms": steady_ms,
                          "kernel_ms_source": "launch period over the K timed launches (HIP events on the launch stream)",
+                         "kernel_ms_mean": steady_ms,
+                         "kernel_ms_median": (sustained or {}).get("kernel_ms_median_of_50s"),
+                         "frac_median": (sustained or {}).get("frac"),
                          "launch_after_synchronize_ms": wake_ms,
                          "sustained": sustained,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BOARD_STEP * n},
