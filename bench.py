@@ -482,6 +482,12 @@ def main():
         ms = max_over_ranks(measure_fused_rollout(torch, T, env, actions, 0, S // args.chunk * args.chunk, args.chunk))
         fused = {"value": float(n) * world / (ms * 1e-3), "unit": "env-steps/s", "steps_per_launch": args.chunk,
                  "ms_per_step": ms, "outputs": "per-step reward f32 + done u8 written", "kernel": "rollout_kernel<auto_reset>"}
+        # the same kernel under the uniform random policy drawn on the device (no actions staged, no per-step outputs)
+        env.rollout_random(100, seed=args.seed)
+        torch.cuda.synchronize(dev)
+        ms_r = max_over_ranks(timed(torch, dev, lambda: env.rollout_random(100, seed=args.seed), 4) / 100)
+        fused["device_random_policy"] = {"value": float(n) * world / (ms_r * 1e-3), "ms_per_step": ms_r, "steps_per_launch": 100,
+                                         "outputs": "reward sums and episode counts only"}
     carved = None
     if args.carved_pool > 0 and world == 1:
         carved = measure_carved_pool(torch, T, env, actions, reward, done, W, K, args.carved_pool, args.seed)

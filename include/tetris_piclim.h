@@ -136,6 +136,13 @@ int tpl_step(tpl_env* env, const void* action, int32_t dtype, float* reward, uin
 int tpl_rollout(tpl_env* env, const uint8_t* actions, int64_t action_stride, int32_t num_steps,
                 float* reward_steps, uint8_t* done_steps, float* reward_sum, uint32_t* finished, void* stream);
 
+/* tpl_rollout with the UNIFORM RANDOM POLICY drawn on the device -- the loop of game/performance_test.py:13-17, whose
+ * moves are random.randint draws -- so that no actions need staging: step k plays, on every board, the action
+ * tpl_explore_actions(epsilon = 1, seed, step0 + k) would put there (uniform in [0, 40), a hash of seed, global board
+ * index and step).  actions_out u8[num_steps][n] (optional) records what was played; the other outputs as tpl_rollout. */
+int tpl_rollout_random(tpl_env* env, uint64_t seed, uint32_t step0, int32_t num_steps, uint8_t* actions_out,
+                       float* reward_steps, uint8_t* done_steps, float* reward_sum, uint32_t* finished, void* stream);
+
 /* Replaces Tetris.get_state() (game/tetris.py:435-436) and the public attributes, batched and in the
  * interchange layout.  Any output may be NULL.  rows [n][20] u16; cur/nxt u8[n] (7 = no such piece);
  * lines/moves u8[n] (lines_cleared, moves_used -- L_rem = L - lines, M_rem = M - moves); state u8[n];

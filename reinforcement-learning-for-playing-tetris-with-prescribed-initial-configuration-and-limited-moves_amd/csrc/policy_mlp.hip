@@ -318,14 +318,6 @@ __global__ __launch_bounds__(64 * kPolicyWaves) void policy_kernel(const PolicyA
 #endif
 }
 
-__device__ __forceinline__ uint32_t explore(uint32_t action, uint64_t seed, uint64_t gidx, uint32_t step, uint32_t eps_q24) {
-    uint32_t u = fmix32((uint32_t)gidx ^ ((uint32_t)(gidx >> 32) * 0x9E3779B9u) ^ (uint32_t)seed ^ 0x51ED270Bu);
-    u = fmix32(u + step * 0x9E3779B1u + (uint32_t)(seed >> 32));
-    // the decision uses the upper 24 bits; the replacement is a second 32-bit draw reduced to [0, 40) by multiply-high
-    // (40 / 2^32 of bias, where eight bits times 40 gave sixteen of the actions 7/256 and the others 6/256)
-    return (u >> 8) < eps_q24 ? __umulhi(fmix32(u ^ 0x2545F491u), 40u) : action;
-}
-
 __global__ __launch_bounds__(kBlock) void explore_kernel(uint8_t* action, int64_t n, uint64_t seed, int64_t global_offset,
                                                         uint32_t step, uint32_t eps_q24) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;

@@ -266,7 +266,10 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
 // same freeze / auto-reset rules, same statistics, and -- when asked for -- the same per-step reward/done.
 struct RolloutArgs {
     StepArgs s;
-    const uint8_t* actions;     // [K][stride]
+    const uint8_t* actions;     // [K][stride]; null in the random form
+    uint64_t random_seed;       // random form: action of step k = explore(seed, global board index, step0 + k), uniform
+    uint32_t step0;
+    uint8_t* actions_out;       // random form: [K][n] or null, the actions that were played
     int64_t action_stride;
     uint32_t K;
     float* reward_steps;        // [K][n] or null
@@ -275,7 +278,7 @@ struct RolloutArgs {
     uint32_t* finished;         // [n] or null: episodes this board finished during the K steps
 };
 
-template <bool kAutoReset>
+template <bool kAutoReset, bool kRandom = false>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
     const StepArgs& p = q.s;
     __shared__ ShapeWord s_shape[32];
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
     if (valid) {
         A = p.plane_a[i];
         B = p.plane_b[i];
-        act = q.actions[i];
+        if (!kRandom) act = q.actions[i];
     }
     // the index of the first step: the clock of the wave's first group, through the scalar cache (as in step_kernel)
     const int64_t wave_first = (int64_t)blockIdx.x * kBlock + (int64_t)(__builtin_amdgcn_readfirstlane((int)threadIdx.x) & ~63);
@@ -310,6 +313,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
         float rsum = 0.0f;
         // per-step streams are walked with running pointers (a 64-bit multiply-add per step and stream otherwise)
         const uint8_t* act_next_ptr = q.actions + i;
+        uint8_t* act_out_ptr = q.actions_out + i;
         float* reward_ptr = q.reward_steps + i;
         uint8_t* done_ptr = q.done_steps + i;
         const bool want_reward = q.reward_steps != nullptr, want_done = q.done_steps != nullptr;   // wave-uniform
@@ -332,8 +336,14 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
             }
             // next step's action is independent of the board: fetch it under this step's move
             uint32_t act_next = 0;
-            act_next_ptr += q.action_stride;
-            if (k + 1 < q.K) act_next = *act_next_ptr;
+            if (kRandom) {
+                // the uniform random policy, drawn on the device (what tpl_explore_actions gives at epsilon = 1)
+                act = explore(0u, q.random_seed, (uint64_t)(p.global_offset + i), q.step0 + k, 1u << 24);
+                if (q.actions_out) { *act_out_ptr = (uint8_t)act; act_out_ptr += p.n; }
+            } else {
+                act_next_ptr += q.action_stride;
+                if (k + 1 < q.K) act_next = *act_next_ptr;
+            }
             uint32_t rot, loc;
             split_small_action(act, rot, loc);
             float reward;
@@ -848,8 +858,34 @@ int tpl_rollout(tpl_env* e, const uint8_t* actions, int64_t action_stride, int32
     q.actions = actions; q.action_stride = action_stride; q.K = (uint32_t)num_steps;
     q.reward_steps = reward_steps; q.done_steps = done_steps; q.reward_sum = reward_sum; q.finished = finished;
     const dim3 grid(blocks_for(e->n)), block(kBlock);
-    if (e->auto_reset) hipLaunchKernelGGL(rollout_kernel<true>, grid, block, 0, (hipStream_t)stream, q);
-    else hipLaunchKernelGGL(rollout_kernel<false>, grid, block, 0, (hipStream_t)stream, q);
+    if (e->auto_reset) hipLaunchKernelGGL((rollout_kernel<true, false>), grid, block, 0, (hipStream_t)stream, q);
+    else hipLaunchKernelGGL((rollout_kernel<false, false>), grid, block, 0, (hipStream_t)stream, q);
+    TPL_HIP(hipGetLastError());
+    count_steps(e, num_steps);
+    return TPL_OK;
+}
+
+int tpl_rollout_random(tpl_env* e, uint64_t seed, uint32_t step0, int32_t num_steps, uint8_t* actions_out, float* reward_steps,
+                       uint8_t* done_steps, float* reward_sum, uint32_t* finished, void* stream) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (num_steps < 1) return fail_msg(TPL_ERR_ARG, "num_steps must be >= 1");
+    if (int rc = check_can_advance(e)) return rc;
+    DeviceGuard guard(e->device);
+    Pool& cur = e->pool[e->cur_slot];
+    if (cur.n_cfg != 0 && !cur.side_ready) {
+        hipLaunchKernelGGL(build_side_kernel, dim3(blocks_for(cur.n_cfg)), dim3(kBlock), 0, (hipStream_t)stream, cur.rec,
+                           e->stride_shift, cur.n_cfg, cur.side);
+        TPL_HIP(hipGetLastError());
+        cur.side_ready = true;
+    }
+    RolloutArgs q{};
+    q.s = make_args(e);
+    q.actions = nullptr; q.action_stride = 0; q.K = (uint32_t)num_steps;
+    q.random_seed = seed; q.step0 = step0; q.actions_out = actions_out;
+    q.reward_steps = reward_steps; q.done_steps = done_steps; q.reward_sum = reward_sum; q.finished = finished;
+    const dim3 grid(blocks_for(e->n)), block(kBlock);
+    if (e->auto_reset) hipLaunchKernelGGL((rollout_kernel<true, true>), grid, block, 0, (hipStream_t)stream, q);
+    else hipLaunchKernelGGL((rollout_kernel<false, true>), grid, block, 0, (hipStream_t)stream, q);
     TPL_HIP(hipGetLastError());
     count_steps(e, num_steps);
     return TPL_OK;

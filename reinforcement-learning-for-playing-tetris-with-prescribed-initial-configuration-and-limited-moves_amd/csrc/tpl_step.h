@@ -99,6 +99,17 @@ __device__ __forceinline__ void split_small_action(uint32_t action, uint32_t& ro
     loc = action - __umul24(rot, 10u);
 }
 
+// Epsilon-greedy exploration (tpl_explore_actions): with probability eps_q24 / 2^24 the action is replaced by a uniform
+// draw from [0, 40), decided by a hash of (seed, global board index, step).  With eps_q24 = 2^24 it is the uniform random
+// policy on the device (tpl_rollout_random).
+__device__ __forceinline__ uint32_t explore(uint32_t action, uint64_t seed, uint64_t gidx, uint32_t step, uint32_t eps_q24) {
+    uint32_t u = fmix32((uint32_t)gidx ^ ((uint32_t)(gidx >> 32) * 0x9E3779B9u) ^ (uint32_t)seed ^ 0x51ED270Bu);
+    u = fmix32(u + step * 0x9E3779B1u + (uint32_t)(seed >> 32));
+    // the decision uses the upper 24 bits; the replacement is a second 32-bit draw reduced to [0, 40) by multiply-high
+    // (40 / 2^32 of bias, where eight bits times 40 gave sixteen of the actions 7/256 and the others 6/256)
+    return (u >> 8) < eps_q24 ? __umulhi(fmix32(u ^ 0x2545F491u), 40u) : action;
+}
+
 // (re)initialise a board from pool entry `cfg` of the current slot.  reset()/load_warm_reset() (:438-449), with the
 // counters zeroed; the record's two state words are one 32-B read.
 __device__ __forceinline__ void load_config(const StepArgs& p, uint32_t cfg, uint4& A, uint4& B) {

@@ -333,6 +333,25 @@ class BatchedTetris:
             raise ValueError(f"actions must be uint8 [>= K, {self.num_envs}] on {self.device} with unit inner stride")
         check(self._lib.tpl_rollout(self._h, _ptr(actions), actions.stride(0), K, None, None, None, None, self._stream()))
 
+    def rollout_random(self, steps: int, seed: int = 0, step0: int = 0, record: bool = False):
+        """`steps` consecutive steps in one launch under the UNIFORM RANDOM POLICY drawn on the device (the loop of
+        game/performance_test.py:13-17): step k plays the action explore_actions(epsilon=1, seed, step0 + k) would draw.
+        No actions are staged.  Returns (reward_sum f32[N], finished int32[N]) and, if record, also
+        (actions uint8[K,N], reward f32[K,N], done bool[K,N])."""
+        if steps < 1:
+            raise ValueError("steps must be positive")
+        n, d = self.num_envs, self.device
+        rsum = torch.empty(n, dtype=torch.float32, device=d)
+        fin = torch.empty(n, dtype=torch.int32, device=d)
+        acts = rs = ds = None
+        if record:
+            acts = torch.empty((steps, n), dtype=torch.uint8, device=d)
+            rs = torch.empty((steps, n), dtype=torch.float32, device=d)
+            ds = torch.empty((steps, n), dtype=torch.uint8, device=d)
+        check(self._lib.tpl_rollout_random(self._h, int(seed), int(step0), int(steps), _ptr(acts), _ptr(rs), _ptr(ds), _ptr(rsum),
+                                           _ptr(fin), self._stream()))
+        return (rsum, fin, acts, rs, ds.view(torch.bool)) if record else (rsum, fin)
+
     def observe(self, dtype=torch.float32, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[N, 217] observation for Model(217, 14) (model/train.py:26)."""
         if out is None:

@@ -428,6 +428,48 @@ def test_compat_tetris_pool_walk_freeze_and_forward_supplier(T):
     game.terminate()
 
 
+@pytest.mark.parametrize("auto", [True, False])
+def test_rollout_random_equals_explore_then_step_and_the_oracle(T, oracle, auto):
+    """tpl_rollout_random (the uniform random policy drawn on the device, K steps per launch) == K x (tpl_explore_actions at
+    epsilon 1, tpl_step) on a twin handle; the recorded actions replayed through the oracle give the same rewards, dones,
+    boards and statistics; two launches continue one another (step0); the draws are uniform."""
+    import torch
+    L, M, n, seed, K = 6, 25, 9001, 19, 41
+    envs = []
+    for _ in range(2):
+        env = T.BatchedTetris(L, M, n, seed=seed, global_offset=12345, auto_reset=auto, reward=(1.0, 2.0, -0.5))
+        rows, pieces = env.synthetic_configs(777)
+        env.load_configs(rows, pieces)
+        env.reset()
+        envs.append(env)
+    fused, ref = envs
+    cpu = oracle.Env(n, L, M, 12345, seed)
+    cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
+    cpu.set_options(auto_reset=auto, assign_mode=0, per_line=1.0, win=2.0, lose=-0.5)
+    cpu.reset()
+    cut = 17
+    r1 = fused.rollout_random(cut, seed=5, step0=1000, record=True)
+    r2 = fused.rollout_random(K - cut, seed=5, step0=1000 + cut, record=True)
+    acts, rs, ds = (torch.cat([a, b]) for a, b in zip(r1[2:], r2[2:]))
+    rsum = np.zeros(n, np.float32)
+    for t in range(K):
+        a = ref.explore_actions(torch.zeros(n, dtype=torch.uint8, device=ref.device), 1.0, seed=5, step=1000 + t)
+        assert torch.equal(acts[t], a), t
+        _, r, d, _ = ref.step(a, observe=False)
+        assert torch.equal(rs[t], r) and torch.equal(ds[t], d), t
+        r_c, d_c = cpu.step(_np(a))
+        assert np.array_equal(_np(r), r_c) and np.array_equal(_np(d).astype(np.uint8), d_c), t
+        if t >= cut:
+            rsum += r_c
+    assert np.array_equal(_np(r2[0]), rsum)
+    _assert_state_equal(_state(fused), cpu.get_state(), "rollout_random")
+    assert fused.stats() == ref.stats() == cpu.stats() and fused.step_clock() == K
+    counts = np.bincount(_np(acts).ravel(), minlength=40).astype(np.float64)
+    assert counts.shape == (40,) and abs(counts / counts.sum() - 1 / 40).max() < 0.002
+    for e in envs:
+        e.terminate()
+
+
 def test_decode_actions(T):
     import torch
     n = 5000
