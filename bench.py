@@ -189,6 +189,33 @@ def measure_config_supply(torch, T, dev, L, M, seed):
                                               "winnable_fraction": float(fw["winnable"].mean())}}
 
 
+def measure_live_supply(torch, T, env, actions, reward, done, seed, count=65536, steps=8000):
+    """The replenished supply under load (game/tetris.py:195-211, 473-488: producers feed the reset queue while games
+    run): PoolRefresher carves `count` configurations at a time on a side stream while the main stream steps, and each
+    finished batch becomes the current pool (boards in mid-episode finish on the buffer they started from)."""
+    n, dev, S = env.num_envs, env.device, actions.shape[0]
+    rows, pieces = T.generate_configs(env.L, env.M, 4096, seed=seed)          # something carved to start from
+    env.load_configs(rows, pieces)
+    env.reset()
+    for t in range(50):
+        env.step_into(actions[t % S], reward, done)
+    torch.cuda.synchronize(dev)
+    ms_alone = timed(torch, dev, lambda: env.step_into(actions[0], reward, done), 500)
+    feeder = T.PoolRefresher(env, count, seed=seed, first=4096)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for t in range(steps):
+        env.step_into(actions[t % S], reward, done)
+        if t % 32 == 31:
+            feeder.poll()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / steps
+    return {"unit": "env-steps/s", "value": float(n) / (ms * 1e-3), "ms_per_step": ms, "ms_per_step_without_refresher": ms_alone,
+            "configurations_per_batch": count, "pool_swaps": feeder.swaps, "steps": steps,
+            "configurations_supplied_per_s": feeder.swaps * count / (ms * 1e-3 * steps)}
+
+
 def measure_carved_pool(torch, T, env, actions, reward, done, W, K, pool, seed):
     """SURVEY 8(d) "realism run": the same step loop on a pool of CARVED (solvable) configurations."""
     n, dev, S = env.num_envs, env.device, actions.shape[0]
@@ -488,9 +515,10 @@ def main():
         ms_r = max_over_ranks(timed(torch, dev, lambda: env.rollout_random(100, seed=args.seed), 4) / 100)
         fused["device_random_policy"] = {"value": float(n) * world / (ms_r * 1e-3), "ms_per_step": ms_r, "steps_per_launch": 100,
                                          "outputs": "reward sums and episode counts only"}
-    carved = None
+    carved = live = None
     if args.carved_pool > 0 and world == 1:
         carved = measure_carved_pool(torch, T, env, actions, reward, done, W, K, args.carved_pool, args.seed)
+        live = measure_live_supply(torch, T, env, actions, reward, done, args.seed)
     env.terminate()
     del actions
 
@@ -543,6 +571,7 @@ def main():
             "fused_rollout": fused,
             "strong_scaling": strong,
             "carved_pool_run": carved,
+            "live_supply_run": live,
             "config1_run": config1,
             "config_supply": supply,
             "actor_loop": actor,
