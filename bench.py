@@ -554,6 +554,9 @@ def main():
                                            "ahead of the first timed launch (it takes the wake-up of the idle queue)",
                        "per_rank_ms_per_step": per_rank_ms, "wall_ms_per_step": wall_ms / K, "collective_ms": collective_ms,
                        "launch_after_synchronize_ms": wake_ms,
+                       "order": "side figures that own their boards (actor loop, config supply, configs[1]; strong scaling for "
+                                "N > 1) ran BEFORE the timed region; those on the main boards (sustained pass, fused rollout, "
+                                "carved pool, live supply) and the CPU baseline after it",
                        "note": "launch_after_synchronize_ms = the last warm-up launch, the one that finds the queue empty "
                                "(outside the timed region); the K timed launches follow it back to back"},
             "ranks_seen": ranks_seen,
