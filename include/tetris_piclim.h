@@ -111,6 +111,9 @@ int tpl_pool_info(tpl_env* env, int32_t* current_slot, int64_t* n_cfg_current, i
  * boards are then as old as they were when the copy was taken, so the swap guard goes back to the value
  * tpl_pool_info reported at that moment.  0 <= steps_until_swap <= M + 1. */
 int tpl_pool_set_hold(tpl_env* env, int64_t steps_until_swap);
+/* For a caller that REPLAYS a captured hipGraph of step launches: the guard above counts steps as they pass through
+ * this API, which a replay does not; tell it how many steps the replay just enqueued.  Host-side. */
+int tpl_note_steps(tpl_env* env, int64_t steps);
 
 /* Replaces Tetris.reset() (game/tetris.py:438-443).  mask == NULL: the step counters and the statistics are
  * zeroed and every board starts an episode at step 0 (from the current pool buffer); otherwise boards with

@@ -10,14 +10,14 @@ from . import _lib
 from ._lib import (LIB_PATH, SYMBOLS, TplError, build_library, carve, forward_generate, generate_configs, pack_policy,
                    shape_info)
 
-__all__ = ["BatchedTetris", "Tetris", "OBS_DIM", "NUM_ACTIONS", "RUNNING", "WON", "LOST", "TplError",
+__all__ = ["BatchedTetris", "Tetris", "Snapshot", "OBS_DIM", "NUM_ACTIONS", "RUNNING", "WON", "LOST", "TplError",
            "RandomPieceGenerator", "get_tetromino", "piece_translations", "carve", "build_library", "shape_info", "generate_configs", "forward_generate", "pack_policy", "LIB_PATH", "SYMBOLS"]
 
 
 def __getattr__(name):
     # env.py needs torch; keep `import tetris_piclim` cheap for callers that only build or bind the library
     import importlib
-    if name in ("BatchedTetris", "Tetris", "OBS_DIM", "NUM_ACTIONS", "RUNNING", "WON", "LOST", "env"):
+    if name in ("BatchedTetris", "Tetris", "Snapshot", "OBS_DIM", "NUM_ACTIONS", "RUNNING", "WON", "LOST", "env"):
         env = importlib.import_module(__name__ + ".env")
         return env if name == "env" else getattr(env, name)
     if name in ("save_pool", "load_pool", "PoolRefresher"):

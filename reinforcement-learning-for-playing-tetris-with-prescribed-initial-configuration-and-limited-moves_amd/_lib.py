@@ -41,7 +41,7 @@ SYMBOLS = [
     "tpl_generate_configs_device_work_bytes", "tpl_generate_configs_device",
     "tpl_policy_image_bytes", "tpl_policy_pack", "tpl_policy_act",
     "tpl_policy_image_bytes_f32", "tpl_policy_pack_f32", "tpl_policy_act_f32",
-    "tpl_explore_actions", "tpl_actor_rollout", "tpl_pool_info", "tpl_pool_set_hold", "tpl_clock_ptr",
+    "tpl_explore_actions", "tpl_actor_rollout", "tpl_pool_info", "tpl_pool_set_hold", "tpl_note_steps", "tpl_clock_ptr",
 ]
 
 TPL_U8, TPL_I32, TPL_I64 = 0, 1, 2
@@ -159,6 +159,7 @@ def lib() -> C.CDLL:
     L.tpl_clock_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.tpl_pool_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.tpl_pool_set_hold.argtypes = [vp, i64]
+    L.tpl_note_steps.argtypes = [vp, i64]
     L.tpl_get_board.argtypes = [vp, vp, vp]
     L.tpl_carve.argtypes = [vp, i32, i32, i32, i32, C.POINTER(i32)]
     L.tpl_set_tuning.argtypes = [vp, i32, i32]

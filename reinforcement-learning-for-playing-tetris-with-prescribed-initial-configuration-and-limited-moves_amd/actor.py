@@ -97,6 +97,8 @@ class Actor:
             if self._graph is None or self._graph_pool != self.env.pool_generation:
                 self._capture()                      # first use, or load_configs() has replaced the pool since
             self._graph.replay()
+            # the library's pool-swap guard counts steps as they pass through its API; a replay does not: tell it
+            self.env.note_steps(1)
         else:
             self._iteration()
 

@@ -642,6 +642,22 @@ static int launch_step(tpl_env* e, const void* act0, const void* act1, int32_t d
     return TPL_OK;
 }
 
+// The resets of the multi-step kernel read the current pool's side records: written once per pool, on first use (a
+// caller that only steps never pays for them).  Under stream capture the build is only RECORDED into the graph -- it
+// has not run when the call returns and runs again with every replay -- so the pool is not marked: the next eager
+// rollout, or a rollout captured into another graph, builds them itself.
+static int ensure_side_records(tpl_env* e, hipStream_t stream) {
+    Pool& cur = e->pool[e->cur_slot];
+    if (cur.n_cfg == 0 || cur.side_ready) return TPL_OK;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    TPL_HIP(hipStreamIsCapturing(stream, &capturing));
+    hipLaunchKernelGGL(build_side_kernel, dim3(blocks_for(cur.n_cfg)), dim3(kBlock), 0, stream, cur.rec, e->stride_shift,
+                       cur.n_cfg, cur.side);
+    TPL_HIP(hipGetLastError());
+    cur.side_ready = capturing == hipStreamCaptureStatusNone;
+    return TPL_OK;
+}
+
 }  // namespace tpl
 
 using namespace tpl;
@@ -802,6 +818,13 @@ int tpl_pool_set_hold(tpl_env* e, int64_t steps_until_swap) {
     return TPL_OK;
 }
 
+int tpl_note_steps(tpl_env* e, int64_t steps) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (steps < 0) return fail_msg(TPL_ERR_ARG, "steps is negative");
+    count_steps(e, steps);
+    return TPL_OK;
+}
+
 int tpl_reset(tpl_env* e, const uint8_t* mask, void* stream) {
     if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
     if (e->pool[e->cur_slot].n_cfg == 0) return fail_msg(TPL_ERR_STATE, "tpl_reset needs tpl_load_configs first");
@@ -845,14 +868,7 @@ int tpl_rollout(tpl_env* e, const uint8_t* actions, int64_t action_stride, int32
     if (action_stride < e->n) return fail_msg(TPL_ERR_ARG, "action_stride %lld is smaller than num_envs", (long long)action_stride);
     if (int rc = check_can_advance(e)) return rc;
     DeviceGuard guard(e->device);
-    // the resets of this kernel read the current pool's side records: written here, once per pool, on first use
-    Pool& cur = e->pool[e->cur_slot];
-    if (cur.n_cfg != 0 && !cur.side_ready) {
-        hipLaunchKernelGGL(build_side_kernel, dim3(blocks_for(cur.n_cfg)), dim3(kBlock), 0, (hipStream_t)stream, cur.rec,
-                           e->stride_shift, cur.n_cfg, cur.side);
-        TPL_HIP(hipGetLastError());
-        cur.side_ready = true;
-    }
+    if (int rc = ensure_side_records(e, (hipStream_t)stream)) return rc;
     RolloutArgs q{};
     q.s = make_args(e);
     q.actions = actions; q.action_stride = action_stride; q.K = (uint32_t)num_steps;
@@ -871,13 +887,7 @@ int tpl_rollout_random(tpl_env* e, uint64_t seed, uint32_t step0, int32_t num_st
     if (num_steps < 1) return fail_msg(TPL_ERR_ARG, "num_steps must be >= 1");
     if (int rc = check_can_advance(e)) return rc;
     DeviceGuard guard(e->device);
-    Pool& cur = e->pool[e->cur_slot];
-    if (cur.n_cfg != 0 && !cur.side_ready) {
-        hipLaunchKernelGGL(build_side_kernel, dim3(blocks_for(cur.n_cfg)), dim3(kBlock), 0, (hipStream_t)stream, cur.rec,
-                           e->stride_shift, cur.n_cfg, cur.side);
-        TPL_HIP(hipGetLastError());
-        cur.side_ready = true;
-    }
+    if (int rc = ensure_side_records(e, (hipStream_t)stream)) return rc;
     RolloutArgs q{};
     q.s = make_args(e);
     q.actions = nullptr; q.action_stride = 0; q.K = (uint32_t)num_steps;

@@ -32,6 +32,23 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+class Snapshot:
+    """What BatchedTetris.snapshot() returns: a copy of the resident state together with what it refers to -- the pool
+    generation and assignment mode it was taken under and the pool-swap guard's value at that moment.  The three travel
+    WITH the copy (clone(), to()), so restore() can always tell a foreign snapshot from its own."""
+
+    __slots__ = ("data", "pool_generation", "assign", "hold")
+
+    def __init__(self, data: torch.Tensor, pool_generation: int, assign: str, hold: int):
+        self.data, self.pool_generation, self.assign, self.hold = data, int(pool_generation), assign, int(hold)
+
+    def clone(self) -> "Snapshot":
+        return Snapshot(self.data.clone(), self.pool_generation, self.assign, self.hold)
+
+    def to(self, *args, **kwargs) -> "Snapshot":
+        return Snapshot(self.data.to(*args, **kwargs), self.pool_generation, self.assign, self.hold)
+
+
 class BatchedTetris:
     """N independent Tetris-piclim boards on one GPU, stepped in lockstep.
 
@@ -117,14 +134,16 @@ class BatchedTetris:
         return x, _INT_CODES[x.dtype]
 
     # ------------------------------------------------------------------------------------------ configs
-    def load_configs(self, rows, pieces) -> None:
+    def load_configs(self, rows, pieces, validate: bool = True) -> None:
         """Upload a pool of prescribed (board, pieces) configurations (the supply behind reset()).
 
         rows: [n_cfg, 20] uint16 (bit x = column x) or [n_cfg, 20, 10] bool; pieces: [n_cfg, M+1] uint8.
         On a live environment this REPLACES the supply without disturbing running boards: the pool goes into the
         handle's other buffer and becomes current; boards that are mid-episode finish on the one they started from.
         Raises (TPL_ERR_STATE) if that other buffer may still be in use -- see pool_info().  The work is enqueued on
-        the current stream (PoolRefresher shows the side-stream form)."""
+        the current stream (PoolRefresher shows the side-stream form).  validate=False skips the piece-id check, which
+        reads device data back and so makes the host wait for the stream: for batches the caller vouches for (the
+        device generator cannot emit an invalid id)."""
         if not isinstance(rows, torch.Tensor):
             rows = np.asarray(rows)
             if rows.ndim == 3:
@@ -141,7 +160,7 @@ class BatchedTetris:
             raise ValueError(f"rows must be [n,20] and pieces [n,{self.M + 1}]; got {tuple(rows.shape)} {tuple(pieces.shape)}")
         if n_cfg == 0:
             raise ValueError("the pool needs at least one configuration")
-        if int(pieces.max()) > 6:                       # tetrominos[piece] of the reference raises IndexError here
+        if validate and int(pieces.max()) > 6:          # tetrominos[piece] of the reference raises IndexError here
             raise ValueError("piece ids must be in 0..6 (I L J T S Z O)")
         nbytes = self._lib.tpl_pool_bytes(n_cfg, self.M)
         pool_mem = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
@@ -162,12 +181,21 @@ class BatchedTetris:
         check(self._lib.tpl_pool_info(self._h, C.byref(slot), C.byref(cur), C.byref(other), C.byref(wait)))
         return dict(current_slot=slot.value, n_configs=cur.value, n_configs_other=other.value, steps_until_swap=wait.value)
 
-    def step_clock(self) -> int:
-        """Steps since the last full reset(), as the device counts them (host sync)."""
+    def _clocks(self) -> torch.Tensor:
+        """The step clocks (one int64 per group of 32 boards) as a view of the workspace."""
         ptr, count = C.c_void_p(), C.c_int64()
         check(self._lib.tpl_clock_ptr(self._h, C.byref(ptr), C.byref(count)))
         off = ptr.value - self._workspace.data_ptr()
-        clocks = self._workspace[off: off + 8 * count.value].view(torch.int64)
+        return self._workspace[off: off + 8 * count.value].view(torch.int64)
+
+    def note_steps(self, steps: int) -> None:
+        """Tell the pool-swap guard that `steps` steps were enqueued by replaying a captured HIP graph (it counts the
+        steps that pass through the C API, which a replay does not)."""
+        check(self._lib.tpl_note_steps(self._h, int(steps)))
+
+    def step_clock(self) -> int:
+        """Steps since the last full reset(), as the device counts them (host sync)."""
+        clocks = self._clocks()
         first = int(clocks[0])
         if not bool((clocks == first).all()):
             raise _lib.TplError("the step clocks of the board groups disagree")
@@ -291,9 +319,7 @@ class BatchedTetris:
                 capture()
             state["graph"].replay()
             # the library counts steps as they pass through its API (the pool-swap guard); a replay does not: tell it
-            hold = self.pool_info()["steps_until_swap"]
-            if hold:
-                check(self._lib.tpl_pool_set_hold(self._h, max(0, hold - K)))
+            check(self._lib.tpl_note_steps(self._h, K))
 
         return replay
 
@@ -433,6 +459,21 @@ class BatchedTetris:
         b = self._workspace[off_b: off_b + n * 16].view(torch.int32).view(n, 4).clone()
         return a, b
 
+    def write_raw_planes(self, a: torch.Tensor, b: torch.Tensor) -> None:
+        """Put two int32 [N, 4] planes (as raw_planes() returns them) into the resident state: mid-game positions that
+        the public surface cannot create -- e.g. lines_cleared / moves_used of a game in progress (the reference lets a
+        caller assign them, game/tetris.py:149-150).  The caller answers for their consistency."""
+        n = self.num_envs
+        pa, pb = C.c_void_p(), C.c_void_p()
+        check(self._lib.tpl_state_ptrs(self._h, C.byref(pa), C.byref(pb)))
+        base = self._workspace.data_ptr()
+        for ptr, src in ((pa, a), (pb, b)):
+            src = src.to(device=self.device, dtype=torch.int32).contiguous()
+            if tuple(src.shape) != (n, 4):
+                raise ValueError(f"a plane must be int32 [{n}, 4]")
+            off = ptr.value - base
+            self._workspace[off: off + n * 16].view(torch.int32).view(n, 4).copy_(src)
+
     def expand_states(self, states_a: torch.Tensor, states_b: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
         """[K, 217] observations of K recorded 32-byte states (int32 [K, 4] pairs as actor_rollout(record_states=True)
         returns them, e.g. a replay-buffer minibatch)."""
@@ -479,23 +520,25 @@ class BatchedTetris:
     moves_used = property(lambda self: self._field("moves"))
     state = property(lambda self: self._field("state"))
 
-    def snapshot(self) -> torch.Tensor:
+    def snapshot(self) -> Snapshot:
         """Copy of the whole resident state (boards, counters, piece windows, step clocks, statistics).  The boards
-        refer to the pool that is loaded now: the copy remembers which."""
-        saved = self._workspace.clone()
-        saved._tpl_pool = (self.pool_generation, self.assign)
-        saved._tpl_hold = self.pool_info()["steps_until_swap"]
-        return saved
+        refer to the pool that is loaded now: the Snapshot remembers which."""
+        return Snapshot(self._workspace.clone(), self.pool_generation, self.assign, self.pool_info()["steps_until_swap"])
 
-    def restore(self, saved: torch.Tensor) -> None:
+    def restore(self, saved: Snapshot) -> None:
         """Put a snapshot() back.  Refused if the pool or the assignment mode has changed since it was taken: the
-        running boards of the snapshot would continue with the piece lists of other configurations."""
-        tag = getattr(saved, "_tpl_pool", None)
-        if tag is not None and tag != (self.pool_generation, self.assign):
+        running boards of the snapshot would continue with the piece lists of other configurations.  A bare tensor is
+        refused too: it cannot say what it was taken under."""
+        if not isinstance(saved, Snapshot):
+            raise TypeError("restore() takes the Snapshot that snapshot() returned (a bare tensor does not say which "
+                            "configuration pool its boards refer to)")
+        if (saved.pool_generation, saved.assign) != (self.pool_generation, self.assign):
             raise _lib.TplError("this snapshot was taken under another configuration pool or assignment mode")
-        self._workspace.copy_(saved)
+        if saved.data.shape != self._workspace.shape:
+            raise _lib.TplError("this snapshot belongs to an environment of another size")
+        self._workspace.copy_(saved.data)
         # the boards are as old again as they were then: so is the guard on the other pool buffer
-        check(self._lib.tpl_pool_set_hold(self._h, getattr(saved, "_tpl_hold", self.pool_info()["steps_until_swap"])))
+        check(self._lib.tpl_pool_set_hold(self._h, saved.hold))
 
     def stats(self) -> dict:
         """Episodes finished since the last full reset: counts for the episodic-return mean (host sync)."""
@@ -536,8 +579,10 @@ class Tetris:
     `solution` is the list of (rotations, location) that wins the current configuration (:155-156).  Like the
     reference's constructor it carves its own prescribed configurations -- with the native generator, a pool of
     `pool_size` at a time instead of two worker processes; `configs=(rows, pieces)` supplies them instead.
-    reset() moves on to another configuration of the pool (entry `moves made so far` mod pool size: the sequential
-    assignment of the batched environment).  render=True (the pygame window, :158-182) is out of scope and raises.
+    reset() moves on to another configuration of the pool (entry `steps so far` mod pool size: the sequential
+    assignment of the batched environment, a step being a move() or a reset() that follows no move -- so that, as with
+    the reference's queue (:445-447), resetting twice in a row gives two different games).  render=True (the pygame
+    window, :158-182) is out of scope and raises.
 
     One divergence from the reference: a FINISHED game is frozen.  The reference's move() keeps popping pieces and
     changing board / moves_used / lines_cleared after `state` has been set (game/tetris.py:354-422 never looks at it);
@@ -600,6 +645,11 @@ class Tetris:
         self._board = self._cache = None
 
     def reset(self) -> None:
+        if self._steps == self._birth:
+            # no move since this game was dealt: let one step pass unplayed (the board is about to be replaced, so its
+            # birth step need not survive), or the masked reset below would deal the same configuration again
+            self._env._clocks().add_(1)
+            self._steps += 1
         self._birth = self._steps
         self._env.reset(mask=[1])
         self._finished = False

@@ -23,7 +23,7 @@ class PoolRefresher:
         feeder = PoolRefresher(env, count=1 << 20)
         while training:
             env.step_into(...)
-            feeder.poll()            # cheap: an event query; swaps at most once per M + 1 steps
+            feeder.poll()            # cheap: an event query, no wait on any stream; swaps at most once per M + 1 steps
     """
 
     def __init__(self, env, count: int, seed: int = 0, first: int = 0):
@@ -31,6 +31,7 @@ class PoolRefresher:
         self.env, self.count, self.seed, self.next_first = env, int(count), int(seed), int(first)
         self.side = torch.cuda.Stream(env.device)
         self._ready = None            # event recorded behind the batch being generated
+        self._bad_host = None         # pinned: the batch's count of configurations that hit the iteration cap
         self._batch = None
         self.swaps = 0
         self.start()
@@ -50,10 +51,14 @@ class PoolRefresher:
             check(env._lib.tpl_generate_configs_device(env.L, env.M, self.seed, self.next_first, n, 0, C.c_void_p(rows.data_ptr()),
                                                        C.c_void_p(pieces.data_ptr()), None, None, C.c_void_p(status.data_ptr()),
                                                        C.c_void_p(work.data_ptr()), nbytes, self.side.cuda_stream))
-            bad = status.sum()                                     # stays on the device until poll() looks at it
+            # how many configurations hit the iteration cap: into pinned host memory, still on the side stream and ahead
+            # of the event, so that poll() reads a host value (no .item(), no wait on any stream)
+            if self._bad_host is None:
+                self._bad_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+            self._bad_host.copy_(status.sum().reshape(1), non_blocking=True)
             self._ready = torch.cuda.Event()
             self._ready.record(self.side)
-        self._batch = (rows, pieces, bad, work, self.next_first)
+        self._batch = (rows, pieces, status, work, self.next_first)
         self.next_first += n
 
     def poll(self) -> bool:
@@ -61,13 +66,14 @@ class PoolRefresher:
         import torch
         if self._ready is None or not self._ready.query() or self.env.pool_info()["steps_until_swap"] > 0:
             return False
-        rows, pieces, bad, _, first = self._batch
-        if int(bad):                                               # the batch is complete: this read does not wait
-            raise RuntimeError(f"{int(bad)} configuration(s) of the batch at {first} hit the generator's iteration cap")
+        rows, pieces, _, _, first = self._batch
+        bad = int(self._bad_host[0])                               # host memory, written ahead of the event that has fired
+        if bad:
+            raise RuntimeError(f"{bad} configuration(s) of the batch at {first} hit the generator's iteration cap")
         main = torch.cuda.current_stream(self.env.device)
         self.side.wait_stream(main)                                # launches that still read the buffer being replaced
         with torch.cuda.stream(self.side):
-            self.env.load_configs(rows, pieces)
+            self.env.load_configs(rows, pieces, validate=False)    # the generator cannot emit an invalid piece id
         main.wait_stream(self.side)                                # the next step sees the packed pool
         for mem in self.env._pool_mems:                            # allocated on the side stream, read on the stepping one
             if mem is not None:

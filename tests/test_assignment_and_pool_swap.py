@@ -262,14 +262,100 @@ def test_actor_graph_is_recaptured_after_a_pool_swap(T, oracle):
     env.reset(); cpu.reset()
     torch.manual_seed(0)
     actor = T.Actor(env, T.PolicyMLP(), dtype=torch.float32, use_graph=True, fused=False)
-    for t in range(60):
-        if t == 25:
-            env.load_configs(*pool_b); cpu.set_pool(*pool_b)
+    for t in range(100):
+        # three swaps, each M + 1 = 21 REPLAYED steps or more after the one before: the swap guard counts the steps
+        # that pass through the C API, so Actor.step() has to tell it about every replay (it did not: the second
+        # swap was refused for good)
+        if t in (25, 50, 75):
+            assert env.pool_info()["steps_until_swap"] == 0, t
+            pool = pool_b if t != 50 else pool_a
+            env.load_configs(*pool); cpu.set_pool(*pool)
         actor.step()
         r_c, d_c = cpu.step(_np(actor.action))
         assert np.array_equal(_np(actor.reward), r_c) and np.array_equal(_np(actor.done), d_c), t
     _same(_state(env), cpu.get_state(), "actor graph")
+    assert env.pool_info()["steps_until_swap"] == 0
     env.terminate()
+
+
+@pytest.mark.gpu
+def test_pool_refresher_keeps_feeding_a_graph_replaying_actor(T, oracle):
+    """PoolRefresher under Actor(use_graph=True): every step is a graph replay, and the supply must keep swapping."""
+    import torch
+    L, M, n, count, seed = 4, 16, 4096, 2048, 13
+    env = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True)
+    first_rows, first_pieces = T.generate_configs(L, M, count, seed=seed, first=0)
+    env.load_configs(first_rows, first_pieces)
+    env.reset()
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_pool(first_rows, first_pieces)
+    cpu.set_options(auto_reset=True, assign_mode=0)
+    cpu.reset()
+    torch.manual_seed(1)
+    actor = T.Actor(env, T.PolicyMLP(), dtype=torch.float32, use_graph=True, fused=True)
+    feeder = T.PoolRefresher(env, count, seed=seed, first=count)
+    for t in range(120):
+        actor.step()
+        r_c, d_c = cpu.step(_np(actor.action))
+        assert np.array_equal(_np(actor.reward), r_c) and np.array_equal(_np(actor.done), d_c), t
+        if t % 4 == 3 and feeder.poll():
+            rows, pieces, _ = feeder.last_batch
+            cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
+    _same(_state(env), cpu.get_state(), "refreshed under graph replay")
+    assert feeder.swaps >= 3, feeder.swaps
+    env.terminate()
+
+
+@pytest.mark.gpu
+def test_snapshot_keeps_its_tags_through_clone_and_bare_tensors_are_refused(T, oracle):
+    L, M, n = 5, 20, 300
+    rows, pieces = oracle.synth_boards(3, 0, 64, L), oracle.synth_pieces(3, 0, 64, M)
+    env = T.BatchedTetris(L, M, n, seed=3, auto_reset=True, config_pool=(rows, pieces))
+    env.reset()
+    env.step(oracle.synth_actions(3, 0, n, 0), observe=False)
+    saved = env.snapshot().clone().to("cpu")              # the tags travel with the copy
+    assert isinstance(saved, T.Snapshot) and saved.pool_generation == env.pool_generation and saved.assign == "hash"
+    before = _state(env)
+    env.step(oracle.synth_actions(3, 0, n, 1), observe=False)
+    env.restore(saved)
+    _same(_state(env), before, "restore of a cloned snapshot")
+    with pytest.raises(TypeError, match="Snapshot"):
+        env.restore(saved.data)
+    env.load_configs(rows, pieces)
+    with pytest.raises(T.TplError, match="another configuration pool"):
+        env.restore(saved)
+    env.terminate()
+
+
+@pytest.mark.gpu
+def test_side_records_first_needed_under_graph_capture(T, oracle):
+    """The multi-step kernel's side records are built by the first rollout against a pool.  When that first rollout is
+    only CAPTURED, the build has not run: a later eager rollout must not trust it (it read uninitialised records)."""
+    import torch
+    L, M, n, seed, K = 4, 12, 3000, 21, 10
+    gpu = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True)
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_options(auto_reset=True, assign_mode=0)
+    pool = (oracle.synth_boards(4, 0, 700, L), oracle.synth_pieces(4, 0, 700, M))
+    gpu.load_configs(*pool); cpu.set_pool(*pool)
+    gpu.reset(); cpu.reset()
+    actions = torch.stack([gpu.synthetic_actions(t) for t in range(K)])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            gpu.rollout_into(actions, K)                         # never replayed
+    torch.cuda.current_stream().wait_stream(side)
+    rsum, fin = gpu.rollout(actions)                              # eager: builds the side records itself
+    want = np.zeros(n, np.float32)
+    for t in range(K):
+        r_c, _ = cpu.step(_np(actions[t]))
+        want = want + r_c
+    assert np.array_equal(_np(rsum), want)
+    _same(_state(gpu), cpu.get_state(), "eager rollout after a captured one")
+    gpu.terminate()
 
 
 @pytest.mark.gpu
@@ -316,6 +402,11 @@ def test_pool_refresher_feeds_a_running_environment_from_a_side_stream(T, oracle
             rows, pieces = _np(rows).view(np.uint16), _np(pieces)
             want_rows, want_pieces = T.generate_configs(L, M, count, seed=seed, first=first)
             assert np.array_equal(rows, want_rows) and np.array_equal(pieces, want_pieces)
+            if len(firsts) == 1:
+                # and against the oracle's own generator (one batch: it builds one configuration per call)
+                for k in range(count):
+                    it, r, p, _ = oracle.generate_config_seeded(L, M, seed, first + k)
+                    assert it >= 0 and np.array_equal(r, rows[k]) and np.array_equal(p, pieces[k]), k
             cpu.set_pool(rows, pieces)
     _same(_state(env), cpu.get_state(), "refreshed")
     assert env.stats() == cpu.stats()

@@ -173,17 +173,27 @@ def test_native_generator_argument_errors():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("L,M,n", [(5, 20, 10000), (10, 40, 3000), (15, 40, 96), (1, 1, 65), (3, 254, 40)])
-def test_device_generator_equals_the_host_generator(L, M, n):
-    """tpl_generate_configs_device (one configuration per lane) == tpl_generate_configs (host threads): boards,
-    piece lists, solutions."""
+def test_device_generator_equals_the_oracle_and_the_host_generator(oracle, L, M, n):
+    """tpl_generate_configs_device (one configuration per lane) against the ORACLE's generator (pinned to the
+    reference's carving loop, game/tetris.py:226-352, by the decision tapes) -- boards, piece lists, solutions -- and
+    against tpl_generate_configs (host threads)."""
     import torch
     import tetris_piclim as T
-    rows, pieces, sol, sol_len = T.generate_configs(L, M, n, seed=12, first=5, with_solutions=True)
     env = T.BatchedTetris(L, M, 64)
     d_rows, d_pieces, d_sol, d_len = env.carved_configs(n, seed=12, first=5, with_solutions=True)
-    assert np.array_equal(d_rows.cpu().numpy().view(np.uint16), rows)
-    assert np.array_equal(d_pieces.cpu().numpy(), pieces)
-    assert np.array_equal(d_len.cpu().numpy(), sol_len) and np.array_equal(d_sol.cpu().numpy(), sol)
+    d_rows, d_pieces = d_rows.cpu().numpy().view(np.uint16), d_pieces.cpu().numpy()
+    d_sol, d_len = d_sol.cpu().numpy(), d_len.cpu().numpy()
+    # the oracle builds one configuration per call: every one of a small batch, a spread of 1500 of a large one
+    picks = np.arange(n) if n <= 1500 else np.unique(np.concatenate([np.arange(750), np.random.default_rng(n).integers(0, n, 750)]))
+    for k in picks:
+        it, r, p, sol_k = oracle.generate_config_seeded(L, M, 12, 5 + int(k))
+        assert it >= 0
+        assert np.array_equal(r, d_rows[k]) and np.array_equal(p, d_pieces[k]), k
+        assert d_len[k] == len(sol_k) and np.array_equal(sol_k, d_sol[k, : d_len[k]]), k
+    rows, pieces, sol, sol_len = T.generate_configs(L, M, n, seed=12, first=5, with_solutions=True)
+    assert np.array_equal(d_rows, rows)
+    assert np.array_equal(d_pieces, pieces)
+    assert np.array_equal(d_len, sol_len) and np.array_equal(d_sol, sol)
     with pytest.raises(T.TplError):
         env.carved_configs(64, seed=12, max_iters=2)       # the cap is reported, not hung on
     env.terminate()

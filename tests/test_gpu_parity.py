@@ -158,13 +158,69 @@ def test_f3_synthetic_against_reference_fingerprints(T, oracle, name):
 
 
 # ------------------------------------------------------------------------------------------------- F4
+def _inject_midgame(env, lines0, moves0, window):
+    """A game in progress, written into the resident planes (the test's own restatement of the
+    layout): lines_cleared -> B.z[27:20], moves_used -> A.y[31:28] (low nibble) and A.w[31:28] (high nibble), the piece
+    window (3-bit ids, entry 0 falls next) -> B.w and B.z[31:28].  The reference's counterpart is plain assignment to
+    game.lines_cleared / game.moves_used / game.pieces (game/tetris.py:149-150, 187)."""
+    import torch
+    a, b = (x.cpu().numpy().view(np.uint32).copy() for x in env.raw_planes())
+    lines0, moves0, window = (np.asarray(v).astype(np.uint64) for v in (lines0, moves0, window))
+    a[:, 1] = (a[:, 1] & 0x0FFFFFFF) | ((moves0 & 15) << 28).astype(np.uint32)
+    a[:, 3] = (a[:, 3] & 0x0FFFFFFF) | (((moves0 >> 4) & 15) << 28).astype(np.uint32)
+    b[:, 2] = (b[:, 2] & 0x000FFFFF) | ((lines0 & 0xFF) << 20).astype(np.uint32) | (((window >> 32) & 15) << 28).astype(np.uint32)
+    b[:, 3] = (window & 0xFFFFFFFF).astype(np.uint32)
+    env.write_raw_planes(torch.from_numpy(a.view(np.int32)), torch.from_numpy(b.view(np.int32)))
+
+
+def _window_of(pieces_abs, cursor, M):
+    """The 36-bit piece window of a board whose next piece is pieces_abs[cursor]: what is left of piece word
+    cursor // 10 (entries [10w, 10w + 12), ids past M read 7) after cursor % 10 pops."""
+    w0 = cursor // 10 * 10
+    ids = [(int(pieces_abs[k]) if k <= M else 7) for k in range(w0, w0 + 12)]
+    return sum(v << (3 * j) for j, v in enumerate(ids[cursor - w0:]))
+
+
+def test_f4_midgame_counters_on_the_hip_path(T):
+    """The F4 cases that begin in mid-game (lines_cleared / moves_used non-zero: game/tetris.py:409-422 with counters
+    carried in) run on the device: the position is written into the resident planes, the step clock set to the moves
+    already made (so that the episode's birth step is 0 and its pool record is found again by the window refill)."""
+    f = load_golden("edges.npz")
+    ran = 0
+    for i in range(int(f["n"])):
+        g = lambda k: f[f"c{i}_{k}"]
+        name = str(f["names"][i])
+        lines0, moves0 = int(g("lines0")), int(g("moves0"))
+        if not (lines0 or moves0):
+            continue
+        L, M = int(g("L")), int(g("M"))
+        given = g("pieces")
+        pieces_abs = np.zeros(M + 1, np.uint8)                    # absolute positions: given[0] falls at move moves0
+        fit = min(len(given), M + 1 - moves0)
+        pieces_abs[moves0: moves0 + fit] = given[:fit]
+        env = T.BatchedTetris(L, M, 1, assign="sequential", config_pool=(g("rows0")[None], pieces_abs[None]))
+        env.reset()
+        _inject_midgame(env, [lines0], [moves0], [_window_of(pieces_abs, moves0, M)])
+        env._clocks().fill_(moves0)
+        for t, (rot, loc) in enumerate(g("actions")):
+            env.move(np.array([rot]), np.array([loc]))
+            s = _state(env)
+            assert np.array_equal(s["rows"][0], g("rows")[t]), (name, t)
+            assert (int(s["lines"][0]), int(s["moves"][0]), int(s["state"][0])) == (g("lines")[t], g("moves")[t], g("state")[t]), (name, t)
+            # pieces consumed so far (the fixture's list may be shorter than what M + 1 - moves0 would leave)
+            assert (M + 1 - moves0) - int(s["pieces_left"][0]) == len(given) - int(g("pieces_left")[t]), (name, t)
+        env.terminate()
+        ran += 1
+    assert ran >= 1
+
+
 def test_f4_edge_cases(T):
     f = load_golden("edges.npz")
     for i in range(int(f["n"])):
         g = lambda k: f[f"c{i}_{k}"]
         name = str(f["names"][i])
         if int(g("lines0")) or int(g("moves0")):
-            continue      # mid-game counters cannot be injected through the public surface; oracle-only case
+            continue      # mid-game cases: test_f4_midgame_counters_on_the_hip_path
         L, M = int(g("L")), int(g("M"))
         pieces = np.full(M + 1, 0, np.uint8)
         given = g("pieces")
@@ -183,25 +239,29 @@ def test_f4_edge_cases(T):
 
 # ------------------------------------------------------------------------------------------------- F5
 def test_f5_random_single_moves(T):
+    """All 4096 reference-generated single moves, the 3590 that start in mid-game included (lines_cleared and
+    moves_used carried in -- up to moves_used > M, which the reference plays on from: game/tetris.py:389-394, 415-422):
+    the counters and the falling piece are written into the resident planes."""
     f = load_golden("random_moves.npz")
-    sel = (f["lines0"] == 0) & (f["moves0"] == 0)
     checked = 0
     for L in np.unique(f["L"]):
         for M in np.unique(f["M"]):
-            idx = np.nonzero(sel & (f["L"] == L) & (f["M"] == M))[0]
+            idx = np.nonzero((f["L"] == L) & (f["M"] == M))[0]
             if len(idx) == 0:
                 continue
             pieces = np.zeros((len(idx), int(M) + 1), np.uint8)
             pieces[:, 0] = f["piece"][idx]
             env = T.BatchedTetris(int(L), int(M), len(idx), assign="sequential", config_pool=(f["rows"][idx], pieces))
             env.reset()
+            # window: the fixture's piece falls next, nothing behind it (moves0 <= 4: no refill is due)
+            _inject_midgame(env, f["lines0"][idx], f["moves0"][idx], f["piece"][idx].astype(np.uint64))
             env.move(f["rot"][idx].astype(np.int32), f["loc"][idx].astype(np.int32))
             s = _state(env)
             _assert_state_equal(s, dict(rows=f["o_rows"][idx], lines=f["o_lines"][idx], moves=f["o_moves"][idx],
                                         state=f["o_state"][idx]), f"L={L} M={M}")
             checked += len(idx)
             env.terminate()
-    assert checked > 300
+    assert checked == 4096
 
 
 # ------------------------------------------------------------------------------------------------- vs oracle
@@ -425,6 +485,14 @@ def test_compat_tetris_pool_walk_freeze_and_forward_supplier(T):
         game.reset()
         assert game.state is None and game.moves_used == 0 and game.lines_cleared == 0
     assert len(seen) > 3
+    # reset() twice with no move in between deals two different games, as the reference's queue does
+    # (game/tetris.py:445-447); the device's step clock follows the wrapper's count
+    dealt = []
+    for _ in range(5):
+        game.reset()
+        dealt.append(game._config())
+        assert game.pieces == game._pieces_host[dealt[-1]].tolist()
+    assert len(set(dealt)) == 5 and game._env.step_clock() == game._steps
     game.terminate()
 
 
