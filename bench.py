@@ -50,7 +50,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3            # f32-input MFMA = the f32 vector rate (MI355X_MICROARCH.md)
 
 
-def numpy_port_leg(L, M, seed, cores, seconds=3.0):
+def numpy_port_leg(L, M, seed, cores, seconds=2.0):
     """the NumPy per-board restatement of the reference's move (oracle/numpy_port.py: the reference's
     own operation sequence, so its rate on a core is the reference's rate on that core), one process per host core.
     Started BEFORE this process touches the GPU (a process that has initialised HIP must not exec another)."""
@@ -68,21 +68,29 @@ def numpy_port_leg(L, M, seed, cores, seconds=3.0):
             "sample": f"{cores} processes x {seconds:.0f} s of move-and-reset over 256 synthetic configurations, L={L} M={M}"}
 
 
-def cpu_baseline(L, M, seed, numpy_leg):
-    """The oracle's loop (game/performance_test.py:13-17 shape: move, reset when finished) on the host cores."""
+def cpu_model():
+    """Model name of the host CPU (SURVEY 8d-ii asks for it beside the core count)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def cpu_baseline(L, M, seed, numpy_leg, seconds=2.0):
+    """The oracle's loop (game/performance_test.py:13-17 shape: move, reset when finished) on the host cores: a bounded
+    sample of about `seconds` of wall time on all the cores the container may use."""
     from oracle import oracle as O
     import tetris_piclim as T
     cores = T._lib.cpu_budget()                                  # affinity mask capped by the cgroup CPU quota
     boards, steps = 262144, 40
     O.bench_run(seed, 4096, L, M, 8, cores)                      # warm the thread pool / page in
+    done, sec = O.bench_run(seed, boards, L, M, steps, cores)    # calibration: a few hundredths of a second
+    steps = int(max(40, min(20000, seconds * (done / sec) / boards)))
     done, sec = O.bench_run(seed, boards, L, M, steps, cores)
-    # bounded sample: grow the step count until the timed part is a few seconds of wall time on all cores
-    for _ in range(3):
-        if sec >= 3.0 or steps >= 20000:
-            break
-        steps = int(max(40, min(20000, 5.0 * (done / sec) / boards)))
-        done, sec = O.bench_run(seed, boards, L, M, steps, cores)
-    out = {"value": done / sec, "unit": "env-steps/s", "cores": cores, "kind": "port",
+    out = {"value": done / sec, "unit": "env-steps/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
            "sample": f"{boards} boards x {steps} lockstep steps, L={L} M={M}, auto-reset, {cores} threads, {sec:.1f}s",
            "numpy_port": numpy_leg}
     if numpy_leg:
@@ -131,13 +139,18 @@ def measure_fused_rollout(torch, T, env, actions, first, K, chunk):
 
 def measure_strong_scaling(torch, T, dev, rank, world, L, M, total, seed, K, chunk, barrier, max_over_ranks):
     """BASELINE configs[3]: ONE batch of `total` boards sharded by global board index over the ranks (fixed total
-    work).  Side figure only; `value` stays the weak-scaling job.  Reported both ways: one launch per step (where the
-    per-launch dispatch gap dominates a shard of 131,072 boards) and `chunk` steps per launch."""
+    work).  Side figure only; `value` stays the weak-scaling job.  It is the G = 1 job, sharded: every rank loads the
+    SAME pool (entry e is synthetic configuration e, for any number of ranks), actions and configuration assignment are
+    keyed by the global board index, and the number of steps depends on the arguments only -- so `episodes` and
+    `mean_episodic_return` are the same numbers for every G (tests/test_multi_rank_gpu.py checks G = 2 against G = 1).
+    Reported both ways: one launch per step (where the per-launch dispatch gap dominates a shard of 131,072 boards)
+    and `chunk` steps per launch."""
     shard = T.sharding.strong_shard(rank, world, total)
     env = T.BatchedTetris(L, M, shard.boards, device=dev, seed=seed, global_offset=shard.global_offset,
                           auto_reset=True, assign="hash")
-    rows, pieces = env.synthetic_configs(shard.boards, first=shard.global_offset)
+    rows, pieces = env.synthetic_configs(total, first=0)          # the whole pool on every rank: 128 B per entry
     env.load_configs(rows, pieces)
+    del rows, pieces
     env.reset()
     S = max(chunk, min(K, 500) // chunk * chunk)
     actions = torch.empty((S, shard.boards), dtype=torch.uint8, device=dev)
@@ -153,10 +166,41 @@ def measure_strong_scaling(torch, T, dev, rank, world, L, M, total, seed, K, chu
     ms_step = max_over_ranks(timed(torch, dev, lambda: env.step_into(actions[next(step)], reward, done), S))
     barrier()
     ms_fused = max_over_ranks(measure_fused_rollout(torch, T, env, actions, 0, S, chunk))
+    steps_made = 20 + S + 2 * S                                   # warm-up, single steps, the fused pass twice (warm + timed)
+    mean_return, episodes = T.sharding.mean_episodic_return(env.stats_tensor(), env.reward_params)
     env.terminate()
-    return {"global_boards": total, "boards_per_gpu": shard.boards, "unit": "env-steps/s",
+    return {"global_boards": total, "boards_per_gpu": shard.boards, "unit": "env-steps/s", "pool_entries": total,
+            "pool": "the same on every rank: entry e = synthetic configuration e",
+            "steps_made": steps_made, "episodes": episodes, "mean_episodic_return": mean_return if episodes else None,
             "one_launch_per_step": {"value": float(total) / (ms_step * 1e-3), "ms_per_step": ms_step},
             "fused_rollout": {"value": float(total) / (ms_fused * 1e-3), "ms_per_step": ms_fused, "steps_per_launch": chunk}}
+
+
+def measure_out_of_cache(torch, T, dev, L, M, seed, boards=1 << 23, pool=1 << 21, steps=100):
+    """The step loop where nothing fits the 256 MiB Infinity Cache: 2^23 boards (256 MiB of state) over a 2^21-entry
+    pool (another 256 MiB).  Reported per 2^20 boards so that it reads beside the main line."""
+    env = T.BatchedTetris(L, M, boards, device=dev, seed=seed, auto_reset=True, assign="hash")
+    rows, pieces = env.synthetic_configs(pool)
+    env.load_configs(rows, pieces)
+    del rows, pieces
+    env.reset()
+    S = 8
+    actions = torch.empty((S, boards), dtype=torch.uint8, device=dev)
+    for t in range(S):
+        env.synthetic_actions(t, out=actions[t])
+    reward = torch.empty(boards, dtype=torch.float32, device=dev)
+    done = torch.empty(boards, dtype=torch.uint8, device=dev)
+    for t in range(10):
+        env.step_into(actions[t % S], reward, done)
+    torch.cuda.synchronize(dev)
+    step = iter(range(steps))
+    ms = timed(torch, dev, lambda: env.step_into(actions[next(step) % S], reward, done), steps)
+    env.terminate()
+    gbs = ALGO_BYTES_PER_BOARD_STEP * boards / (ms * 1e-3) / 1e9
+    return {"boards": boards, "pool_entries": pool, "resident_bytes": boards * 32 + pool * 128,
+            "kernel_ms": ms, "us_per_2^20_boards": ms * 1e3 / (boards / float(1 << 20)),
+            "value": float(boards) / (ms * 1e-3), "unit": "env-steps/s", "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
+            "note": "state (32 B/board) + pool (128 B/entry) = 512 MiB, twice the Infinity Cache: every launch streams from HBM"}
 
 
 def measure_config_supply(torch, T, dev, L, M, seed):
@@ -202,6 +246,7 @@ def measure_live_supply(torch, T, env, actions, reward, done, seed, count=65536,
     torch.cuda.synchronize(dev)
     ms_alone = timed(torch, dev, lambda: env.step_into(actions[0], reward, done), 500)
     feeder = T.PoolRefresher(env, count, seed=seed, first=4096)
+    episodes0 = env.stats()["episodes"]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for t in range(steps):
@@ -211,9 +256,13 @@ def measure_live_supply(torch, T, env, actions, reward, done, seed, count=65536,
     e1.record()
     torch.cuda.synchronize(dev)
     ms = e0.elapsed_time(e1) / steps
+    resets_per_s = (env.stats()["episodes"] - episodes0) / (ms * 1e-3 * steps)
+    fresh_per_s = feeder.swaps * count / (ms * 1e-3 * steps)
     return {"unit": "env-steps/s", "value": float(n) / (ms * 1e-3), "ms_per_step": ms, "ms_per_step_without_refresher": ms_alone,
-            "configurations_per_batch": count, "pool_swaps": feeder.swaps, "steps": steps,
-            "configurations_supplied_per_s": feeder.swaps * count / (ms * 1e-3 * steps)}
+            "slowdown": ms / ms_alone, "configurations_per_batch": count, "pool_swaps": feeder.swaps, "steps": steps,
+            "configurations_supplied_per_s": fresh_per_s, "resets_per_s": resets_per_s,
+            # the reference's reset() blocks on queue.get() (game/tetris.py:445-447): every episode a fresh game, factor 1
+            "pool_reuse_factor": (resets_per_s / fresh_per_s) if fresh_per_s else None}
 
 
 def measure_carved_pool(torch, T, env, actions, reward, done, W, K, pool, seed):
@@ -353,6 +402,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=50, help="steps per launch of the fused-rollout side measurement (0 = skip)")
     ap.add_argument("--sustained", type=int, default=2000, help="launches of the sustained pass after the timed region (0 = skip)")
     ap.add_argument("--no-config1", action="store_true", help="skip the BASELINE configs[1] side line")
+    ap.add_argument("--strong-scaling", action="store_true",
+                    help="run the strong-scaling side figure for N = 1 too (for N > 1 it always runs): the G = 1 job")
+    ap.add_argument("--no-out-of-cache", action="store_true", help="skip the 2^23-board side run (N = 1 only)")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
         ap.error("--gpus and --steps must be positive, --warmup non-negative")
@@ -367,8 +419,9 @@ def main():
                  f"torch.distributed.run with --nproc-per-node equal to --gpus")
 
     # the NumPy leg of the CPU baseline runs in child processes, so it goes first: nothing here has touched the GPU yet
+    # (rank 0 of any world size: the other ranks wait for it in init_process_group)
     numpy_leg = None
-    if world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         import tetris_piclim as T0
         numpy_leg = numpy_port_leg(args.L, args.M, args.seed, T0._lib.cpu_budget())
 
@@ -391,6 +444,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     ranks_seen = dist.get_world_size() if world > 1 else 1
+    backend_seen = dist.get_backend() if world > 1 else None      # what the process group IS, not what was asked for
 
     def barrier():
         if world > 1:
@@ -421,14 +475,16 @@ def main():
             supply = measure_config_supply(torch, T, dev, L, M, args.seed)
         if not args.no_config1:
             config1 = measure_config1(torch, T, dev, args.seed, args.chunk)
-    elif args.chunk > 0:
+    if args.chunk > 0 and (world > 1 or args.strong_scaling):
         strong = measure_strong_scaling(torch, T, dev, rank, world, L, M, n, args.seed, K, args.chunk, barrier, max_over_ranks)
 
     pool = args.pool or n
     shard = T.sharding.weak_shard(rank, world, n)               # batch-index sharding: contiguous blocks
     env = T.BatchedTetris(L, M, n, device=dev, seed=args.seed, global_offset=shard.global_offset, auto_reset=True,
                           assign="hash")
-    rows, pieces = env.synthetic_configs(pool, first=shard.global_offset)
+    # the same pool on every rank (entry e = synthetic configuration e): with actions and assignment keyed by the
+    # global board index, the N-GPU job is ONE job of N x n boards over this pool, sharded
+    rows, pieces = env.synthetic_configs(pool, first=0)
     env.load_configs(rows, pieces)
     del rows, pieces
     env.reset()
@@ -521,17 +577,28 @@ def main():
         live = measure_live_supply(torch, T, env, actions, reward, done, args.seed)
     env.terminate()
     del actions
+    out_of_cache = None
+    if world == 1 and not args.no_out_of_cache:
+        out_of_cache = measure_out_of_cache(torch, T, dev, L, M, args.seed)
+    per_rank_roofline = [{"rank": r, "kernel_ms": ms_r, "achieved": ALGO_BYTES_PER_BOARD_STEP * n / (ms_r * 1e-3) / 1e9,
+                          "frac": ALGO_BYTES_PER_BOARD_STEP * n / (ms_r * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                         for r, ms_r in enumerate(per_rank_ms)]
 
     if rank == 0:
         achieved = ALGO_BYTES_PER_BOARD_STEP * n / (steady_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch by the PMC counters: these cannot be read from inside this process (rocprofv3 collects them
+        # in passes of their own), so the figure comes from the committed profile of this same command and says so
+        traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
+                tj = json.load(open(tpath))
                 # measured at 1,048,576 boards per launch; the kernel's traffic is linear in the board count
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch") * (n / float(1 << 20))
+                traffic = tj.get("hbm_bytes_per_launch") * (n / float(1 << 20))
+                traffic_source = (f"NOT measured in this run: rocprofv3 --pmc passes of this command, {tj.get('source')}"
+                                  f" (commit {tj.get('commit')}), scaled to {n} boards")
             except Exception:
-                traffic = None
+                traffic = traffic_source = None
         out = {
             "metric": "env-steps/sec (whole node) at 1M parallel 20x10 boards",
             "value": float(n) * world * K / (region_ms * 1e-3),
@@ -556,13 +623,18 @@ def main():
                        "launch_after_synchronize_ms": wake_ms,
                        "order": "side figures that own their boards (actor loop, config supply, configs[1]; strong scaling for "
                                 "N > 1) ran BEFORE the timed region; those on the main boards (sustained pass, fused rollout, "
-                                "carved pool, live supply) and the CPU baseline after it",
+                                "carved pool, live supply), the out-of-cache run and the C leg of the CPU baseline after it "
+                                "(its NumPy leg runs in child processes before this process touches the GPU)",
                        "note": "launch_after_synchronize_ms = the last warm-up launch, the one that finds the queue empty "
                                "(outside the timed region); the K timed launches follow it back to back"},
             "ranks_seen": ranks_seen,
-            "backend": (backend if world > 1 else None),
+            "backend": backend_seen,
+            "per_rank_roofline": per_rank_roofline,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         # counter bytes over the same launch period: what the memory system delivered, against the peak
+                         "frac_traffic": (traffic / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "out_of_cache": out_of_cache,
                          "kernel": "step_kernel<action, auto_reset>", "kernel_ms": steady_ms,
                          "kernel_ms_source": "launch period over the K timed launches (HIP events on the launch stream)",
                          "kernel_ms_mean": steady_ms,
@@ -581,7 +653,8 @@ def main():
             "mean_episodic_return": mean_return if episodes else None,
             "episodes": episodes,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # rank 0's host cores, after every collective of the job (the other ranks are on their way out)
             out["cpu_baseline"] = cpu_baseline(L, M, args.seed, numpy_leg)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -56,23 +56,39 @@ def test_two_hip_ranks_equal_one_process_and_the_oracle(tmp_path, oracle, mode):
     assert np.array_equal(got["reward_sum"], rsum) and cpu.stats()["episodes"] == episodes
 
 
-@pytest.mark.gpu
-def test_bench_gpus_2_starts_its_own_ranks():
-    """`python bench.py --gpus 2` outside torchrun (the form the driver uses for N = 1): the parent starts two ranks.
-    On a one-GPU box they share cuda:0 and use gloo (TPL_BENCH_ONE_GPU / TPL_BENCH_BACKEND exist for this rehearsal)."""
+def _bench(gpus, extra=()):
     env = dict(os.environ, TPL_BENCH_ONE_GPU="1", TPL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("RANK", None)
     env.pop("WORLD_SIZE", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--boards", "65536",
-           "--sustained", "100", "--no-cpu-baseline"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "20", "--warmup", "5", "--boards", "65536",
+           "--sustained", "100", "--actor-boards", "0", "--carved-pool", "0", "--no-config1", "--no-out-of-cache", *extra]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
-    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["backend"] == "gloo"
+    return json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_starts_its_own_ranks_and_its_strong_run_is_the_one_rank_job_sharded():
+    """`python bench.py --gpus 2` outside torchrun (the form the driver uses for N = 1): the parent starts two ranks.
+    On a one-GPU box they share cuda:0 and use gloo (TPL_BENCH_ONE_GPU / TPL_BENCH_BACKEND exist for this rehearsal).
+    The strong-scaling figure (BASELINE configs[3]) must be the G = 1 job sharded: the same episodes and the same mean
+    episodic return as the one-rank run of the same command."""
+    out = _bench(2)
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["backend"] == "gloo"      # what dist.get_backend() says
     assert out["steps"] == 20 and out["warmup"] == 5 and len(out["timing"]["per_rank_ms_per_step"]) == 2
-    assert out["strong_scaling"]["global_boards"] == 65536 and out["strong_scaling"]["boards_per_gpu"] == 32768
+    assert [r["rank"] for r in out["per_rank_roofline"]] == [0, 1] and all(r["frac"] > 0 for r in out["per_rank_roofline"])
+    strong = out["strong_scaling"]
+    assert strong["global_boards"] == 65536 and strong["boards_per_gpu"] == 32768 and strong["pool_entries"] == 65536
     assert out["value"] > 0 and out["episodes"] > 0
+    # the line of a multi-rank run carries the CPU baseline too (rank 0's host cores)
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] >= 1 and out["cpu_baseline"]["cpu_model"]
+    one = _bench(1, ["--strong-scaling", "--no-cpu-baseline"])
+    assert one["n_gpus"] == 1 and one["backend"] is None and one["strong_scaling"]["boards_per_gpu"] == 65536
+    for k in ("steps_made", "episodes", "mean_episodic_return"):
+        assert strong[k] == one["strong_scaling"][k], k
+    assert strong["episodes"] > 65536
+    # the weak job on two ranks is one job of 2 x 65536 boards over the same pool: twice the boards, about twice the episodes
+    assert 1.8 < out["episodes"] / one["episodes"] < 2.2
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
