@@ -233,33 +233,42 @@ def measure_config_supply(torch, T, dev, L, M, seed):
                                               "winnable_fraction": float(fw["winnable"].mean())}}
 
 
-def measure_live_supply(torch, T, env, actions, reward, done, seed, count=65536, steps=8000):
+def measure_live_supply(torch, T, env, actions, reward, done, seed, count=65536, min_swaps=3, min_steps=4000, max_steps=40000, **where):
     """The replenished supply under load (game/tetris.py:195-211, 473-488: producers feed the reset queue while games
     run): PoolRefresher carves `count` configurations at a time on a side stream while the main stream steps, and each
-    finished batch becomes the current pool (boards in mid-episode finish on the buffer they started from)."""
+    finished batch becomes the current pool (boards in mid-episode finish on the buffer they started from).  Runs until
+    `min_swaps` batches have been swapped in (and at least `min_steps` steps); the supply rate is batches between the
+    first and the last swap over the wall time between them.  `where` = PoolRefresher's waves / reserved_cus / low_priority."""
     n, dev, S = env.num_envs, env.device, actions.shape[0]
     rows, pieces = T.generate_configs(env.L, env.M, 4096, seed=seed)          # something carved to start from
+    if env.n_configs:
+        env.reset()                                                           # no board left on the buffer about to be replaced
     env.load_configs(rows, pieces)
     env.reset()
     for t in range(50):
         env.step_into(actions[t % S], reward, done)
     torch.cuda.synchronize(dev)
     ms_alone = timed(torch, dev, lambda: env.step_into(actions[0], reward, done), 500)
-    feeder = T.PoolRefresher(env, count, seed=seed, first=4096)
+    feeder = T.PoolRefresher(env, count, seed=seed, first=4096, **where)
     episodes0 = env.stats()["episodes"]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    swap_times = []
     e0.record()
-    for t in range(steps):
-        env.step_into(actions[t % S], reward, done)
-        if t % 32 == 31:
-            feeder.poll()
+    steps = 0
+    while steps < max_steps and (steps < min_steps or len(swap_times) < min_swaps):
+        for t in range(32):
+            env.step_into(actions[(steps + t) % S], reward, done)
+        steps += 32
+        if feeder.poll():
+            swap_times.append(time.perf_counter())       # the host loop runs a bounded queue ahead of the GPU: wall time tracks it
     e1.record()
     torch.cuda.synchronize(dev)
     ms = e0.elapsed_time(e1) / steps
     resets_per_s = (env.stats()["episodes"] - episodes0) / (ms * 1e-3 * steps)
-    fresh_per_s = feeder.swaps * count / (ms * 1e-3 * steps)
+    feeder.close()
+    fresh_per_s = (len(swap_times) - 1) * count / (swap_times[-1] - swap_times[0]) if len(swap_times) >= 2 else None
     return {"unit": "env-steps/s", "value": float(n) / (ms * 1e-3), "ms_per_step": ms, "ms_per_step_without_refresher": ms_alone,
-            "slowdown": ms / ms_alone, "configurations_per_batch": count, "pool_swaps": feeder.swaps, "steps": steps,
+            "slowdown": ms / ms_alone, "configurations_per_batch": count, "pool_swaps": len(swap_times), "steps": steps,
             "configurations_supplied_per_s": fresh_per_s, "resets_per_s": resets_per_s,
             # the reference's reset() blocks on queue.get() (game/tetris.py:445-447): every episode a fresh game, factor 1
             "pool_reuse_factor": (resets_per_s / fresh_per_s) if fresh_per_s else None}
@@ -575,6 +584,16 @@ def main():
     if args.carved_pool > 0 and world == 1:
         carved = measure_carved_pool(torch, T, env, actions, reward, done, W, K, args.carved_pool, args.seed)
         live = measure_live_supply(torch, T, env, actions, reward, done, args.seed)
+        # the same run by the generator's footprint: how many persistent waves share its queue, and -- the form the
+        # round-2 review asked for -- confined to 32 compute units by a CU-masked stream (which turns out to be the
+        # expensive way: profiles/r03_live_supply)
+        live["generator"] = "PoolRefresher defaults: a plain side stream, waves = count / 256"
+        keep = ("ms_per_step", "slowdown", "pool_swaps", "steps", "configurations_per_batch", "configurations_supplied_per_s",
+                "pool_reuse_factor")
+        live["by_generator_footprint"] = [
+            dict(generator=name, **{k: v for k, v in measure_live_supply(torch, T, env, actions, reward, done, args.seed, **kw).items() if k in keep})
+            for name, kw in (("1024 waves", dict(waves=1024)), ("1024 waves, batches of 262144", dict(waves=1024, count=262144)),
+                             ("64 waves", dict(waves=64)), ("256 waves on a 32-CU stream", dict(waves=256, reserved_cus=32)))]
     env.terminate()
     del actions
     out_of_cache = None

@@ -115,6 +115,15 @@ int tpl_pool_set_hold(tpl_env* env, int64_t steps_until_swap);
  * this API, which a replay does not; tell it how many steps the replay just enqueued.  Host-side. */
 int tpl_note_steps(tpl_env* env, int64_t steps);
 
+/* A stream for the producers of the supply to run on beside the stepping stream -- the reference runs its two
+ * producers as separate PROCESSES that compete with the game for nothing but host cores (game/tetris.py:198-211); on the
+ * GPU a generator kernel shares the compute units with the step kernel, whose whole grid is resident at once and slows
+ * down when it is not.  cu_count > 0: work on this stream runs on `cu_count` compute units only (spread evenly over the
+ * XCDs and shader engines), so the generator takes a bounded slice of the chip; cu_count == 0 and low_priority != 0: a
+ * stream of the lowest priority; both 0: a plain non-blocking stream.  The stepping stream is not restricted. */
+int tpl_stream_create(int32_t device_id, int32_t cu_count, int32_t low_priority, void** stream);
+int tpl_stream_destroy(int32_t device_id, void* stream);
+
 /* Replaces Tetris.reset() (game/tetris.py:438-443).  mask == NULL: the step counters and the statistics are
  * zeroed and every board starts an episode at step 0 (from the current pool buffer); otherwise boards with
  * mask[i] != 0 start an episode at the next step.  Unlike the reference, lines_cleared / moves_used / state ARE
@@ -240,6 +249,15 @@ int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t first, int
  * [count] (optional) is 1 for a configuration that hit the iteration cap (max_iters, or 2^22 when 0) and whose
  * outputs are then not a finished configuration.  `work`: tpl_generate_configs_device_work_bytes(M, count) bytes. */
 size_t tpl_generate_configs_device_work_bytes(int32_t M, int64_t count);
+/* The kernel is persistent: its lanes take configurations from a queue until none are left (a lane that held one
+ * configuration for its whole life would idle while the slowest lane of its wave searches on).  `waves` of
+ * tpl_generate_configs_device_waves says how many 64-lane waves share the queue: 0 = automatic (four configurations per
+ * lane, up to two waves per SIMD: the fastest for a generator that has the chip to itself); a small number -- 64 to 256
+ * -- bounds the generator's footprint when it runs BESIDE a stepping environment (every generator wave takes one of a
+ * SIMD's eight wave slots for milliseconds).  The output does not depend on it. */
+int tpl_generate_configs_device_waves(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count, int64_t max_iters,
+                                      int32_t waves, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
+                                      int32_t* solution_len, int32_t* status, void* work, size_t work_bytes, void* stream);
 int tpl_generate_configs_device(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count, int64_t max_iters,
                                 uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* solution_len,
                                 int32_t* status, void* work, size_t work_bytes, void* stream);

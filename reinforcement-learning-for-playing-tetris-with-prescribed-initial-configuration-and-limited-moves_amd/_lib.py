@@ -38,10 +38,10 @@ SYMBOLS = [
     "tpl_set_options", "tpl_load_configs", "tpl_reset", "tpl_move", "tpl_step", "tpl_get_state",
     "tpl_expand_obs", "tpl_expand_states", "tpl_get_board", "tpl_carve", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
     "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_rollout_random", "tpl_decode_actions", "tpl_generate_configs", "tpl_generate_configs_pyseed", "tpl_forward_generate",
-    "tpl_generate_configs_device_work_bytes", "tpl_generate_configs_device",
+    "tpl_generate_configs_device_work_bytes", "tpl_generate_configs_device", "tpl_generate_configs_device_waves",
     "tpl_policy_image_bytes", "tpl_policy_pack", "tpl_policy_act",
     "tpl_policy_image_bytes_f32", "tpl_policy_pack_f32", "tpl_policy_act_f32",
-    "tpl_explore_actions", "tpl_actor_rollout", "tpl_pool_info", "tpl_pool_set_hold", "tpl_note_steps", "tpl_clock_ptr",
+    "tpl_explore_actions", "tpl_actor_rollout", "tpl_pool_info", "tpl_pool_set_hold", "tpl_note_steps", "tpl_clock_ptr", "tpl_stream_create", "tpl_stream_destroy",
 ]
 
 TPL_U8, TPL_I32, TPL_I64 = 0, 1, 2
@@ -160,6 +160,8 @@ def lib() -> C.CDLL:
     L.tpl_pool_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.tpl_pool_set_hold.argtypes = [vp, i64]
     L.tpl_note_steps.argtypes = [vp, i64]
+    L.tpl_stream_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
+    L.tpl_stream_destroy.argtypes = [i32, vp]
     L.tpl_get_board.argtypes = [vp, vp, vp]
     L.tpl_carve.argtypes = [vp, i32, i32, i32, i32, C.POINTER(i32)]
     L.tpl_set_tuning.argtypes = [vp, i32, i32]
@@ -168,6 +170,7 @@ def lib() -> C.CDLL:
     L.tpl_generate_configs_device_work_bytes.restype = sz
     L.tpl_generate_configs_device_work_bytes.argtypes = [i32, i64]
     L.tpl_generate_configs_device.argtypes = [i32, i32, u64, i64, i64, i64, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.tpl_generate_configs_device_waves.argtypes = [i32, i32, u64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp, sz, vp]
     L.tpl_forward_generate.argtypes = [i32, i32, i32, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp]
     L.tpl_synth_configs.argtypes = [vp, u64, i64, i64, vp, vp, vp]
     L.tpl_synth_actions.argtypes = [vp, u64, i64, i64, u64, vp, vp]

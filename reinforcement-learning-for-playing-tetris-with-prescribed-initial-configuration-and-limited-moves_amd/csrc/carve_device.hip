@@ -12,8 +12,15 @@
 // the reversed arrays and truncating on a reload gives the same lists without ever copying them, and a checkpoint
 // is just the ten columns and a length.
 //
-// The search loop is data dependent per lane and has no natural bound (the reference's has none either): every lane
-// stops after `max_iters` iterations (a hard cap applies when the caller passes 0) and reports it in `status`.
+// The search loop is data dependent per lane -- a configuration takes 2,400 iterations on average at L = 10 and ten times
+// that now and then -- so a wave that held 64 configurations for their whole life would run at the pace of its slowest
+// lane with the others idle (measured: 12 of 64 lanes active per vector instruction, profiles/r03_carve).  The kernel is
+// therefore PERSISTENT with a work queue: a launch has fewer lanes than configurations, and a lane that finishes one
+// takes the index of the next from a counter in memory (one atomic add) until none are left.  Which lane builds a
+// configuration does not matter -- configuration k is a function of (seed, first + k) alone.  The wave leaves when all
+// its lanes have found the queue empty, which every lane does after finitely many iterations: the loop of one
+// configuration has no natural bound (the reference's has none either), so every configuration stops after
+// `max_iters` iterations (a hard cap applies when the caller passes 0) and reports it in `status`.
 #include "tpl_internal.h"
 
 namespace tpl {
@@ -30,8 +37,9 @@ struct CarveArgs {
     uint8_t* solution;     // [count][M][2] or null
     int32_t* solution_len; // [count] or null
     int32_t* status;       // [count] or null: 0 finished, 1 stopped at the iteration cap
-    uint8_t* work;         // [count][work_stride]
+    uint8_t* work;         // [lanes][work_stride]: one slice per LANE of the launch
     int64_t work_stride;
+    unsigned long long* next;   // the queue: index of the next configuration nobody has taken yet (zeroed before the launch)
 };
 
 struct DShape { uint32_t pat16, w, h; uint32_t bias; };   // column nibbles, width, height, per-column 3 - revtopo bytes
@@ -119,96 +127,138 @@ __device__ __forceinline__ bool carve(uint32_t* c, const DShape& s, uint32_t loc
 
 constexpr uint32_t kFullBag = 0u | 1u << 3 | 2u << 6 | 3u << 9 | 4u << 12 | 5u << 15 | 6u << 18;
 
-__global__ __launch_bounds__(64) void carve_kernel(const CarveArgs p) {
-    const int64_t k = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (k >= p.count) return;
-    const uint64_t base = rng_base(p.seed, 4, (uint64_t)(p.first + k));
-    uint64_t counter = 0;
-    auto randint = [&](int lo, int hi) { return rng_range(rng_at(base, counter++), lo, hi); };
+// one configuration under construction, in the registers of its lane
+struct Search {
+    uint32_t c[kCols];          // the board's columns
+    uint32_t bag;               // the 7-bag as 3-bit fields
+    int n_bag, n, n_cp, attempts, uses;
+    int64_t iters;
+    uint64_t base, counter;     // the configuration's decision stream
+    __device__ __forceinline__ int randint(int lo, int hi) { return rng_range(rng_at(base, counter++), lo, hi); }
+};
 
-    // this lane's slice of the work memory: reversed piece list, reversed solution, checkpoints
-    uint8_t* pieces_rev = p.work + k * p.work_stride;
-    uint8_t* sol_rev = pieces_rev + 256;
-    uint32_t* cps = (uint32_t*)(sol_rev + 512);                             // entries of 11 words: ten columns, length
-    const int max_cps = p.M / 7 + 3;
+// this lane's slice of the work memory: reversed piece list, reversed solution, checkpoints (entries of 11 words: ten
+// columns, list length)
+struct Slice { uint8_t* pieces_rev; uint8_t* sol_rev; uint32_t* cps; };
 
-    uint32_t c[kCols];
+__device__ __forceinline__ void begin_search(Search& g, const CarveArgs& p, int64_t k) {
     const uint32_t filled = p.L >= kRows ? kColMask : (((1u << p.L) - 1u) << (kRows - p.L));
+    g.base = rng_base(p.seed, 4, (uint64_t)(p.first + k));
+    g.counter = 0;
 #pragma unroll
-    for (int x = 0; x < kCols; ++x) c[x] = filled;                          // :228
-    uint32_t bag = 0;
-    int n_bag = 0, n = 0, n_cp = 0, attempts = 0, uses = 0;
-    int64_t iters = 0;
-    const int64_t cap = p.max_iters > 0 ? p.max_iters : kHardIterationCap;
-    bool capped = false;
+    for (int x = 0; x < kCols; ++x) g.c[x] = filled;                        // :228
+    g.bag = 0; g.n_bag = 0; g.n = 0; g.n_cp = 0; g.attempts = 0; g.uses = 0; g.iters = 0;
+}
 
-    for (;;) {
-        int bottom = 0;
+__device__ __forceinline__ bool solved(const Search& g) {
+    int bottom = 0;
 #pragma unroll
-        for (int x = 0; x < kCols; ++x) bottom += (c[x] >> (kRows - 1)) & 1u;
-        if (bottom <= 8) break;                                             // :234
-        if (iters++ >= cap) { capped = true; break; }
-        bool fresh = false;                                                 // _regenerate (:71-81)
-        if (n_bag == 0) { bag = kFullBag; n_bag = 7; fresh = true; }
-        const int idx = randint(0, n_bag - 1);                              // :85
-        const uint32_t piece = (bag >> (3 * idx)) & 7u;
-        if (fresh && n_cp < max_cps) {                                      // :239-247
-            uint32_t* e = cps + n_cp * 11;
+    for (int x = 0; x < kCols; ++x) bottom += (g.c[x] >> (kRows - 1)) & 1u;
+    return bottom <= 8;                                                     // :234
+}
+
+// one trip of the reference's while loop (:234-279)
+__device__ __forceinline__ void search_iteration(Search& g, const Slice& w, const CarveArgs& p) {
+    const int max_cps = p.M / 7 + 3;
+    bool fresh = false;                                                     // _regenerate (:71-81)
+    if (g.n_bag == 0) { g.bag = kFullBag; g.n_bag = 7; fresh = true; }
+    const int idx = g.randint(0, g.n_bag - 1);                              // :85
+    const uint32_t piece = (g.bag >> (3 * idx)) & 7u;
+    if (fresh && g.n_cp < max_cps) {                                        // :239-247
+        uint32_t* e = w.cps + g.n_cp * 11;
 #pragma unroll
-            for (int x = 0; x < kCols; ++x) e[x] = c[x];
-            e[10] = (uint32_t)n;
-            ++n_cp;
-        }
-        const int rotations = randint(0, 3);                                // :250
-        const DShape s = shape_of(piece, (uint32_t)rotations);
-        const int loc = randint(0, kCols - (int)s.w);                       // :253
-        if (n < p.M && carve(c, s, (uint32_t)loc, n == 0)) {                // :257
-            pieces_rev[n] = (uint8_t)piece;                                 // insert(0, ...) (:258-260), reversed
-            sol_rev[2 * n] = (uint8_t)rotations;
-            sol_rev[2 * n + 1] = (uint8_t)loc;
-            ++n;
-            const uint32_t low = bag & ((1u << (3 * idx)) - 1u);            // delete_index (:262)
-            bag = low | ((bag >> (3 * (idx + 1))) << (3 * idx));
-            --n_bag;
-        } else if (n >= p.M || ++attempts > 40) {                           // :268, add_attempt (:121-123)
-            attempts = 0;                                                   // load_checkpoint (:128-137)
-            if (n_cp > 1 && uses > 10) { --n_cp; uses = 0; }
-            else ++uses;
-            const uint32_t* e = cps + (n_cp - 1) * 11;
-#pragma unroll
-            for (int x = 0; x < kCols; ++x) c[x] = e[x];                    // :275-276
-            n = (int)e[10];
-            bag = kFullBag; n_bag = 7;                                      // :278
-        }
+        for (int x = 0; x < kCols; ++x) e[x] = g.c[x];
+        e[10] = (uint32_t)g.n;
+        ++g.n_cp;
     }
+    const int rotations = g.randint(0, 3);                                  // :250
+    const DShape s = shape_of(piece, (uint32_t)rotations);
+    const int loc = g.randint(0, kCols - (int)s.w);                         // :253
+    if (g.n < p.M && carve(g.c, s, (uint32_t)loc, g.n == 0)) {              // :257
+        w.pieces_rev[g.n] = (uint8_t)piece;                                 // insert(0, ...) (:258-260), reversed
+        w.sol_rev[2 * g.n] = (uint8_t)rotations;
+        w.sol_rev[2 * g.n + 1] = (uint8_t)loc;
+        ++g.n;
+        const uint32_t low = g.bag & ((1u << (3 * idx)) - 1u);              // delete_index (:262)
+        g.bag = low | ((g.bag >> (3 * (idx + 1))) << (3 * idx));
+        --g.n_bag;
+    } else if (g.n >= p.M || ++g.attempts > 40) {                           // :268, add_attempt (:121-123)
+        g.attempts = 0;                                                     // load_checkpoint (:128-137)
+        if (g.n_cp > 1 && g.uses > 10) { --g.n_cp; g.uses = 0; }
+        else ++g.uses;
+        const uint32_t* e = w.cps + (g.n_cp - 1) * 11;
+#pragma unroll
+        for (int x = 0; x < kCols; ++x) g.c[x] = e[x];                      // :275-276
+        g.n = (int)e[10];
+        g.bag = kFullBag; g.n_bag = 7;                                      // :278
+    }
+}
 
+// configuration k is finished (or gave up at the cap): lists un-reversed, the piece list filled up to M + 1 (:281-284),
+// the board in the interchange layout
+__device__ __forceinline__ void write_configuration(Search& g, const Slice& w, const CarveArgs& p, int64_t k, bool capped) {
     if (p.status) p.status[k] = capped ? 1 : 0;
-    if (p.solution_len) p.solution_len[k] = n;
+    if (p.solution_len) p.solution_len[k] = g.n;
     uint8_t* out = p.pieces + k * (p.M + 1);
-    for (int i = 0; i < n; ++i) {                                           // un-reverse
-        out[i] = pieces_rev[n - 1 - i];
+    int n = g.n;
+    for (int i = 0; i < n; ++i) {
+        out[i] = w.pieces_rev[n - 1 - i];
         if (p.solution) {
-            p.solution[(k * p.M + i) * 2 + 0] = sol_rev[2 * (n - 1 - i)];
-            p.solution[(k * p.M + i) * 2 + 1] = sol_rev[2 * (n - 1 - i) + 1];
+            p.solution[(k * p.M + i) * 2 + 0] = w.sol_rev[2 * (n - 1 - i)];
+            p.solution[(k * p.M + i) * 2 + 1] = w.sol_rev[2 * (n - 1 - i) + 1];
         }
     }
-    int need = p.M - n + 1;                                                 // :281-284, get_random_sequence (:95-102)
+    int need = p.M - n + 1;                                                 // get_random_sequence (:95-102)
     while (need > 0) {
-        if (n_bag == 0) { bag = kFullBag; n_bag = 7; }
-        for (int i = n_bag - 1; i >= 1; --i) {                              // random.shuffle (:93)
-            const int j = randint(0, i);
-            const uint32_t vi = (bag >> (3 * i)) & 7u, vj = (bag >> (3 * j)) & 7u;
-            bag = (bag & ~(7u << (3 * i))) | (vj << (3 * i));
-            bag = (bag & ~(7u << (3 * j))) | (vi << (3 * j));
+        if (g.n_bag == 0) { g.bag = kFullBag; g.n_bag = 7; }
+        for (int i = g.n_bag - 1; i >= 1; --i) {                            // random.shuffle (:93)
+            const int j = g.randint(0, i);
+            const uint32_t vi = (g.bag >> (3 * i)) & 7u, vj = (g.bag >> (3 * j)) & 7u;
+            g.bag = (g.bag & ~(7u << (3 * i))) | (vj << (3 * i));
+            g.bag = (g.bag & ~(7u << (3 * j))) | (vi << (3 * j));
         }
-        const int take = need < n_bag ? need : n_bag;
-        for (int i = 0; i < take; ++i) out[n + i] = (uint8_t)((bag >> (3 * i)) & 7u);
+        const int take = need < g.n_bag ? need : g.n_bag;
+        for (int i = 0; i < take; ++i) out[n + i] = (uint8_t)((g.bag >> (3 * i)) & 7u);
         n += take; need -= take;
-        n_bag = 0;                                                          // :100
+        g.n_bag = 0;                                                        // :100
     }
     uint16_t* rows = p.rows + k * kRows;
 #pragma unroll
-    for (int r = 0; r < kRows; ++r) rows[r] = (uint16_t)row_of_cols(c, r);
+    for (int r = 0; r < kRows; ++r) rows[r] = (uint16_t)row_of_cols(g.c, r);
+}
+
+__global__ __launch_bounds__(64) void carve_kernel(const CarveArgs p) {
+    const int64_t slot = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    Slice w;
+    w.pieces_rev = p.work + slot * p.work_stride;
+    w.sol_rev = w.pieces_rev + 256;
+    w.cps = (uint32_t*)(w.sol_rev + 512);
+    const int64_t cap = p.max_iters > 0 ? p.max_iters : kHardIterationCap;
+
+    Search g;
+    begin_search(g, p, 0);
+    int64_t k = 0;                                                          // the configuration this lane is building
+    bool busy = false, dry = false;                                         // dry: this lane found the queue empty
+    for (;;) {
+        if (!busy && !dry) {
+            k = (int64_t)atomicAdd(p.next, 1ULL);
+            dry = k >= p.count;
+            busy = !dry;
+            if (busy) begin_search(g, p, k);
+        }
+        // every lane of the wave stays in the loop until all of them are dry: the exit is wave-uniform
+        if (__ballot(busy) == 0ULL) break;
+        if (busy) {
+            const bool done = solved(g), capped = !done && g.iters >= cap;
+            if (!done && !capped) {
+                ++g.iters;
+                search_iteration(g, w, p);
+            } else {
+                write_configuration(g, w, p, k, capped);
+                busy = false;
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -216,27 +266,49 @@ __global__ __launch_bounds__(64) void carve_kernel(const CarveArgs p) {
 
 using namespace tpl;
 
+// work memory: one slice per lane of the launch (never more lanes than configurations, rounded up to whole waves), then
+// the queue's counter on a line of its own
+static size_t work_stride_bytes(int32_t M) { return (256 + 512 + (size_t)(M / 7 + 3) * 44 + 63) / 64 * 64; }
+static size_t work_slices(int64_t count) { return ((size_t)count + 63) / 64 * 64; }
+
 extern "C" size_t tpl_generate_configs_device_work_bytes(int32_t M, int64_t count) {
     if (M < 1 || count < 1) return 0;
-    const size_t stride = (256 + 512 + (size_t)(M / 7 + 3) * 44 + 63) / 64 * 64;
-    return stride * (size_t)count;
+    return work_stride_bytes(M) * work_slices(count) + 64;
+}
+
+extern "C" int tpl_generate_configs_device_waves(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count,
+                                                 int64_t max_iters, int32_t waves, uint16_t* rows, uint8_t* pieces,
+                                                 uint8_t* solution, int32_t* solution_len, int32_t* status, void* work,
+                                                 size_t work_bytes, void* stream) {
+    if (L < 1 || L > 16) return fail_msg(TPL_ERR_ARG, "carving needs 1 <= L <= 16 (got %d)", L);
+    if (M < 1 || M > 254) return fail_msg(TPL_ERR_ARG, "M=%d out of range [1, 254]", M);
+    if (count < 1 || first < 0 || !rows || !pieces) return fail_msg(TPL_ERR_ARG, "bad count / first / output pointers");
+    if (waves < 0) return fail_msg(TPL_ERR_ARG, "waves is negative");
+    const size_t need = tpl_generate_configs_device_work_bytes(M, count);
+    if (!work || work_bytes < need) return fail_msg(TPL_ERR_ARG, "work has %zu bytes, need %zu", work_bytes, need);
+    if (((uintptr_t)work & 7u) != 0) return fail_msg(TPL_ERR_ARG, "work must be 8-byte aligned");
+    // how many waves share the queue.  Automatic: four configurations per lane on average (the wave's tail is then one
+    // configuration out of four or more), at most two waves per SIMD of the chip.
+    const int64_t most = (count + 63) / 64;
+    int64_t launch = waves > 0 ? waves : (count + 255) / 256;
+    if (launch > most) launch = most;
+    if (waves == 0 && launch > 2048) launch = 2048;
+    if (launch < 1) launch = 1;
+    CarveArgs p{};
+    p.L = L; p.M = M; p.seed = seed; p.first = first; p.count = count; p.max_iters = max_iters;
+    p.rows = rows; p.pieces = pieces; p.solution = solution; p.solution_len = solution_len; p.status = status;
+    p.work = (uint8_t*)work; p.work_stride = (int64_t)work_stride_bytes(M);
+    p.next = (unsigned long long*)((uint8_t*)work + work_stride_bytes(M) * work_slices(count));
+    TPL_HIP(hipMemsetAsync(p.next, 0, sizeof(unsigned long long), (hipStream_t)stream));
+    hipLaunchKernelGGL(carve_kernel, dim3((unsigned)launch), dim3(64), 0, (hipStream_t)stream, p);
+    TPL_HIP(hipGetLastError());
+    return TPL_OK;
 }
 
 extern "C" int tpl_generate_configs_device(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count,
                                            int64_t max_iters, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
                                            int32_t* solution_len, int32_t* status, void* work, size_t work_bytes,
                                            void* stream) {
-    if (L < 1 || L > 16) return fail_msg(TPL_ERR_ARG, "carving needs 1 <= L <= 16 (got %d)", L);
-    if (M < 1 || M > 254) return fail_msg(TPL_ERR_ARG, "M=%d out of range [1, 254]", M);
-    if (count < 1 || first < 0 || !rows || !pieces) return fail_msg(TPL_ERR_ARG, "bad count / first / output pointers");
-    const size_t need = tpl_generate_configs_device_work_bytes(M, count);
-    if (!work || work_bytes < need) return fail_msg(TPL_ERR_ARG, "work has %zu bytes, need %zu", work_bytes, need);
-    if (((uintptr_t)work & 3u) != 0) return fail_msg(TPL_ERR_ARG, "work must be 4-byte aligned");
-    CarveArgs p{};
-    p.L = L; p.M = M; p.seed = seed; p.first = first; p.count = count; p.max_iters = max_iters;
-    p.rows = rows; p.pieces = pieces; p.solution = solution; p.solution_len = solution_len; p.status = status;
-    p.work = (uint8_t*)work; p.work_stride = (int64_t)(need / (size_t)count);
-    hipLaunchKernelGGL(carve_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, (hipStream_t)stream, p);
-    TPL_HIP(hipGetLastError());
-    return TPL_OK;
+    return tpl_generate_configs_device_waves(L, M, seed, first, count, max_iters, 0, rows, pieces, solution, solution_len,
+                                             status, work, work_bytes, stream);
 }

@@ -111,6 +111,13 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         asm volatile("" ::"v"(A[k].x), "v"(B[k].x), "v"(a0[k]), "v"(a1[k]), "s"(clock[k]));
     }
     TPL_STAMP(1);
+    // From here on the wave issues ahead of any wave of another kernel on its SIMD.  A supply generator running beside
+    // the environment (PoolRefresher: long-lived, vector-ALU-bound waves) otherwise wins the issue arbitration as the
+    // OLDEST wave of every SIMD it sits on, and a launch whose whole grid is resident at once lasts as long as its
+    // slowest SIMD: 19.1 us per step instead of 15.4 with 1024 generator waves, 18.0 even with 32; 16.3 / 15.9 with this
+    // line (profiles/r03_live_supply).  Raised only now, after the state words have arrived: at kernel entry it delays the
+    // loads of the waves that start later (+0.35 us on the launch alone); here it costs nothing alone.
+    __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int k = 0; k < kBpl; ++k) {
         moves[k] = packed_moves(A[k]);
@@ -815,6 +822,47 @@ int tpl_pool_set_hold(tpl_env* e, int64_t steps_until_swap) {
     if (steps_until_swap < 0 || steps_until_swap > (int64_t)e->M + 1) return fail_msg(TPL_ERR_ARG, "steps_until_swap out of [0, M + 1]");
     e->other_slot_live = steps_until_swap > 0;
     e->steps_since_swap = (int64_t)e->M + 1 - steps_until_swap;
+    return TPL_OK;
+}
+
+int tpl_stream_create(int32_t device_id, int32_t cu_count, int32_t low_priority, void** stream) {
+    if (!stream) return fail_msg(TPL_ERR_ARG, "stream is null");
+    *stream = nullptr;
+    int ndev = 0;
+    TPL_HIP(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail_msg(TPL_ERR_ARG, "device %d not in [0, %d)", device_id, ndev);
+    DeviceGuard guard(device_id);
+    if (!guard.ok) return fail_msg(TPL_ERR_HIP, "hipSetDevice(%d) failed", device_id);
+    hipDeviceProp_t prop;
+    TPL_HIP(hipGetDeviceProperties(&prop, device_id));
+    const int cus = prop.multiProcessorCount;
+    if (cu_count < 0 || cu_count > cus) return fail_msg(TPL_ERR_ARG, "cu_count %d not in [0, %d]", cu_count, cus);
+    hipStream_t s = nullptr;
+    if (cu_count > 0) {
+        // The driver deals the mask's bits out round-robin: bit i -> XCD i mod 8, then shader engine, then CU -- so the
+        // LOW cu_count bits are an even spread over the chip's XCDs and shader engines (32 = one CU in each of the four
+        // shader engines of each of the eight XCDs).
+        uint32_t mask[32] = {0};
+        const uint32_t words = (uint32_t)(cus + 31) / 32u;
+        for (int i = 0; i < cu_count; ++i) mask[i >> 5] |= 1u << (i & 31);
+        TPL_HIP(hipExtStreamCreateWithCUMask(&s, words, mask));
+    } else if (low_priority) {
+        int least = 0, greatest = 0;
+        TPL_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        TPL_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));
+    } else {
+        TPL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    }
+    *stream = s;
+    return TPL_OK;
+}
+
+int tpl_stream_destroy(int32_t device_id, void* stream) {
+    if (!stream) return TPL_OK;
+    DeviceGuard guard(device_id);
+    if (!guard.ok) return fail_msg(TPL_ERR_HIP, "hipSetDevice(%d) failed", device_id);
+    TPL_HIP(hipStreamSynchronize((hipStream_t)stream));
+    TPL_HIP(hipStreamDestroy((hipStream_t)stream));
     return TPL_OK;
 }
 

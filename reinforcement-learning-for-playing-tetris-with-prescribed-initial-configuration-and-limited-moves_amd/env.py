@@ -202,8 +202,9 @@ class BatchedTetris:
         return first
 
     def carved_configs(self, count: int, seed: Optional[int] = None, first: int = 0, with_solutions: bool = False,
-                       max_iters: int = 0):
-        """Carved (solvable) configurations generated ON THE DEVICE, one per lane -- the same configurations
+                       max_iters: int = 0, waves: int = 0):
+        """Carved (solvable) configurations generated ON THE DEVICE (a persistent kernel whose lanes take configurations
+        from a queue; `waves` = how many 64-lane waves share it, 0 = automatic) -- the same configurations
         generate_configs(L, M, count, seed, first) builds on the host.  Returns device tensors (rows int16 [count, 20],
         pieces uint8 [count, M+1]) and, with_solutions, (solution uint8 [count, M, 2], solution_len int32 [count]);
         raises if a configuration hit the iteration cap."""
@@ -216,8 +217,9 @@ class BatchedTetris:
         status = torch.empty(count, dtype=torch.int32, device=d)
         nbytes = self._lib.tpl_generate_configs_device_work_bytes(self.M, count)
         work = torch.empty(nbytes, dtype=torch.uint8, device=d)
-        check(self._lib.tpl_generate_configs_device(self.L, self.M, seed, first, count, max_iters, _ptr(rows), _ptr(pieces),
-                                                    _ptr(sol), _ptr(sol_len), _ptr(status), _ptr(work), nbytes, self._stream()))
+        check(self._lib.tpl_generate_configs_device_waves(self.L, self.M, seed, first, count, max_iters, int(waves), _ptr(rows),
+                                                          _ptr(pieces), _ptr(sol), _ptr(sol_len), _ptr(status), _ptr(work), nbytes,
+                                                          self._stream()))
         if bool(status.any()):
             raise _lib.TplError(f"{int(status.sum())} configuration(s) hit the iteration cap")
         return (rows, pieces, sol, sol_len) if with_solutions else (rows, pieces)

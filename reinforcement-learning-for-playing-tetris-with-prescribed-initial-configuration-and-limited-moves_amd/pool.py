@@ -9,6 +9,26 @@ from __future__ import annotations
 import numpy as np
 
 
+# CU-masked / low-priority streams made through tpl_stream_create, one per (device, cu_count, low_priority), kept for the
+# life of the process like torch's own stream pool: torch's allocators remember the streams a block was used on and record
+# events on them when the block is freed (a pinned host buffer does, long after a refresher is gone), so a stream that
+# torch has seen must never be destroyed under it.
+_SIDE_STREAMS = {}
+
+
+def side_stream(env, reserved_cus: int = 0, low_priority: bool = False):
+    """A torch stream on `env`'s device whose work runs on `reserved_cus` compute units only (or at the lowest priority)."""
+    import ctypes as C
+    import torch
+    from ._lib import check
+    key = (env._index, int(reserved_cus), bool(low_priority))
+    if key not in _SIDE_STREAMS:
+        raw = C.c_void_p()
+        check(env._lib.tpl_stream_create(env._index, int(reserved_cus), int(bool(low_priority)), C.byref(raw)))
+        _SIDE_STREAMS[key] = torch.cuda.ExternalStream(raw.value, device=env.device)
+    return _SIDE_STREAMS[key]
+
+
 class PoolRefresher:
     """Keeps a running BatchedTetris supplied with FRESH prescribed configurations -- the analogue of the reference's
     two producer processes feeding the reset queue while games are played (game/tetris.py:195-211, 473-488).
@@ -26,10 +46,18 @@ class PoolRefresher:
             feeder.poll()            # cheap: an event query, no wait on any stream; swaps at most once per M + 1 steps
     """
 
-    def __init__(self, env, count: int, seed: int = 0, first: int = 0):
+    def __init__(self, env, count: int, seed: int = 0, first: int = 0, waves: int = 0, reserved_cus: int = 0,
+                 low_priority: bool = False):
+        """waves: how many persistent 64-lane waves share the generator's queue (0 = count / 256): its footprint beside
+        the stepping environment.  Measured at 2^20 boards, L = 10 (profiles/r03_live_supply): 1024 waves supply 1.0 M
+        configurations/s for 6-7 % of the step rate, 256 waves 0.6 M/s for 3-4 %.  (The step kernel raises its waves'
+        issue priority above the generator's; without that any generator wave on a SIMD cost the whole launch 18-29 %.)
+        reserved_cus > 0 runs the generator on a CU-masked stream of that many compute units (`tpl_stream_create`),
+        low_priority on a lowest-priority stream: both measured 3x SLOWER steps than a plain side stream -- kept as
+        options because the review of round 2 asked for the comparison, not because they help."""
         import torch
-        self.env, self.count, self.seed, self.next_first = env, int(count), int(seed), int(first)
-        self.side = torch.cuda.Stream(env.device)
+        self.env, self.count, self.seed, self.next_first, self.waves = env, int(count), int(seed), int(first), int(waves)
+        self.side = side_stream(env, reserved_cus, low_priority) if (reserved_cus or low_priority) else torch.cuda.Stream(env.device)
         self._ready = None            # event recorded behind the batch being generated
         self._bad_host = None         # pinned: the batch's count of configurations that hit the iteration cap
         self._batch = None
@@ -48,9 +76,10 @@ class PoolRefresher:
             status = torch.empty(n, dtype=torch.int32, device=d)
             nbytes = env._lib.tpl_generate_configs_device_work_bytes(env.M, n)
             work = torch.empty(nbytes, dtype=torch.uint8, device=d)
-            check(env._lib.tpl_generate_configs_device(env.L, env.M, self.seed, self.next_first, n, 0, C.c_void_p(rows.data_ptr()),
-                                                       C.c_void_p(pieces.data_ptr()), None, None, C.c_void_p(status.data_ptr()),
-                                                       C.c_void_p(work.data_ptr()), nbytes, self.side.cuda_stream))
+            check(env._lib.tpl_generate_configs_device_waves(env.L, env.M, self.seed, self.next_first, n, 0, self.waves,
+                                                             C.c_void_p(rows.data_ptr()), C.c_void_p(pieces.data_ptr()), None, None,
+                                                             C.c_void_p(status.data_ptr()), C.c_void_p(work.data_ptr()), nbytes,
+                                                             self.side.cuda_stream))
             # how many configurations hit the iteration cap: into pinned host memory, still on the side stream and ahead
             # of the event, so that poll() reads a host value (no .item(), no wait on any stream)
             if self._bad_host is None:
@@ -82,6 +111,12 @@ class PoolRefresher:
         self.swaps += 1
         self.start()
         return True
+
+
+    def close(self) -> None:
+        """Waits for the batch in flight and drops it (the side stream itself lives as long as the process)."""
+        self.side.synchronize()
+        self._ready = self._batch = None
 
 
 def save_pool(path: str, L: int, M: int, rows, pieces, solution=None, solution_len=None) -> None:

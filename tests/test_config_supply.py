@@ -194,6 +194,13 @@ def test_device_generator_equals_the_oracle_and_the_host_generator(oracle, L, M,
     assert np.array_equal(d_rows, rows)
     assert np.array_equal(d_pieces, pieces)
     assert np.array_equal(d_len, sol_len) and np.array_equal(d_sol, sol)
+    # the kernel is persistent, its lanes take configurations from a queue: the output must not depend on how many
+    # waves share the queue (one wave of 64 lanes builds them all; an odd number; more waves than configurations need)
+    for waves in (1, 3, 10 ** 6):
+        m = min(n, 700)
+        w_rows, w_pieces, w_sol, w_len = env.carved_configs(m, seed=12, first=5, with_solutions=True, waves=waves)
+        assert np.array_equal(w_rows.cpu().numpy().view(np.uint16), rows[:m]) and np.array_equal(w_pieces.cpu().numpy(), pieces[:m])
+        assert np.array_equal(w_len.cpu().numpy(), sol_len[:m]) and np.array_equal(w_sol.cpu().numpy(), sol[:m])
     with pytest.raises(T.TplError):
         env.carved_configs(64, seed=12, max_iters=2)       # the cap is reported, not hung on
     env.terminate()
