@@ -377,6 +377,25 @@ def measure_config1(torch, T, dev, seed, chunk):
     if chunk > 0:
         ms_f = measure_fused_rollout(torch, T, env, actions, 0, K // chunk * chunk, chunk)
         out["fused_rollout"] = {"value": float(n) / (ms_f * 1e-3), "ms_per_step": ms_f, "steps_per_launch": chunk}
+    # north_star's step(action) -> (obs, reward, done) for a host-driven loop: the move and the [n,217] float32 observation
+    # as ONE launch (tpl_step_observe) against tpl_step followed by tpl_expand_obs
+    obs = torch.empty((n, 217), dtype=torch.float32, device=dev)
+    step = iter(range(2 * K))
+
+    def two_launches():
+        env.step_into(actions[next(step) % K], reward, done)
+        env.observe(out=obs)
+    for t in range(20):
+        env.step_observe_into(actions[t], reward, done, obs)
+    torch.cuda.synchronize(dev)
+    ms_two = timed(torch, dev, two_launches, K)
+    ms_one = timed(torch, dev, lambda: env.step_observe_into(actions[next(step) % K], reward, done, obs), K)
+    bytes_moved = (32 + 32 + 1 + 4 + 1 + 217 * 4) * n            # state in and out, action, reward, done, observation
+    out["obs_step"] = {"unit": "env-steps/s", "observation": "float32 [n, 217] written every step",
+                       "step_then_observe": {"value": float(n) / (ms_two * 1e-3), "ms_per_step": ms_two, "launches": 2},
+                       "step_observe": {"value": float(n) / (ms_one * 1e-3), "ms_per_step": ms_one, "launches": 1,
+                                        "achieved_GBs": bytes_moved / (ms_one * 1e-3) / 1e9},
+                       "speedup": ms_two / ms_one}
     env.terminate()
     return out
 

@@ -140,6 +140,13 @@ int tpl_move(tpl_env* env, const void* rot, const void* loc, int32_t dtype,
 /* step(action): move(action / 10, action % 10).  The surface BASELINE.json's north_star names. */
 int tpl_step(tpl_env* env, const void* action, int32_t dtype, float* reward, uint8_t* done, void* stream);
 
+/* tpl_step and tpl_expand_obs in ONE launch -- north_star's step(action) -> (obs, reward, done) for a host-driven loop that
+ * needs the observation at every step: the kernel that makes the move writes the [n][217] observation (obs_dtype TPL_F32 /
+ * TPL_BF16; the boards as they stand after the step, a finished board's reset included) from the registers it holds,
+ * instead of a second kernel reading the state back.  Same results as the two calls.  `obs` must be 16-byte aligned. */
+int tpl_step_observe(tpl_env* env, const void* action, int32_t dtype, float* reward, uint8_t* done, void* obs,
+                     int32_t obs_dtype, void* stream);
+
 /* num_steps consecutive steps in one launch, equivalent to num_steps calls of tpl_step with
  * action = actions + k*action_stride (uint8, device).  The loop shape of game/performance_test.py:13-17
  * (move; reset when finished) with the board held in registers between moves.  Outputs, each optional:

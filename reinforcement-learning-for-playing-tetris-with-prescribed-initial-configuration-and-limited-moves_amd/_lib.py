@@ -29,13 +29,13 @@ LIB_PATH = os.path.join(_LIBDIR, "libtetris_piclim_diag.so" if _DIAG else
 _UNITS = [os.path.join(_CSRC, f) for f in ("tetris_piclim.hip", "carve_generator.hip", "carve_device.hip",
                                            "forward_generator.hip", "policy_mlp.hip", "policy_f32.hip", "observe.hip")]
 _SOURCES = _UNITS + [os.path.join(_CSRC, "tpl_device.h"), os.path.join(_CSRC, "tpl_internal.h"),
-                     os.path.join(_CSRC, "tpl_step.h"), os.path.join(_CSRC, "tpl_policy.h"), os.path.join(_CSRC, "py_random.h"),
+                     os.path.join(_CSRC, "tpl_step.h"), os.path.join(_CSRC, "tpl_observe.h"), os.path.join(_CSRC, "tpl_policy.h"), os.path.join(_CSRC, "py_random.h"),
                      os.path.join(_ROOT, "include", "tetris_piclim.h")]
 
 # entry points declared in include/tetris_piclim.h (tests check that the .so exports every one of them)
 SYMBOLS = [
     "tpl_last_error", "tpl_version", "tpl_workspace_bytes", "tpl_pool_bytes", "tpl_create", "tpl_destroy",
-    "tpl_set_options", "tpl_load_configs", "tpl_reset", "tpl_move", "tpl_step", "tpl_get_state",
+    "tpl_set_options", "tpl_load_configs", "tpl_reset", "tpl_move", "tpl_step", "tpl_step_observe", "tpl_get_state",
     "tpl_expand_obs", "tpl_expand_states", "tpl_get_board", "tpl_carve", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
     "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_rollout_random", "tpl_decode_actions", "tpl_generate_configs", "tpl_generate_configs_pyseed", "tpl_forward_generate",
     "tpl_generate_configs_device_work_bytes", "tpl_generate_configs_device", "tpl_generate_configs_device_waves",
@@ -137,6 +137,7 @@ def lib() -> C.CDLL:
     L.tpl_reset.argtypes = [vp, vp, vp]
     L.tpl_move.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
     L.tpl_step.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.tpl_step_observe.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp]
     L.tpl_rollout.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, vp]
     L.tpl_rollout_random.argtypes = [vp, u64, C.c_uint32, i32, vp, vp, vp, vp, vp, vp]
     L.tpl_get_state.argtypes = [vp] * 9

@@ -2,9 +2,12 @@
 // gfx950 only.  The per-lane move lives in tpl_device.h; this file holds the kernels around it, the handle
 // and the extern "C" entry points.  Citations "(:NNN)" are lines of the reference's game/tetris.py.
 #include "tpl_internal.h"
+#include "tpl_observe.h"
 #include "tpl_step.h"
 
 #include <hip/hip_bf16.h>
+
+#include <type_traits>
 
 #include <cstdarg>
 #include <cstdio>
@@ -60,11 +63,23 @@ static inline size_t record_stride(int M) { return (size_t)1 << record_stride_sh
 #define TPL_STAMP(k) do { } while (0)
 #endif
 
-template <bool kActionForm, bool kAutoReset, int kBpl, int kThreads>
+//
+// Obs = float / __hip_bfloat16 makes it step-AND-observe (tpl_step_observe): after the state has been written back the
+// wave expands its 64 boards -- as they stand after the move and the reset -- into their [64][217] span of p.obs, with
+// the two stages of observe.hip (tpl_observe.h), from the registers it already holds.  A host-driven loop that needs the
+// observation every step (north_star's step(action) -> obs, reward, done) then makes ONE launch per iteration and reads
+// the 32-byte state once.  One board per lane in this form (a wave's boards must be 64 neighbours); the column words of
+// the moving board sit at the head of the wave's observation bytes, which are written only after the move is over.
+template <bool kActionForm, bool kAutoReset, int kBpl, int kThreads, typename Obs = void>
 __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
+    constexpr bool kObserve = !std::is_void<Obs>::value;
+    static_assert(!kObserve || kBpl == 1, "step-and-observe: one board per lane");
+    static_assert((int)sizeof(uint32_t) * kLdsCols * kLdsStride <= obs::kWaveLds, "the column words fit the wave's observation bytes");
     __shared__ ShapeWord s_shape[32];
     __shared__ uint32_t s_stat[4];
-    __shared__ uint32_t s_cols[kThreads / 64][kLdsCols][kLdsStride];    // a board's column words while it moves (tpl_device.h)
+    // a board's column words while it moves (tpl_device.h); with kObserve they live inside s_rows
+    __shared__ uint32_t s_cols[kObserve ? 1 : kThreads / 64][kObserve ? 1 : kLdsCols][kObserve ? 1 : kLdsStride];
+    __shared__ __attribute__((aligned(16))) uint8_t s_rows[kObserve ? kThreads / 64 : 1][kObserve ? obs::kWaveLds : 16];
 #ifdef TPL_DIAG_CLOCK
     unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -162,7 +177,8 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
         // the move indexes the board's columns by the piece's position: through LDS, where a lane can (tpl_device.h;
         // 0.1 us on the launch against the all-registers form, profiles/r02_step/ab_lds_move.log)
         unpack_board<true>(A[k], B[k], s);
-        uint32_t* cols = &s_cols[threadIdx.x >> 6][0][threadIdx.x & 63];
+        uint32_t* cols = kObserve ? (uint32_t*)s_rows[threadIdx.x >> 6] + (threadIdx.x & 63)
+                                  : &s_cols[threadIdx.x >> 6][0][threadIdx.x & 63];
         lds_store_cols(cols, s.c);
         if (k == 0) {
 #pragma unroll
@@ -249,6 +265,21 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs p) {
     }
 
     TPL_STAMP(4);
+    // the observation of the boards as they now stand (get_state() :435-436 as a vector; Model(217, 14), model/train.py:26)
+    if constexpr (kObserve) {
+        const int lane = threadIdx.x & 63;
+        const int64_t wave_base = (int64_t)blockIdx.x * kThreads + (threadIdx.x & ~63);
+        const int64_t left = p.n - wave_base;
+        const int count = left >= 64 ? 64 : left > 0 ? (int)left : 0;          // wave-uniform
+        uint8_t* const rows = s_rows[threadIdx.x >> 6];
+        int lines_left = 0;
+        if (lane < count) {
+            Board s;
+            unpack_board(A[0], B[0], s);
+            lines_left = obs::board_to_bytes(s, p.L, p.M, rows, lane);
+        }
+        if (count > 0) obs::store_span<Obs>(rows, lane, count, wave_base, lines_left, (Obs*)p.obs);
+    }
     // per-block statistics of the episodes that finished in this step -> one sharded 64-bit atomic per counter
     if (__syncthreads_or(finished ? 1 : 0)) {
         if (threadIdx.x < 4) {
@@ -595,6 +626,13 @@ __global__ __launch_bounds__(kBlock) void synth_actions_kernel(uint64_t seed, in
 
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
+template <typename Obs>
+static void launch_step_observe(bool auto_reset, const StepArgs& a, hipStream_t stream) {
+    const dim3 grid((unsigned)((a.n + kBlock - 1) / kBlock)), block(kBlock);
+    if (auto_reset) hipLaunchKernelGGL((step_kernel<true, true, 1, kBlock, Obs>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((step_kernel<true, false, 1, kBlock, Obs>), grid, block, 0, stream, a);
+}
+
 template <int kBpl, int kThreads>
 static void launch_step_cfg(bool action_form, bool auto_reset, const StepArgs& a, hipStream_t stream) {
     const int64_t per_block = (int64_t)kThreads * kBpl;
@@ -906,6 +944,26 @@ int tpl_step(tpl_env* e, const void* action, int32_t dtype, float* reward, uint8
     if (!action) return fail_msg(TPL_ERR_ARG, "action is null");
     DeviceGuard guard(e->device);
     return launch_step(e, action, nullptr, dtype, reward, done, nullptr, (hipStream_t)stream);
+}
+
+int tpl_step_observe(tpl_env* e, const void* action, int32_t dtype, float* reward, uint8_t* done, void* obs, int32_t obs_dtype,
+                     void* stream) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!action || !obs) return fail_msg(TPL_ERR_ARG, "action/obs is null");
+    if (dtype != TPL_U8 && dtype != TPL_I32 && dtype != TPL_I64) return fail_msg(TPL_ERR_ARG, "unknown integer dtype %d", dtype);
+    if (obs_dtype != TPL_F32 && obs_dtype != TPL_BF16) return fail_msg(TPL_ERR_ARG, "unknown observation dtype %d", obs_dtype);
+    if (((uintptr_t)obs & 15u) != 0)
+        return fail_msg(TPL_ERR_ARG, "obs must be 16-byte aligned (tpl_step followed by tpl_expand_obs takes any address)");
+    if (int rc = check_can_advance(e)) return rc;
+    DeviceGuard guard(e->device);
+    StepArgs a = make_args(e);
+    a.act0 = action; a.act1 = nullptr; a.int_shift = dtype == TPL_U8 ? 0u : dtype == TPL_I32 ? 2u : 3u;
+    a.reward = reward; a.done = done; a.cleared = nullptr; a.obs = obs;
+    if (obs_dtype == TPL_F32) launch_step_observe<float>(e->auto_reset != 0, a, (hipStream_t)stream);
+    else launch_step_observe<__hip_bfloat16>(e->auto_reset != 0, a, (hipStream_t)stream);
+    TPL_HIP(hipGetLastError());
+    count_steps(e, 1);
+    return TPL_OK;
 }
 
 int tpl_rollout(tpl_env* e, const uint8_t* actions, int64_t action_stride, int32_t num_steps, float* reward_steps,

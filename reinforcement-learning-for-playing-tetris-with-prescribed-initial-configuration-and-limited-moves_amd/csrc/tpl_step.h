@@ -17,6 +17,7 @@ struct StepArgs {
     float* reward;
     uint8_t* done;
     uint8_t* cleared;
+    void* obs;                 // step-and-observe form: the [n][217] observation (float or bf16 by the kernel's type), else null
     float r_line, r_win, r_lose;
     // configuration pools (auto-reset, window refills): new episodes start from pool[cur_slot], a running board
     // refills its window from the slot it carries

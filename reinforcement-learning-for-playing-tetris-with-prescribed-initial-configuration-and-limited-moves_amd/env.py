@@ -326,13 +326,29 @@ class BatchedTetris:
         return replay
 
     def step(self, action, observe: bool = True, obs_dtype=torch.float32):
-        """step(action) with action = rot*10 + loc.  Returns (obs [N,217] or None, reward, done, info)."""
+        """step(action) with action = rot*10 + loc.  Returns (obs [N,217] or None, reward, done, info).  With the
+        observation it is ONE kernel launch (tpl_step_observe): the move and the [N,217] rows of the boards as they stand
+        after it."""
         act, code = self._int_arg(action)
         reward = torch.empty(self.num_envs, dtype=torch.float32, device=self.device)
         done = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
-        check(self._lib.tpl_step(self._h, _ptr(act), code, _ptr(reward), _ptr(done), self._stream()))
-        obs = self.observe(obs_dtype) if observe else None
+        obs = None
+        if observe:
+            obs = torch.empty((self.num_envs, OBS_DIM), dtype=obs_dtype, device=self.device)
+            check(self._lib.tpl_step_observe(self._h, _ptr(act), code, _ptr(reward), _ptr(done), _ptr(obs), _OBS_CODES[obs_dtype],
+                                             self._stream()))
+        else:
+            check(self._lib.tpl_step(self._h, _ptr(act), code, _ptr(reward), _ptr(done), self._stream()))
         return obs, reward, done.view(torch.bool), {}
+
+    def step_observe_into(self, action: torch.Tensor, reward: torch.Tensor, done: torch.Tensor, obs: torch.Tensor) -> None:
+        """step() with the observation, writing into caller-owned buffers (as step_into; obs f32 / bf16 [N, 217])."""
+        self._own(action, _INT_CODES, "action")
+        self._own(reward, torch.float32, "reward")
+        self._own(done, torch.uint8, "done")
+        self._own(obs, _OBS_CODES, "obs", (self.num_envs, OBS_DIM))
+        check(self._lib.tpl_step_observe(self._h, action.data_ptr(), _INT_CODES[action.dtype], reward.data_ptr(), done.data_ptr(),
+                                         obs.data_ptr(), _OBS_CODES[obs.dtype], self._stream()))
 
     def rollout(self, actions: torch.Tensor, per_step: bool = False):
         """K consecutive steps in one kernel launch: actions uint8 [K, N] on the device.  Equivalent to K calls

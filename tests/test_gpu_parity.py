@@ -659,6 +659,60 @@ def test_observation_on_dense_boards_frozen_wins_and_odd_sizes(T, oracle, n):
     gpu.terminate()
 
 
+@pytest.mark.parametrize("L,M,n,bf16,auto,steps", [(5, 20, 65536, False, True, 45), (10, 40, 1 << 20, True, True, 14),
+                                                  (4, 12, 1000, False, True, 40), (4, 12, 63, True, True, 40),
+                                                  (3, 9, 2049, True, False, 12), (2, 30, 129, False, False, 12)])
+def test_step_observe_is_step_then_observe_and_the_oracle(T, oracle, L, M, n, bf16, auto, steps):
+    """tpl_step_observe -- the move and the [N,217] observation in one launch -- against the oracle's step followed by
+    its expand_obs (rewards and dones at every step, the observation at every step of the small cases and at a few steps
+    of the large ones), and against tpl_step + tpl_expand_obs on a twin handle.  BASELINE's configs[1] and configs[2]
+    sizes, ragged sizes around a wave's and a block's span, with and without auto-reset (without it: frozen boards,
+    among them a win whose last clear overshot L -- lines left below zero)."""
+    import torch
+    dtype = torch.bfloat16 if bf16 else torch.float32
+    seed = 31 + n % 97
+    pool_n = min(n, 4096)
+    rows, pieces = oracle.synth_boards(seed, 0, pool_n, L), oracle.synth_pieces(seed, 0, pool_n, M)
+    if not auto and pool_n >= 7:                       # the overshoot of test_observation_on_dense_boards...: I upright at x = 0
+        rows[3] = 0
+        rows[3, 17:20] = 0x3FE
+        pieces[3, 0] = 0
+    make = lambda: T.BatchedTetris(L, M, n, seed=seed, auto_reset=auto, assign="sequential", config_pool=(rows, pieces))
+    gpu, twin = make(), make()
+    cpu = oracle.Env(n, L, M, 0, seed)
+    cpu.set_pool(rows, pieces)
+    cpu.set_options(auto_reset=auto, assign_mode=1)
+    gpu.reset(); twin.reset(); cpu.reset()
+    obs = torch.empty((n, 217), dtype=dtype, device=gpu.device)
+    reward = torch.empty(n, dtype=torch.float32, device=gpu.device)
+    done = torch.empty(n, dtype=torch.uint8, device=gpu.device)
+    r2, d2 = torch.empty_like(reward), torch.empty_like(done)
+    look = set(range(steps)) if n <= 4096 else {0, 1, steps // 2, steps - 1}
+    for t in range(steps):
+        a = gpu.synthetic_actions(t)
+        if t == 0 and not auto:
+            a[:] = 10                                  # rot 1, loc 0: the upright I into the three-row well of board 3
+        gpu.step_observe_into(a, reward, done, obs)
+        r_c, d_c = cpu.step(_np(a))
+        assert np.array_equal(_np(reward), r_c) and np.array_equal(_np(done), d_c), t
+        twin.step_into(a, r2, d2)
+        if t in look:
+            want = cpu.expand_obs()
+            got = _np(obs.float())
+            assert np.array_equal(got, want), (t, np.argwhere(got != want)[:5].tolist())
+            assert torch.equal(twin.observe(dtype), obs), t
+    _assert_state_equal(_state(gpu), cpu.get_state(), "step_observe")
+    assert gpu.stats() == cpu.stats() and gpu.stats() == twin.stats()
+    if not auto and pool_n >= 7 and L < 3:
+        final = _np(obs.float())
+        assert final[3, 214] < 0 and final[3, 216] == 1               # three rows cleared where two were asked for; frozen
+    # an observation buffer that is not 16-byte aligned is refused (tpl_step + tpl_expand_obs serve it)
+    spare = torch.empty(n * 217 + 8, dtype=dtype, device=gpu.device)
+    with pytest.raises(T.TplError, match="16-byte aligned"):
+        gpu.step_observe_into(a, reward, done, spare[1: 1 + n * 217].view(n, 217))
+    gpu.terminate(); twin.terminate()
+
+
 def test_sharding_is_independent_of_the_number_of_gpus(T):
     """Two handles with global offsets reproduce one handle over the whole batch (the multi-GPU partition)."""
     import torch
