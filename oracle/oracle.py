@@ -63,6 +63,8 @@ def lib():
         L.to_env_get_state.argtypes = [vp] * 8
         L.to_env_expand_obs.argtypes = [vp, vp]
         L.to_env_get_stats.argtypes = [vp, vp]
+        L.to_explore_actions.argtypes = [vp, i64, i64, u64, C.c_uint32, C.c_uint32]
+        L.to_explore_actions.restype = None
         L.to_rng.restype = u64
         L.to_rng.argtypes = [u64, u64, u64, u64]
         L.to_synth_boards.argtypes = [u64, i64, i64, i32, vp]
@@ -213,6 +215,14 @@ def synth_pieces(seed, first, count, M):
 def synth_actions(seed, first, count, step):
     a = np.empty(count, np.uint8)
     lib().to_synth_actions(seed, first, count, step, _p(a))
+    return a
+
+
+def explore_actions(action, epsilon, seed, step, global_offset=0):
+    """tpl_explore_actions on a copy of `action` (uint8): replaced by the exploration draw with probability epsilon."""
+    a = np.ascontiguousarray(action, dtype=np.uint8).copy()
+    eps_q24 = int(np.float32(epsilon) * np.float32(16777216.0))
+    lib().to_explore_actions(_p(a), len(a), global_offset, seed, step, eps_q24)
     return a
 
 

@@ -241,6 +241,27 @@ int64_t to_env_assign(const to_env* e, int64_t board, uint64_t birth) {
     return (int64_t)(((uint64_t)h * (uint64_t)(uint32_t)n_cfg) >> 32);
 }
 
+/* Epsilon-greedy exploration -- the build's own definition, restated here so that the device's
+ * draws can be checked against something that does not share its code.  Steps 2j and 2j + 1 of a board share one
+ * 32-bit word w = fmix32(base + j * 0x9E3779B1 + (seed >> 32)), base = fmix32(low(g) ^ high(g) * 0x9E3779B9 ^ low(seed)
+ * ^ 0x51ED270B); the even step takes its low sixteen bits, the odd step its high sixteen, and the replacement action is
+ * (those sixteen bits * 40) >> 16.  With epsilon = eps_q24 / 2^24 < 1 the action is replaced iff the top 24 bits of
+ * fmix32(w ^ (0x2545F491 + step parity)) are below eps_q24. */
+void to_explore_actions(uint8_t* action, int64_t n, int64_t global_offset, uint64_t seed, uint32_t step, uint32_t eps_q24) {
+    for (int64_t b = 0; b < n; ++b) {
+        const uint64_t g = (uint64_t)(global_offset + b);
+        const uint32_t base = fmix32((uint32_t)g ^ ((uint32_t)(g >> 32) * 0x9E3779B9u) ^ (uint32_t)seed ^ 0x51ED270Bu);
+        const uint32_t w = fmix32(base + (step / 2u) * 0x9E3779B1u + (uint32_t)(seed >> 32));
+        const uint32_t sixteen = (step % 2u) ? (w >> 16) : (w & 0xFFFFu);
+        const uint32_t replacement = (sixteen * 40u) >> 16;
+        if (eps_q24 < (1u << 24)) {
+            const uint32_t decision = fmix32(w ^ (0x2545F491u + (step % 2u))) >> 8;
+            if (decision >= eps_q24) continue;
+        }
+        action[b] = (uint8_t)replacement;
+    }
+}
+
 uint64_t to_env_clock(const to_env* e) { return e->clock; }
 uint64_t to_env_birth(const to_env* e, int64_t board) { return e->birth[board]; }
 

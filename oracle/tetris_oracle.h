@@ -101,6 +101,10 @@ void    to_env_expand_obs(const to_env* e, float* out);
 /* out = {episodes finished, sum of lines_cleared at finish, wins, top-outs} */
 void    to_env_get_stats(const to_env* e, uint64_t out[4]);
 
+/* Epsilon-greedy exploration (tpl_explore_actions; the uniform random policy of tpl_rollout_random at eps_q24 = 2^24):
+ * action[b] is replaced by the draw of (seed, global_offset + b, step) with probability eps_q24 / 2^24. */
+void to_explore_actions(uint8_t* action, int64_t n, int64_t global_offset, uint64_t seed, uint32_t step, uint32_t eps_q24);
+
 /* ---- synthetic inputs: counter-based, identical on CPU and GPU ------------------------- */
 uint64_t to_rng(uint64_t seed, uint64_t stream, uint64_t index, uint64_t counter);
 void to_synth_boards(uint64_t seed, int64_t first, int64_t count, int L, uint16_t* rows /*[count][20]*/);

@@ -316,7 +316,7 @@ struct RolloutArgs {
     uint32_t* finished;         // [n] or null: episodes this board finished during the K steps
 };
 
-template <bool kAutoReset, bool kRandom = false>
+template <bool kAutoReset, bool kRandom>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
     const StepArgs& p = q.s;
     __shared__ ShapeWord s_shape[32];
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
     if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
     __syncthreads();
 
-    Tally tally;
+    RareTally tally;
     if (valid) {
         Board s;
         unpack_board<true>(A, B, s);
@@ -347,13 +347,21 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
         lds_store_cols(cols, s.c);
 #pragma unroll
         for (int k = kCols; k < kLdsCols; ++k) cols[k * kLdsStride] = kSentinelBit;
-        const uint8_t* rec = current_record(s, p, (uint32_t)i, clock);
+        const uint8_t* next_word = next_piece_word(current_record(s, p, (uint32_t)i, clock), s.moves);
+        uint32_t until_refill = moves_until_refill(s.moves);
+        // random form: the part of the exploration draw that does not depend on the step, and the pair word in use
+        const uint32_t draw_base = kRandom ? explore_base(q.random_seed, (uint64_t)(p.global_offset + i)) : 0u;
+        uint32_t draw_pair = 0;
         float rsum = 0.0f;
-        // per-step streams are walked with running pointers (a 64-bit multiply-add per step and stream otherwise)
-        const uint8_t* act_next_ptr = q.actions + i;
-        uint8_t* act_out_ptr = q.actions_out + i;
-        float* reward_ptr = q.reward_steps + i;
-        uint8_t* done_ptr = q.done_steps + i;
+        // The per-step streams are addressed as a wave-uniform row pointer (the block's first board in step k's row,
+        // moved on by the scalar unit) plus the lane's constant offset in the block: no vector instruction per step
+        // and stream (a running per-lane pointer costs a 64-bit add each).
+        const int64_t block_first = (int64_t)blockIdx.x * kBlock;
+        const uint32_t in_block = threadIdx.x;
+        const uint8_t* act_row = q.actions + block_first;
+        uint8_t* act_out_row = q.actions_out + block_first;
+        float* reward_row = q.reward_steps + block_first;
+        uint8_t* done_row = q.done_steps + block_first;
         const bool want_reward = q.reward_steps != nullptr, want_done = q.done_steps != nullptr;   // wave-uniform
         // The first action must have ARRIVED before the loop is entered.  Otherwise its register is "possibly still
         // being loaded" at the loop header on one of the two ways in, and the compiler puts a full memory wait at
@@ -369,30 +377,34 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
         for (uint32_t k = 0; k < q.K; ++k) {
             if (k > 0) {
                 // (non-temporal: a trajectory is written once and consumed later, by someone else)
-                if (want_reward) { __builtin_nontemporal_store(reward_prev, reward_ptr); reward_ptr += p.n; }
-                if (want_done) { __builtin_nontemporal_store((uint8_t)(done_prev ? 1 : 0), done_ptr); done_ptr += p.n; }
+                if (want_reward) { __builtin_nontemporal_store(reward_prev, reward_row + in_block); reward_row += p.n; }
+                if (want_done) { __builtin_nontemporal_store((uint8_t)(done_prev ? 1 : 0), done_row + in_block); done_row += p.n; }
             }
             // next step's action is independent of the board: fetch it under this step's move
             uint32_t act_next = 0;
             if (kRandom) {
-                // the uniform random policy, drawn on the device (what tpl_explore_actions gives at epsilon = 1)
-                act = explore(0u, q.random_seed, (uint64_t)(p.global_offset + i), q.step0 + k, 1u << 24);
-                if (q.actions_out) { *act_out_ptr = (uint8_t)act; act_out_ptr += p.n; }
+                // the uniform random policy, drawn on the device (what tpl_explore_actions gives at epsilon = 1): one hash
+                // serves two steps, so it is taken at even steps and at the first step of the launch (a wave-uniform test)
+                const uint32_t step = q.step0 + k;
+                if (k == 0 || (step & 1u) == 0u) draw_pair = explore_pair(draw_base, q.random_seed, step);
+                act = explore_pick(draw_pair, step);
+                if (q.actions_out) { act_out_row[in_block] = (uint8_t)act; act_out_row += p.n; }
             } else {
-                act_next_ptr += q.action_stride;
-                if (k + 1 < q.K) act_next = *act_next_ptr;
+                act_row += q.action_stride;
+                if (k + 1 < q.K) act_next = act_row[in_block];
             }
             uint32_t rot, loc;
             split_small_action(act, rot, loc);
             float reward;
-            const bool done = advance_board_lds<kAutoReset>(s, cols, rec, rot, loc, p, (uint32_t)i, clock + k, s_shape, reward, tally);
+            const bool done = advance_board_lds<kAutoReset>(s, cols, next_word, until_refill, rot, loc, p, (uint32_t)i, clock + k,
+                                                            s_shape, reward, tally);
             rsum = rsum + reward;
             reward_prev = reward;
             done_prev = done;
             act = act_next;
         }
-        if (want_reward) __builtin_nontemporal_store(reward_prev, reward_ptr);
-        if (want_done) __builtin_nontemporal_store((uint8_t)(done_prev ? 1 : 0), done_ptr);
+        if (want_reward) __builtin_nontemporal_store(reward_prev, reward_row + in_block);
+        if (want_done) __builtin_nontemporal_store((uint8_t)(done_prev ? 1 : 0), done_row + in_block);
         lds_load_cols(cols, s.c);
         pack_board<true>(s, A, B);
         p.plane_a[i] = A;
@@ -687,6 +699,13 @@ static int launch_step(tpl_env* e, const void* act0, const void* act1, int32_t d
     return TPL_OK;
 }
 
+template <bool kRandom>
+static void launch_rollout(const tpl_env* e, const RolloutArgs& q, hipStream_t stream) {
+    const dim3 grid(blocks_for(e->n)), block(kBlock);
+    if (e->auto_reset) hipLaunchKernelGGL((rollout_kernel<true, kRandom>), grid, block, 0, stream, q);
+    else hipLaunchKernelGGL((rollout_kernel<false, kRandom>), grid, block, 0, stream, q);
+}
+
 // The resets of the multi-step kernel read the current pool's side records: written once per pool, on first use (a
 // caller that only steps never pays for them).  Under stream capture the build is only RECORDED into the graph -- it
 // has not run when the call returns and runs again with every replay -- so the pool is not marked: the next eager
@@ -979,9 +998,7 @@ int tpl_rollout(tpl_env* e, const uint8_t* actions, int64_t action_stride, int32
     q.s = make_args(e);
     q.actions = actions; q.action_stride = action_stride; q.K = (uint32_t)num_steps;
     q.reward_steps = reward_steps; q.done_steps = done_steps; q.reward_sum = reward_sum; q.finished = finished;
-    const dim3 grid(blocks_for(e->n)), block(kBlock);
-    if (e->auto_reset) hipLaunchKernelGGL((rollout_kernel<true, false>), grid, block, 0, (hipStream_t)stream, q);
-    else hipLaunchKernelGGL((rollout_kernel<false, false>), grid, block, 0, (hipStream_t)stream, q);
+    launch_rollout<false>(e, q, (hipStream_t)stream);
     TPL_HIP(hipGetLastError());
     count_steps(e, num_steps);
     return TPL_OK;
@@ -999,9 +1016,7 @@ int tpl_rollout_random(tpl_env* e, uint64_t seed, uint32_t step0, int32_t num_st
     q.actions = nullptr; q.action_stride = 0; q.K = (uint32_t)num_steps;
     q.random_seed = seed; q.step0 = step0; q.actions_out = actions_out;
     q.reward_steps = reward_steps; q.done_steps = done_steps; q.reward_sum = reward_sum; q.finished = finished;
-    const dim3 grid(blocks_for(e->n)), block(kBlock);
-    if (e->auto_reset) hipLaunchKernelGGL((rollout_kernel<true, true>), grid, block, 0, (hipStream_t)stream, q);
-    else hipLaunchKernelGGL((rollout_kernel<false, true>), grid, block, 0, (hipStream_t)stream, q);
+    launch_rollout<true>(e, q, (hipStream_t)stream);
     TPL_HIP(hipGetLastError());
     count_steps(e, num_steps);
     return TPL_OK;

@@ -78,7 +78,8 @@ __device__ __forceinline__ uint32_t window_word(uint32_t t) { return t >> 11; }
 // ---- shape table --------------------------------------------------------------------------------------
 // `tetrominos` (:23-57) re-encoded per (piece, rotations & 3) for the column layout.  Two words per entry:
 //   .x  bits 0-15: four nibbles, nibble c = the piece's column c as a bit-per-row pattern (bit i = mask row i)
-//       bits 16-18: width, bits 19-21: height
+//       bits 16-18: width, bits 19-21: height, bits 22-25: 10 - width (the right clamp of :364 as one v_min),
+//       bits 26-29: (1 << height) - 1 (the piece's rows as a mask, for the full-row test of :382-386)
 //   .y  byte c = 3 - reverse_topography[c] for a covered column, 64 for columns past the piece's width
 // so that  drop = min_c(top[c] + byte_c) - 4  ==  min_c(top[c] - revtopo[c]) - 1   (:424-425, :433).
 // get_tetromino's `rotations % len` (:60-61) is folded in: len is 1, 2 or 4, so (rotations & 3) % len
@@ -96,7 +97,7 @@ __host__ __device__ constexpr ShapeWord make_shape(int h, int w, int m0, int m1,
         x |= colbits << (4 * c);
         y |= (uint32_t)(c < w ? 3 - t[c] : 64) << (8 * c);
     }
-    x |= (uint32_t)w << 16 | (uint32_t)h << 19;
+    x |= (uint32_t)w << 16 | (uint32_t)h << 19 | (uint32_t)(kCols - w) << 22 | ((1u << h) - 1u) << 26;
     return ShapeWord{x, y};
 }
 
@@ -324,13 +325,15 @@ __device__ __forceinline__ void lds_load_cols(const uint32_t* cols, uint32_t (&c
     for (int k = 0; k < kCols; ++k) c[k] = cols[k * kLdsStride];
 }
 
-// Tetris.move (:354-422) as move_board, on the column words at `cols` (this lane's column 0).  `s.c` is not used.
+// Tetris.move (:354-422) as move_board, on the column words at `cols` (this lane's column 0).  `s.c` is not used, and
+// `s.state` is not written: how the move ended comes back as three flags (at most one set), which the multi-step
+// kernel keeps as lane masks -- its tallies, its reward and its reset test are then scalar-unit work.
+struct MoveEnd { bool topout, won, limit; };
+
 __device__ __forceinline__ uint32_t move_board_lds(Board& s, uint32_t* cols, const ShapeWord* shape, uint32_t rot, uint32_t loc,
-                                                   uint32_t L, uint32_t M, bool& topout) {
+                                                   uint32_t L, uint32_t M, MoveEnd& end) {
     const ShapeWord sh = shape[(s.window & 7u) * 4u + (rot & 3u)];                 // get_tetromino (:60-61, :359-360)
-    const uint32_t w = (sh.x >> 16) & 7u;
-    const uint32_t h = (sh.x >> 19) & 7u;
-    loc = min(loc, (uint32_t)kCols - w);                                           // right clamp only (:363-364)
+    loc = min(loc, (sh.x >> 22) & 15u);                                            // right clamp only (:363-364)
 
     // calculate_drop_deltas (:427-433) on the piece's own columns
     uint32_t* under = cols + loc * kLdsStride;
@@ -341,7 +344,7 @@ __device__ __forceinline__ uint32_t move_board_lds(Board& s, uint32_t* cols, con
 #pragma unroll
     for (int j = 0; j < 4; ++j) best = min(best, (uint32_t)__builtin_ctz(c[j]) + ((sh.y >> (8 * j)) & 0xFFu));
     const int drop = (int)best - 4;                                                // calculate_drop (:424-425)
-    topout = drop < 0;                                                             // (:372-374)
+    const bool topout = drop < 0;                                                  // (:372-374)
     const uint32_t dshift = topout ? 0u : (uint32_t)drop;
 
     // lock (:377-378): the four columns go back with the piece's column patterns ORed in (nothing on a top-out)
@@ -356,7 +359,7 @@ __device__ __forceinline__ uint32_t move_board_lds(Board& s, uint32_t* cols, con
     uint32_t full = b[0];
 #pragma unroll
     for (int k = 1; k < kCols; ++k) full &= b[k];
-    uint32_t clear = topout ? 0u : (full & (((1u << h) - 1u) << dshift));
+    uint32_t clear = topout ? 0u : (full & (((sh.x >> 26) & 15u) << dshift));
     const uint32_t n = (uint32_t)__builtin_popcount(clear);
 
     // compaction (:397-407), on the registers, written back when it ran
@@ -374,9 +377,19 @@ __device__ __forceinline__ uint32_t move_board_lds(Board& s, uint32_t* cols, con
     s.lines += n;                                                                  // (:409)
 
     // terminal tests: no-clear exit (:389-394), win before move limit (:415-422)
-    const bool won = !topout && n != 0u && s.lines >= L;
-    const bool limit = !topout && !won && s.moves >= M;
-    s.state = topout ? ST_LOST_TOPOUT : won ? ST_WON : limit ? ST_LOST_LIMIT : ST_RUNNING;
+    end.topout = topout;
+    end.won = !topout && n != 0u && s.lines >= L;
+    end.limit = !topout && !end.won && s.moves >= M;
+    return n;
+}
+
+// the same with the state written, for the kernels that make one move per launch
+__device__ __forceinline__ uint32_t move_board_lds(Board& s, uint32_t* cols, const ShapeWord* shape, uint32_t rot, uint32_t loc,
+                                                   uint32_t L, uint32_t M, bool& topout) {
+    MoveEnd end;
+    const uint32_t n = move_board_lds(s, cols, shape, rot, loc, L, M, end);
+    topout = end.topout;
+    s.state = end.topout ? ST_LOST_TOPOUT : end.won ? ST_WON : end.limit ? ST_LOST_LIMIT : ST_RUNNING;
     return n;
 }
 

@@ -101,14 +101,29 @@ __device__ __forceinline__ void split_small_action(uint32_t action, uint32_t& ro
 }
 
 // Epsilon-greedy exploration (tpl_explore_actions): with probability eps_q24 / 2^24 the action is replaced by a uniform
-// draw from [0, 40), decided by a hash of (seed, global board index, step).  With eps_q24 = 2^24 it is the uniform random
-// policy on the device (tpl_rollout_random).
+// draw from [0, 40).  With eps_q24 = 2^24 it is the uniform random policy on the device (tpl_rollout_random).
+//
+// The draws come in PAIRS: steps 2j and 2j + 1 of a board share ONE 32-bit hash of (seed, global board index, j) and take
+// sixteen bits of it each, reduced to [0, 40) by a 24-bit multiply: (half * 40) >> 16, every action within 40 / 65536 of
+// 1/40.  (Round 2 spent a hash and a multiply-high on every step: five quarter-rate multiplies, 120 of the 550 cycles a
+// wave-step of the multi-step kernel took; this is one hash every other step -- and still a function of the step index
+// alone, so any step can be drawn without the ones before it.)  The decision at epsilon < 1 is a hash of its own, of
+// the pair word and the step's parity: it costs nothing when every action is replaced.
+__device__ __forceinline__ uint32_t explore_base(uint64_t seed, uint64_t gidx) {
+    return fmix32((uint32_t)gidx ^ ((uint32_t)(gidx >> 32) * 0x9E3779B9u) ^ (uint32_t)seed ^ 0x51ED270Bu);
+}
+__device__ __forceinline__ uint32_t explore_pair(uint32_t base, uint64_t seed, uint32_t step) {
+    return fmix32(base + (step >> 1) * 0x9E3779B1u + (uint32_t)(seed >> 32));
+}
+__device__ __forceinline__ uint32_t explore_pick(uint32_t pair, uint32_t step) {
+    return __umul24((pair >> (16u * (step & 1u))) & 0xFFFFu, 40u) >> 16;
+}
 __device__ __forceinline__ uint32_t explore(uint32_t action, uint64_t seed, uint64_t gidx, uint32_t step, uint32_t eps_q24) {
-    uint32_t u = fmix32((uint32_t)gidx ^ ((uint32_t)(gidx >> 32) * 0x9E3779B9u) ^ (uint32_t)seed ^ 0x51ED270Bu);
-    u = fmix32(u + step * 0x9E3779B1u + (uint32_t)(seed >> 32));
-    // the decision uses the upper 24 bits; the replacement is a second 32-bit draw reduced to [0, 40) by multiply-high
-    // (40 / 2^32 of bias, where eight bits times 40 gave sixteen of the actions 7/256 and the others 6/256)
-    return (u >> 8) < eps_q24 ? __umulhi(fmix32(u ^ 0x2545F491u), 40u) : action;
+    const uint32_t pair = explore_pair(explore_base(seed, gidx), seed, step);
+    const uint32_t replacement = explore_pick(pair, step);
+    if (eps_q24 >= (1u << 24)) return replacement;
+    const uint32_t decision = fmix32(pair ^ (0x2545F491u + (step & 1u))) >> 8;
+    return decision < eps_q24 ? replacement : action;
 }
 
 // (re)initialise a board from pool entry `cfg` of the current slot.  reset()/load_warm_reset() (:438-449), with the
@@ -121,17 +136,24 @@ __device__ __forceinline__ void load_config(const StepArgs& p, uint32_t cfg, uin
 }
 
 // reward = per_line * rows_cleared (+ win when the move wins) (+ lose when the move loses): one rounded multiply,
-// then at most one rounded add.  The round-to-nearest intrinsics keep the compiler from contracting the pair into an
-// FMA, whose single rounding differs from the CPU's two when per_line * 3 is not exact.
+// then at most one rounded add.  Contraction is switched off for this function: left alone the compiler fuses the
+// pair into an FMA, whose single rounding differs from the CPU's two when per_line * 3 is not exact (0.1f * 3 - 0.3f
+// is 0 in two roundings and -7.45e-9 fused).  (`__fmul_rn` / `__fadd_rn` do NOT prevent it: in this ROCm's headers they
+// are a plain `*` and `+`; round 2 relied on them and shipped the FMA -- tests/test_gpu_parity.py now has the case.)
 __device__ __forceinline__ float step_reward(const StepArgs& p, uint32_t n_clear, uint32_t state) {
-    float reward = __fmul_rn(p.r_line, (float)n_clear);
-    if (state == ST_WON) reward = __fadd_rn(reward, p.r_win);
-    if (state >= ST_LOST_LIMIT) reward = __fadd_rn(reward, p.r_lose);
+#pragma clang fp contract(off)
+    float reward = p.r_line * (float)n_clear;
+    if (state == ST_WON) reward = reward + p.r_win;
+    if (state >= ST_LOST_LIMIT) reward = reward + p.r_lose;
     return reward;
 }
 
 // episodes a lane finished, accumulated in registers across the steps of one launch
 struct Tally { uint32_t episodes = 0, lines = 0, wins = 0, topouts = 0; };
+// The multi-step kernel's form: top-outs are what is left of the episodes once the wins and the losses at the move limit
+// are taken off -- those two are the rare ways to finish, and each is counted under a branch that the whole wave skips
+// when no lane of it finished that way.
+struct RareTally { uint32_t episodes = 0, lines = 0, wins = 0, limits = 0; };
 
 // The pool record of the board's current episode at step `clock` (kept in registers by the multi-step kernels: the
 // window refill needs it every tenth move, and hashing the entry again each time costs more than the refill itself).
@@ -181,40 +203,76 @@ __device__ __forceinline__ bool advance_board(Board& s, uint32_t& cfg, uint32_t 
     return done;
 }
 
-// advance_board with the board's column words in LDS (move_board_lds); everything else as above.
+// advance_board with the board's column words in LDS (move_board_lds), written for the multi-step kernel's loop:
+//   * how the move ended stays in flags (lane masks), not in a state word;
+//   * `until_refill` counts the moves left before the piece window runs out and `next_word` points at the piece word
+//     that will replace it: the test on the way in is one compare, the refill one load and one add;
+//   * the reward's conditional add happens where only the finished boards are active: one select between the two
+//     constants and one add (a finished board has won or lost, never both: the same single rounded add as step_reward).
 template <bool kAutoReset>
-__device__ __forceinline__ bool advance_board_lds(Board& s, uint32_t* cols, const uint8_t*& rec, uint32_t rot, uint32_t loc,
-                                                  const StepArgs& p, uint32_t i, uint64_t clock, const ShapeWord* shape,
-                                                  float& reward, Tally& tally) {
+__device__ __forceinline__ bool advance_board_lds(Board& s, uint32_t* cols, const uint8_t*& next_word, uint32_t& until_refill,
+                                                  uint32_t rot, uint32_t loc, const StepArgs& p, uint32_t i, uint64_t clock,
+                                                  const ShapeWord* shape, float& reward, RareTally& tally) {
     reward = 0.0f;
     if (s.state != ST_RUNNING) return true;      // frozen
-    const uint32_t tenth = tenths(s.moves + 1u);
-    const bool refill = window_runs_out(tenth) && (p.n_cfg[0] | p.n_cfg[1]) != 0u;
+    // pieces.pop(0) (:356) moves the cursor on by one whatever the move does; when it reaches a multiple of ten the
+    // window is down to its last two entries and the next piece word replaces it
+    until_refill -= 1u;
+    const bool refill = until_refill == 0u && (p.n_cfg[0] | p.n_cfg[1]) != 0u;
     uint64_t word = 0;
-    if (refill) word = piece_word_at(rec, window_word(tenth));
-    bool topout;
-    const uint32_t n_clear = move_board_lds(s, cols, shape, rot, loc, p.L, p.M, topout);
+    if (refill) {
+        word = *(const uint64_t*)next_word;
+        next_word += 8;
+        until_refill = (uint32_t)kWindowStride;
+    }
+    MoveEnd end;
+    const uint32_t n_clear = move_board_lds(s, cols, shape, rot, loc, p.L, p.M, end);
     next_window(s, refill, word);
-    reward = step_reward(p, n_clear, s.state);
-    const bool done = s.state != ST_RUNNING;
+    const bool done = end.topout || end.won || end.limit;
+    if (!kAutoReset) s.state = end.topout ? ST_LOST_TOPOUT : end.won ? ST_WON : end.limit ? ST_LOST_LIMIT : ST_RUNNING;
+    const float base_reward = p.r_line * (float)n_clear;
+    reward = base_reward;
     if (done) {
+#pragma clang fp contract(off)
         tally.episodes += 1u;
         tally.lines += s.lines;
-        tally.wins += s.state == ST_WON ? 1u : 0u;
-        tally.topouts += s.state == ST_LOST_TOPOUT ? 1u : 0u;
+        // A finished board has lost unless it has won: the common add is the loss's, and the two rare ways to finish sit
+        // under branches that a wave skips (on its lane mask) when none of its boards finished that way.  The empty asm
+        // statements keep them branches: turned into selects they would cost every wave-step two instructions each.
+        reward = base_reward + p.r_lose;
+        if (end.won) {
+            asm volatile("");
+            reward = base_reward + p.r_win;
+            tally.wins += 1u;
+        }
+        if (end.limit) {
+            asm volatile("");
+            tally.limits += 1u;
+        }
         if (kAutoReset) {
             // the new episode's first move is the next step; the board comes from the side record, already unpacked
             const uint32_t cfg = config_of(p, i, clock + 1u, p.cur_slot);
-            rec = pool_record(p, p.cur_slot, cfg);
+            next_word = ((p.cur_slot ? p.pool[1] : p.pool[0]) + 32) + ((size_t)cfg << p.stride_shift);   // piece word 1 of the record
             const uint4* side = (const uint4*)((p.cur_slot ? p.side[1] : p.side[0]) + ((size_t)cfg << kSideShift));
             const uint4 s0 = side[0], s1 = side[1], s2 = side[2];
             const uint32_t c[kCols] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y};
             lds_store_cols(cols, c);
             s.window = s2.z; s.window_hi = s2.w;
-            s.moves = 0; s.lines = 0; s.state = ST_RUNNING; s.slot = p.cur_slot;
+            s.moves = 0; s.lines = 0; s.slot = p.cur_slot;
+            until_refill = (uint32_t)kWindowStride;
         }
     }
     return done;
+}
+
+// For a board at `moves` moves (cursor = moves; a board that topped out is finished and never asks): the moves left before
+// its window runs out, 10 - cursor % 10, and the piece word that will then replace it, word cursor / 10 + 1 of its record
+// (words 1.. sit behind the record's 32 state bytes).
+__device__ __forceinline__ uint32_t moves_until_refill(uint32_t moves) {
+    return (uint32_t)kWindowStride - (moves - window_word(tenths(moves)) * (uint32_t)kWindowStride);
+}
+__device__ __forceinline__ const uint8_t* next_piece_word(const uint8_t* rec, uint32_t moves) {
+    return rec + 32u + 8u * window_word(tenths(moves));
 }
 
 // block-level flush of the lanes' tallies: LDS atomics, then one sharded 64-bit global atomic per counter.
@@ -232,6 +290,13 @@ __device__ __forceinline__ void flush_tally(const Tally& t, uint32_t* s_stat, un
             if (v) atomicAdd(&stats[(size_t)(blockIdx.x % kStatShards) * kStatStride + threadIdx.x], (unsigned long long)v);
         }
     }
+}
+
+// the multi-step kernel's tally: top-outs = episodes - wins - losses at the move limit
+__device__ __forceinline__ void flush_tally(const RareTally& r, uint32_t* s_stat, unsigned long long* stats) {
+    Tally t;
+    t.episodes = r.episodes; t.lines = r.lines; t.wins = r.wins; t.topouts = r.episodes - r.wins - r.limits;
+    flush_tally(t, s_stat, stats);
 }
 
 }  // namespace tpl

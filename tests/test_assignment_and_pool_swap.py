@@ -358,6 +358,58 @@ def test_side_records_first_needed_under_graph_capture(T, oracle):
     gpu.terminate()
 
 
+def test_exploration_draw_statistics_on_the_oracle(oracle):
+    """The exploration draw (the build's own function; two steps share one 32-bit hash word and take sixteen bits each):
+    uniform over [0, 40) on even and on odd steps, the two draws of a pair independent of each other, consecutive
+    draws across a pair boundary independent, a board's draws independent of its neighbour's, and at epsilon < 1 the
+    replacement rate is epsilon with the replacements still uniform."""
+    n = 1 << 18
+
+    def chi2(counts):
+        counts = counts.astype(np.float64).ravel()
+        e = counts.sum() / counts.size
+        return float(((counts - e) ** 2 / e).sum()), counts.size - 1
+
+    def ok(counts):
+        c, dof = chi2(counts)
+        return c < dof + 6 * np.sqrt(2 * dof)                      # six sigma of the chi-square distribution
+
+    zero = np.zeros(n, np.uint8)
+    draws = {t: oracle.explore_actions(zero, 1.0, 77, t, global_offset=1 << 33) for t in range(100, 106)}
+    for t, a in draws.items():
+        assert a.max() < 40 and ok(np.bincount(a, minlength=40)), t
+    pair = lambda x, y: np.bincount(x.astype(np.int64) * 40 + y, minlength=1600)
+    assert ok(pair(draws[100], draws[101]))                         # the two halves of one hash word
+    assert ok(pair(draws[101], draws[102]))                         # across a pair boundary
+    assert ok(pair(draws[100], draws[102]))                         # the same half of consecutive words
+    assert ok(pair(draws[104][:-1], draws[104][1:]))                # neighbouring boards, same step
+    other = oracle.explore_actions(zero, 1.0, 78, 100, global_offset=1 << 33)
+    assert ok(pair(draws[100], other))                              # another seed
+    for eps in (0.25, 0.01):
+        for t in (200, 201):
+            kept = np.full(n, 41, np.uint8)
+            a = oracle.explore_actions(kept, eps, 77, t)
+            replaced = a != 41
+            rate = replaced.mean()
+            assert abs(rate - eps) < 6 * np.sqrt(eps * (1 - eps) / n), (eps, t, rate)
+            assert ok(np.bincount(a[replaced], minlength=40)[:40]), (eps, t)
+            # what is replaced does not depend on what it is replaced by: the replacement is the epsilon = 1 draw
+            assert np.array_equal(a[replaced], oracle.explore_actions(zero, 1.0, 77, t)[replaced])
+
+
+@pytest.mark.gpu
+def test_exploration_draw_equals_the_oracle_restatement(T, oracle):
+    import torch
+    n = 70001
+    env = T.BatchedTetris(5, 20, n, seed=1, global_offset=(1 << 35) + 3)
+    for eps, step in ((1.0, 4), (1.0, 5), (0.3, 10), (0.3, 11), (0.001, 2 ** 32 - 1), (0.0, 7)):
+        start = torch.arange(n, device=env.device).remainder(40).to(torch.uint8)
+        got = env.explore_actions(start.clone(), eps, seed=(9 << 32) + 11, step=step)
+        want = oracle.explore_actions(_np(start), eps, (9 << 32) + 11, step, global_offset=(1 << 35) + 3)
+        assert np.array_equal(_np(got), want), (eps, step)
+    env.terminate()
+
+
 @pytest.mark.gpu
 def test_exploration_draw_is_uniform(T):
     """epsilon = 1: every action is replaced by the exploration draw, which must be uniform on [0, 40) (it was

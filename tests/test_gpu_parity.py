@@ -278,6 +278,46 @@ def _dense_boards(rng, n):
     return (cells.astype(np.uint16) << np.arange(10, dtype=np.uint16)).sum(-1).astype(np.uint16)
 
 
+@pytest.mark.parametrize("params,want", [((0.1, 0.0, -0.3), 0.0), ((0.7, 0.0, 0.1), 2.1999998)])
+def test_reward_is_two_roundings_not_a_fused_multiply_add(T, oracle, params, want):
+    """reward = per_line * rows (+ win) (+ lose) with TWO roundings, as on the CPU.  A move that clears three rows and
+    loses at the move limit: 0.1f * 3 - 0.3f is exactly 0 in two roundings and -7.45e-9 as one fused multiply-add (and
+    0.7f * 3 + 0.1f is 2.1999998 against 2.2) -- the compiler fuses the pair unless told not to, and random boards almost
+    never make this move.  Every entry point that computes a reward: move, step, step + observe, fused rollout."""
+    import torch
+    L, M, n = 10, 1, 130
+    rows = np.zeros((n, 20), np.uint16)
+    rows[:, 17:20] = 0x3FE                             # three rows with the cell at x = 0 missing
+    pieces = np.zeros((n, M + 1), np.uint8)            # I first: upright at x = 0 it clears all three
+    want32 = np.float32(want)
+    assert np.float32(np.float32(params[0]) * np.float32(3)) + np.float32(params[2]) == want32
+    cpu = oracle.Env(n, L, M)
+    cpu.set_pool(rows, pieces)
+    cpu.set_options(auto_reset=False, assign_mode=1, per_line=params[0], win=params[1], lose=params[2])
+    cpu.reset()
+    r_c, d_c = cpu.step(np.full(n, 10, np.uint8))
+    assert np.all(r_c == want32) and np.all(d_c == 1) and np.all(cpu.get_state()["lines"] == 3)
+    act = torch.full((n,), 10, dtype=torch.uint8, device="cuda")
+    for how in ("move", "step", "step_observe", "rollout"):
+        gpu = T.BatchedTetris(L, M, n, assign="sequential", reward=params, config_pool=(rows, pieces))
+        gpu.reset()
+        if how == "move":
+            r, d, cleared = gpu.move(np.ones(n, np.uint8), np.zeros(n, np.uint8))
+            assert np.all(_np(cleared) == 3)
+        elif how == "step":
+            _, r, d, _ = gpu.step(act, observe=False)
+        elif how == "step_observe":
+            _, r, d, _ = gpu.step(act)
+        else:
+            rsum, fin, rs, ds = gpu.rollout(act.unsqueeze(0), per_step=True)
+            assert np.array_equal(_np(rsum), _np(rs[0]))
+            r, d = rs[0], ds[0]
+        got = _np(r)
+        assert got.dtype == np.float32 and np.all(got == want32), (how, got[:4], want32)
+        assert np.all(_np(d).astype(np.uint8) == 1)
+        gpu.terminate()
+
+
 @pytest.mark.parametrize("L,M,n", [(3, 12, 8192), (10, 40, 65536), (250, 254, 4096), (1, 1, 1024)])
 def test_move_matches_oracle_on_dense_random_boards(T, oracle, L, M, n):
     rng = np.random.default_rng(L * 1000 + M)
@@ -515,14 +555,18 @@ def test_rollout_random_equals_explore_then_step_and_the_oracle(T, oracle, auto)
     cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
     cpu.set_options(auto_reset=auto, assign_mode=0, per_line=1.0, win=2.0, lose=-0.5)
     cpu.reset()
-    cut = 17
-    r1 = fused.rollout_random(cut, seed=5, step0=1000, record=True)
-    r2 = fused.rollout_random(K - cut, seed=5, step0=1000 + cut, record=True)
+    # the draws come in pairs of steps sharing one hash word: the first launch begins on an ODD step and the second one
+    # too (in the middle of a pair), so both ways into the loop are taken
+    cut, step0 = 18, 1001
+    r1 = fused.rollout_random(cut, seed=5, step0=step0, record=True)
+    r2 = fused.rollout_random(K - cut, seed=5, step0=step0 + cut, record=True)
     acts, rs, ds = (torch.cat([a, b]) for a, b in zip(r1[2:], r2[2:]))
     rsum = np.zeros(n, np.float32)
     for t in range(K):
-        a = ref.explore_actions(torch.zeros(n, dtype=torch.uint8, device=ref.device), 1.0, seed=5, step=1000 + t)
+        a = ref.explore_actions(torch.zeros(n, dtype=torch.uint8, device=ref.device), 1.0, seed=5, step=step0 + t)
         assert torch.equal(acts[t], a), t
+        # ... and the oracle's own restatement of the draw
+        assert np.array_equal(_np(a), oracle.explore_actions(np.zeros(n, np.uint8), 1.0, 5, step0 + t, global_offset=12345)), t
         _, r, d, _ = ref.step(a, observe=False)
         assert torch.equal(rs[t], r) and torch.equal(ds[t], d), t
         r_c, d_c = cpu.step(_np(a))
