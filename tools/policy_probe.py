@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import tetris_piclim as T
 
-n = 262144
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+reps = 200 if n <= 262144 else 12
 env = T.BatchedTetris(10, 40, n, auto_reset=True)
 rows, pieces = env.synthetic_configs(n)
 env.load_configs(rows, pieces)
@@ -20,10 +21,10 @@ for _ in range(5):
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(200):
+for _ in range(reps):
     env.policy_act(image, out=act)
 e1.record()
 torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 200
+ms = e0.elapsed_time(e1) / reps
 tf = 2.0 * (224 * 128 + 3 * 128 * 128 + 128 * 16) * n / (ms * 1e-3) / 1e12
 print(f"policy_bf16 {n} boards: {ms * 1e3:.2f} us = {tf:.0f} TFLOP/s = {tf / 2500:.3f} of the bf16 MFMA peak")
