@@ -235,8 +235,8 @@ int tpl_state_ptrs(tpl_env* env, void** plane_a, void** plane_b);
  * steps since the last full reset. */
 int tpl_clock_ptr(tpl_env* env, void** clock, int64_t* count);
 
-/* Tuning knobs of the step kernel: boards handled per lane (1, 2 or 4; default 2) and threads per block
- * (64, 128, 256 or 512; default 256).  Results do not depend on them. */
+/* Tuning knobs of the step kernel: boards handled per lane (1, 2 or 4; default 1 up to 2^19 boards, 2 beyond) and threads
+ * per block (64, 128, 256 or 512; default 256).  Results do not depend on them. */
 int tpl_set_tuning(tpl_env* env, int32_t boards_per_lane, int32_t block_threads);
 
 /* Replaces the carving generator behind Tetris.reset() (game/tetris.py:226-352 with RandomPieceGenerator :64-108
