@@ -212,7 +212,9 @@ int tpl_policy_pack_f32(const float* w1, const float* b1, const float* w2, const
                         const float* b3, const float* w4, const float* b4, const float* w5, const float* b5, void* image);
 int tpl_policy_act_f32(tpl_env* env, const void* image, uint8_t* action, float* logits, void* stream);
 /* Epsilon-greedy exploration on an action array: with probability epsilon action[i] is replaced by a uniform
- * action in [0, 40) (a 32-bit draw reduced by multiply-high), decided by a hash of (seed, global board index, step). */
+ * action in [0, 40), a function of (seed, global board index, step) alone: steps 2j and 2j + 1 of a board share one 32-bit
+ * hash word of (seed, index, j) and take sixteen bits of it each, (bits * 40) >> 16 -- every action within 40 / 65536 of 1/40;
+ * whether to replace is a hash of that word and the step's parity.  (The CPU restatement: oracle/tetris_oracle.c.) */
 int tpl_explore_actions(tpl_env* env, uint8_t* action, float epsilon, uint64_t seed, uint32_t step, void* stream);
 /* num_steps iterations of (tpl_policy_act, tpl_explore_actions(step0 + t), tpl_step) in ONE launch: the weights
  * stay in LDS and the boards in registers; only the trajectory leaves the chip.  Outputs, each optional:
@@ -251,7 +253,7 @@ int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t first, int
                          int64_t max_iters, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
                          int32_t* solution_len);
 
-/* The same generator on the GPU, one configuration per lane: same decisions, same output as tpl_generate_configs, for
+/* The same generator on the GPU: same decisions, same output as tpl_generate_configs, for
  * refreshing a device pool without the host (whose container may own only a few CPUs).  DEVICE pointers; `status`
  * [count] (optional) is 1 for a configuration that hit the iteration cap (max_iters, or 2^22 when 0) and whose
  * outputs are then not a finished configuration.  `work`: tpl_generate_configs_device_work_bytes(M, count) bytes. */

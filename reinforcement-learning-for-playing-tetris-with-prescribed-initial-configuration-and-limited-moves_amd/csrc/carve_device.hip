@@ -1,4 +1,4 @@
-// carve_device.hip -- the carving generator (game/tetris.py:226-352) on the GPU: one configuration per lane.
+// carve_device.hip -- the carving generator (game/tetris.py:226-352) on the GPU: each lane builds one configuration at a time.
 //
 // Same algorithm, same counter-based decision stream and therefore the same output, bit for bit, as the host
 // generator in carve_generator.hip (`tpl_generate_configs`); it exists because the container of a GPU box may use

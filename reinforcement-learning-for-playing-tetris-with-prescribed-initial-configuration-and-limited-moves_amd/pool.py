@@ -29,6 +29,54 @@ def side_stream(env, reserved_cus: int = 0, low_priority: bool = False):
     return _SIDE_STREAMS[key]
 
 
+_CONCURRENT = {}          # device index -> a torch stream whose kernels were SEEN to run beside the stepping stream's
+
+
+def concurrent_stream(env):
+    """A torch stream for the generator, tested to run CONCURRENTLY with the current (stepping) stream.
+
+    HIP deals its streams out over a few hardware queues (four by default), the stepping stream's among them, and two
+    streams on one queue do not overlap: a generator kernel submitted between two steps makes the next step wait until it
+    has finished -- 30 ms for a batch of 65,536 configurations, which is what every fourth stream of torch's pool did to
+    the step loop (profiles/r03_live_supply/hardware_queue_aliasing.log).  Nothing in the API says which queue a stream
+    is on, so the candidates are tried: a generator launch of a few milliseconds goes onto the candidate, a tiny launch
+    onto the stepping stream behind it, and the candidate is good if the tiny launch is done while the generator is still
+    running.  The first good one is kept for the life of the process."""
+    import ctypes as C
+    import torch
+    from ._lib import check
+    if env._index in _CONCURRENT:
+        return _CONCURRENT[env._index]
+    d, main = env.device, torch.cuda.current_stream(env.device)
+    L, M, count = min(env.L, 16), env.M, 64
+    rows = torch.empty((count, 20), dtype=torch.int16, device=d)
+    pieces = torch.empty((count, M + 1), dtype=torch.uint8, device=d)
+    status = torch.empty(count, dtype=torch.int32, device=d)
+    nbytes = env._lib.tpl_generate_configs_device_work_bytes(M, count)
+    work = torch.empty(nbytes, dtype=torch.uint8, device=d)
+    scratch = torch.empty(4, dtype=torch.int64, device=d)
+    torch.cuda.synchronize(d)
+    chosen = None
+    for attempt in range(12):
+        cand = torch.cuda.Stream(d)
+        busy, quick = torch.cuda.Event(), torch.cuda.Event()
+        # one wave, every lane capped at 4,000 search iterations: several milliseconds, whatever the configurations
+        check(env._lib.tpl_generate_configs_device_waves(L, M, 0x5EED, 0, count, 4000, 1, C.c_void_p(rows.data_ptr()),
+                                                         C.c_void_p(pieces.data_ptr()), None, None, C.c_void_p(status.data_ptr()),
+                                                         C.c_void_p(work.data_ptr()), nbytes, cand.cuda_stream))
+        busy.record(cand)
+        check(env._lib.tpl_get_stats(env._h, C.c_void_p(scratch.data_ptr()), main.cuda_stream))
+        quick.record(main)
+        quick.synchronize()
+        overlapped = not busy.query()             # the stepping stream's launch is done and the generator's is not
+        cand.synchronize()
+        chosen = cand
+        if overlapped:
+            break
+    _CONCURRENT[env._index] = chosen
+    return chosen
+
+
 class PoolRefresher:
     """Keeps a running BatchedTetris supplied with FRESH prescribed configurations -- the analogue of the reference's
     two producer processes feeding the reset queue while games are played (game/tetris.py:195-211, 473-488).
@@ -57,7 +105,7 @@ class PoolRefresher:
         options because the review of round 2 asked for the comparison, not because they help."""
         import torch
         self.env, self.count, self.seed, self.next_first, self.waves = env, int(count), int(seed), int(first), int(waves)
-        self.side = side_stream(env, reserved_cus, low_priority) if (reserved_cus or low_priority) else torch.cuda.Stream(env.device)
+        self.side = side_stream(env, reserved_cus, low_priority) if (reserved_cus or low_priority) else concurrent_stream(env)
         self._ready = None            # event recorded behind the batch being generated
         self._bad_host = None         # pinned: the batch's count of configurations that hit the iteration cap
         self._batch = None
