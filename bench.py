@@ -209,7 +209,7 @@ def measure_config_supply(torch, T, dev, L, M, seed):
     solver is host code."""
     import numpy as np
     env = T.BatchedTetris(L, M, 64, device=dev, seed=seed)
-    count = 1 << 18
+    count = 1 << 20                                              # a pool's worth: the batch is as long as its slowest configuration
     env.carved_configs(4096)                                     # load the kernel
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()

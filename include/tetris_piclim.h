@@ -260,8 +260,8 @@ int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t first, int
 size_t tpl_generate_configs_device_work_bytes(int32_t M, int64_t count);
 /* The kernel is persistent: its lanes take configurations from a queue until none are left (a lane that held one
  * configuration for its whole life would idle while the slowest lane of its wave searches on).  `waves` of
- * tpl_generate_configs_device_waves says how many 64-lane waves share the queue: 0 = automatic (four configurations per
- * lane, up to two waves per SIMD: the fastest for a generator that has the chip to itself); a small number -- 64 to 256
+ * tpl_generate_configs_device_waves says how many 64-lane waves share the queue (at most 4096): 0 = automatic (four
+ * configurations per lane: the fastest for a generator that has the chip to itself); a small number -- 64 to 256
  * -- bounds the generator's footprint when it runs BESIDE a stepping environment (every generator wave takes one of a
  * SIMD's eight wave slots for milliseconds).  The output does not depend on it. */
 int tpl_generate_configs_device_waves(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count, int64_t max_iters,
