@@ -611,7 +611,7 @@ def main():
                 "pool_reuse_factor")
         live["by_generator_footprint"] = [
             dict(generator=name, **{k: v for k, v in measure_live_supply(torch, T, env, actions, reward, done, args.seed, **kw).items() if k in keep})
-            for name, kw in (("1024 waves", dict(waves=1024)), ("1024 waves, batches of 262144", dict(waves=1024, count=262144)),
+            for name, kw in (("1024 waves", dict(waves=1024)), ("1024 waves, batches of 2^20 (a pool's worth)", dict(waves=1024, count=1 << 20)),
                              ("64 waves", dict(waves=64)), ("256 waves on a 32-CU stream", dict(waves=256, reserved_cus=32)))]
     env.terminate()
     del actions

@@ -38,12 +38,15 @@ def main():
              ("256b4", "256 waves, step kernel with 4 boards per lane", dict(waves=256), 4),
              ("128low", "128 waves, lowest-priority stream", dict(waves=128, low_priority=True), 2),
              ("128cu32", "128 waves on a 32-CU stream", dict(waves=128, reserved_cus=32), 2)]
+    cases += [("1M1024", "1024 waves, batches of 2^20", dict(waves=1024, count=1 << 20), 2),
+              ("1M2048", "2048 waves, batches of 2^20", dict(waves=2048, count=1 << 20), 2),
+              ("1M4096", "4096 waves, batches of 2^20", dict(waves=4096, count=1 << 20), 2)]
     for r in range(args.rounds):
         for key, name, kw, bpl in cases:
             if args.only and key not in args.only.split(","):
                 continue
             env.set_tuning(bpl, 256)
-            out = bench.measure_live_supply(torch, T, env, actions, reward, done, 0, count=args.count, min_steps=args.steps, **kw)
+            out = bench.measure_live_supply(torch, T, env, actions, reward, done, 0, **{'count': args.count, 'min_steps': args.steps, **kw})
             print(json.dumps({"round": r, "generator": name, **{k: out[k] for k in (
                 "ms_per_step", "ms_per_step_without_refresher", "slowdown", "pool_swaps", "configurations_supplied_per_s",
                 "pool_reuse_factor")}}), flush=True)
