@@ -65,11 +65,9 @@ __device__ __forceinline__ void select4(const uint32_t* c, uint32_t loc, uint32_
     d[1] = blend(m3, b[9], d[1]);
 }
 
-// calculate_drop_deltas + calculate_drop (:424-433): drop, and reverse_topography of the first column that attains
-// the minimum (np.argmin, :298)
-__device__ __forceinline__ int drop_of(const uint32_t* c, uint32_t loc, const DShape& s, uint32_t& revtopo_at_min) {
-    uint32_t d[4];
-    select4(c, loc, d);
+// calculate_drop_deltas + calculate_drop (:424-433) on the four columns under the piece (d = c[loc .. loc+3]): drop, and
+// reverse_topography of the first column that attains the minimum (np.argmin, :298)
+__device__ __forceinline__ int drop_of(const uint32_t* d, const DShape& s, uint32_t& revtopo_at_min) {
     uint32_t best = 0xFFu, at_bias = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -91,37 +89,38 @@ __device__ __forceinline__ void piece_columns(const DShape& s, uint32_t loc, uin
     m[9] = ((hi >> 4) & 0xFu) << drop;
 }
 
-// calculate_carve (:313-352)
-__device__ __forceinline__ bool try_carve(uint32_t* c, int drop, uint32_t loc, const DShape& s, bool allow_partial) {
+// calculate_carve (:313-352).  Everything a carve looks at lies in the piece's own four columns, so the attempt is made on
+// the local copy d (no second trip through the select network for the check of :341-349); the board is touched only when
+// the carve stands.
+__device__ __forceinline__ bool try_carve(uint32_t* c, const uint32_t* d, int drop, uint32_t loc, const DShape& s, bool allow_partial) {
     if (drop + (int)s.h > kRows || drop < 0) return false;                  // :317-318
-    uint32_t m[10];
-    piece_columns(s, loc, (uint32_t)drop, m);
-    if (!allow_partial) {                                                   // :321-329
-        uint32_t missing = 0;
+    uint32_t m[4], after[4], missing = 0;
 #pragma unroll
-        for (int k = 0; k < kCols; ++k) missing |= m[k] & ~c[k];
-        if (missing) return false;
+    for (int k = 0; k < 4; ++k) {
+        m[k] = ((s.pat16 >> (4 * k)) & 0xFu) << (uint32_t)drop;
+        missing |= m[k] & ~d[k];
+        after[k] = d[k] & ~m[k];                                            // :332-337
     }
-    uint32_t saved[10];
-#pragma unroll
-    for (int k = 0; k < kCols; ++k) { saved[k] = c[k]; c[k] &= ~m[k]; }     // :332-337
+    if (!allow_partial && missing) return false;                            // :321-329
     uint32_t unused;
-    if (drop_of(c, loc, s, unused) != drop) {                               // :341-349
+    if (drop_of(after, s, unused) != drop) return false;                    // :341-349: the piece must come to rest there
+    uint32_t all[10];
+    piece_columns(s, loc, (uint32_t)drop, all);
 #pragma unroll
-        for (int k = 0; k < kCols; ++k) c[k] = saved[k];
-        return false;
-    }
+    for (int k = 0; k < kCols; ++k) c[k] &= ~all[k];
     return true;
 }
 
 // carve (:286-311)
 __device__ __forceinline__ bool carve(uint32_t* c, const DShape& s, uint32_t loc, bool allow_partial) {
+    uint32_t d[4];
+    select4(c, loc, d);
     uint32_t revtopo;
-    int drop = drop_of(c, loc, s, revtopo);
+    int drop = drop_of(d, s, revtopo);
     drop += (int)revtopo + 1;                                               // :298-301
     const int tries = allow_partial ? (int)s.h : 1;                         // :304
     for (int k = 0; k < tries; ++k, --drop)
-        if (try_carve(c, drop, loc, s, allow_partial)) return true;
+        if (try_carve(c, d, drop, loc, s, allow_partial)) return true;
     return false;
 }
 
