@@ -91,3 +91,30 @@ def test_no_gpu_fails_loudly():
         T.BatchedTetris(5, 20, 16)
     with pytest.raises(ValueError):
         T.BatchedTetris(5, 20, 16, device="cpu")
+
+
+def test_snapshot_object_carries_its_tags_without_a_gpu():
+    """BatchedTetris.snapshot() returns a Snapshot: the copy of the state together with the pool generation, assignment
+    mode and swap-guard value it was taken under; clone() and to() keep them (attributes hung on a tensor were lost)."""
+    import torch
+    snap = T.Snapshot(torch.arange(12, dtype=torch.uint8), 3, "hash", 17)
+    for other in (snap.clone(), snap.to(torch.device("cpu")), snap.clone().to("cpu")):
+        assert isinstance(other, T.Snapshot)
+        assert (other.pool_generation, other.assign, other.hold) == (3, "hash", 17)
+        assert torch.equal(other.data, snap.data)
+    assert snap.clone().data.data_ptr() != snap.data.data_ptr()
+
+
+def test_generator_work_memory_is_sized_by_lanes_not_by_configurations():
+    """The device generator is persistent: its work memory is one slice per LANE (at most 4096 waves of 64), not per
+    configuration -- 2^20 configurations need what 262,144 need."""
+    lib = T._lib.lib()
+    small, big, huge = (lib.tpl_generate_configs_device_work_bytes(40, c) for c in (1000, 1 << 18, 1 << 20))
+    assert 0 < small < big == huge
+    assert lib.tpl_generate_configs_device_work_bytes(0, 10) == 0 and lib.tpl_generate_configs_device_work_bytes(40, 0) == 0
+
+
+def test_bench_names_the_host_cpu():
+    import bench
+    model = bench.cpu_model()
+    assert model is None or (isinstance(model, str) and model.strip())
