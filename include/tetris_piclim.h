@@ -214,7 +214,7 @@ int tpl_policy_act_f32(tpl_env* env, const void* image, uint8_t* action, float* 
 /* Epsilon-greedy exploration on an action array: with probability epsilon action[i] is replaced by a uniform
  * action in [0, 40), a function of (seed, global board index, step) alone: steps 2j and 2j + 1 of a board share one 32-bit
  * hash word of (seed, index, j) and take sixteen bits of it each, (bits * 40) >> 16 -- every action within 40 / 65536 of 1/40;
- * whether to replace is a hash of that word and the step's parity.  (The CPU restatement: oracle/tetris_oracle.c.) */
+ * whether to replace is a hash of that word and the step's parity. */
 int tpl_explore_actions(tpl_env* env, uint8_t* action, float epsilon, uint64_t seed, uint32_t step, void* stream);
 /* num_steps iterations of (tpl_policy_act, tpl_explore_actions(step0 + t), tpl_step) in ONE launch: the weights
  * stay in LDS and the boards in registers; only the trajectory leaves the chip.  Outputs, each optional:
@@ -246,8 +246,8 @@ int tpl_set_tuning(tpl_env* env, int32_t boards_per_lane, int32_t block_threads)
  * configurations on `threads` host threads (0 = all cores).  HOST pointers: rows [count][20] uint16,
  * pieces [count][M+1] uint8, and optionally the carved solution [count][M][2] (rotations, location) with
  * solution_len [count] (the reference's debug `solution`, :155-156).  Decision k of configuration first+i is
- * the draw hash(seed, 4, first+i, k) reduced to [lo, hi] by multiply-high, so the output does not depend on
- * `threads`.  max_iters > 0 bounds
+ * a 32-bit hash of (seed, first+i, k) whose top 24 bits are reduced to [lo, hi] by a multiply (csrc/tpl_device.h,
+ * decision()), so the output does not depend on `threads`.  max_iters > 0 bounds
  * the search loop of one configuration (the reference has no bound); 1 <= L <= 16. */
 int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count, int32_t threads,
                          int64_t max_iters, uint16_t* rows, uint8_t* pieces, uint8_t* solution,

@@ -561,17 +561,23 @@ int64_t to_generate_config_tape(int L, int M, const int32_t* tape, int64_t n, in
     return t.bad ? -2 : it;
 }
 
-typedef struct { uint64_t seed, index, counter; } seeded_ctx;
+/* The counter-driven decision stream (the build's own definition): decision k of configuration `index`
+ * is the 32-bit murmur3 finaliser of  key + k * 0x9E3779B1,  key = low half XOR high half of the second-stage word of
+ * to_rng(seed, 4, index, .)  (i.e. sm64(sm64(seed ^ 4 * 0xD1B54A32D192ED03) ^ index)); its top 24 bits are reduced to
+ * [lo, hi] as lo + ((top24 * (hi - lo + 1)) >> 24). */
+typedef struct { uint32_t key, counter; } seeded_ctx;
 
 static int32_t seeded_randint(void* vctx, int32_t lo, int32_t hi) {
     seeded_ctx* c = (seeded_ctx*)vctx;
-    uint64_t h = to_rng(c->seed, 4, c->index, c->counter++);
-    return lo + (int32_t)(((h >> 32) * (uint64_t)(hi - lo + 1)) >> 32);   /* multiply-high range reduction */
+    uint32_t top24 = fmix32(c->key + c->counter * 0x9E3779B1u) >> 8;
+    c->counter += 1;
+    return lo + (int32_t)(((uint64_t)top24 * (uint64_t)(hi - lo + 1)) >> 24);
 }
 
 int64_t to_generate_config_seeded(int L, int M, uint64_t seed, uint64_t index, int64_t max_iters,
                                   uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* sol_len) {
-    seeded_ctx c = {seed, index, 0};
+    uint64_t b = sm64(sm64(seed ^ (4ull * 0xD1B54A32D192ED03ULL)) ^ index);
+    seeded_ctx c = {(uint32_t)b ^ (uint32_t)(b >> 32), 0};
     return to_generate_config(L, M, seeded_randint, &c, max_iters, rows, pieces, solution, sol_len);
 }
 

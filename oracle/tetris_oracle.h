@@ -130,8 +130,9 @@ int64_t to_generate_config(int L, int M, to_randint_fn randint, void* ctx, int64
  * *consumed = decisions used. */
 int64_t to_generate_config_tape(int L, int M, const int32_t* tape, int64_t n, int64_t* consumed,
                                 uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* sol_len);
-/* (b) counter-driven: decision k of configuration `index` is to_rng(seed, 4, index, k), reduced to [lo, hi] by
- * lo + ((draw >> 32) * (hi - lo + 1) >> 32). */
+/* (b) counter-driven: decision k of configuration `index` is the 32-bit murmur3 finaliser of key + k * 0x9E3779B1 (key = the
+ * two halves of the second-stage word of to_rng(seed, 4, index, .) folded together), its top 24 bits reduced to [lo, hi] by
+ * lo + ((top24 * (hi - lo + 1)) >> 24). */
 int64_t to_generate_config_seeded(int L, int M, uint64_t seed, uint64_t index, int64_t max_iters,
                                   uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* sol_len);
 

@@ -132,8 +132,8 @@ struct Search {
     uint32_t bag;               // the 7-bag as 3-bit fields
     int n_bag, n, n_cp, attempts, uses;
     int64_t iters;
-    uint64_t base, counter;     // the configuration's decision stream
-    __device__ __forceinline__ int randint(int lo, int hi) { return rng_range(rng_at(base, counter++), lo, hi); }
+    uint32_t key;               // the configuration's decision stream (decision(), tpl_device.h)
+    __device__ __forceinline__ int randint(int lo, int hi) { return decision(key, lo, hi); }
 };
 
 // this lane's slice of the work memory: reversed piece list, reversed solution, checkpoints (entries of 11 words: ten
@@ -142,8 +142,7 @@ struct Slice { uint8_t* pieces_rev; uint8_t* sol_rev; uint32_t* cps; };
 
 __device__ __forceinline__ void begin_search(Search& g, const CarveArgs& p, int64_t k) {
     const uint32_t filled = p.L >= kRows ? kColMask : (((1u << p.L) - 1u) << (kRows - p.L));
-    g.base = rng_base(p.seed, 4, (uint64_t)(p.first + k));
-    g.counter = 0;
+    g.key = decision_key(p.seed, (uint64_t)(p.first + k));
 #pragma unroll
     for (int x = 0; x < kCols; ++x) g.c[x] = filled;                        // :228
     g.bag = 0; g.n_bag = 0; g.n = 0; g.n_cp = 0; g.attempts = 0; g.uses = 0; g.iters = 0;

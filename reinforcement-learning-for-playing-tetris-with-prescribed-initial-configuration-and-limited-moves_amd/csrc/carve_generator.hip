@@ -7,7 +7,7 @@
 // The board is kept in the same column form as on the device (ten 20-bit words, bit r = row r), with the same
 // encoded shape table (tpl_device.h), so a column's top is one count-trailing-zeros and a carve is one AND per
 // piece column.  Random decisions are counter-based: decision k of configuration g is the draw rng(seed, 4, g, k)
-// reduced to [lo, hi] by multiply-high (rng_range), independent of the thread count.
+// reduced to [lo, hi] by a 24-bit multiply (decision(), tpl_device.h), independent of the thread count.
 #include "tpl_internal.h"
 #include "py_random.h"
 
@@ -21,9 +21,9 @@ namespace tpl {
 namespace {
 
 struct Decisions {
-    uint64_t base, counter = 0;
-    Decisions(uint64_t seed, uint64_t index) : base(rng_base(seed, 4, index)) {}
-    int randint(int lo, int hi) { return rng_range(rng_at(base, counter++), lo, hi); }
+    uint32_t key;
+    Decisions(uint64_t seed, uint64_t index) : key(decision_key(seed, index)) {}
+    int randint(int lo, int hi) { return decision(key, lo, hi); }
 };
 
 struct Shape {

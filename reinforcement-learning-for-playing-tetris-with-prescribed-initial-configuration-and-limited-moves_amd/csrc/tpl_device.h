@@ -419,6 +419,27 @@ __host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
     return h;
 }
 
+// The decision stream of the carving generators (host and device): decision k of configuration
+// `index` is  fmix32(key_k),  key_k = key_0 + k * 0x9E3779B1  (a running add),  key_0 = the two halves of
+// rng_base(seed, 4, index) folded together, and it is reduced to [lo, hi] as  lo + (((d >> 8) * (hi - lo + 1)) >> 24)
+// -- a 24-bit multiply; the ranges drawn from have at most ten values (a bias below 10 / 2^24), and at most 255 fit.
+// (Through round 2 every decision was a 64-bit splitmix round and a 64-bit multiply-high: some seven quarter-rate
+// multiplies each, three decisions per iteration of the search -- a third of what an iteration cost on the device.)
+constexpr uint32_t kDecisionStep = 0x9E3779B1u;
+__host__ __device__ __forceinline__ uint32_t decision_key(uint64_t seed, uint64_t index) {
+    const uint64_t b = rng_base(seed, 4, index);
+    return (uint32_t)b ^ (uint32_t)(b >> 32);
+}
+__host__ __device__ __forceinline__ int decision(uint32_t& key, int lo, int hi) {
+    const uint32_t d = fmix32(key) >> 8;
+    key += kDecisionStep;
+#ifdef __HIP_DEVICE_COMPILE__
+    return lo + (int)(__umul24(d, (uint32_t)(hi - lo + 1)) >> 24);
+#else
+    return lo + (int)((d * (uint32_t)(hi - lo + 1)) >> 24);
+#endif
+}
+
 // which pool entry the episode of global board `g` = global_offset + i that begins at step `birth` starts from.
 // hash mode: (g, birth, seed) folded into 32 bits, one round of a 32-bit finaliser (a bijection), range-reduced with
 // a multiply-high.  For a fixed board the folded word is birth * odd + const, so distinct births (mod 2^32) give
