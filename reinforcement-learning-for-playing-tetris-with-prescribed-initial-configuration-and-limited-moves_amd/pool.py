@@ -29,7 +29,7 @@ def side_stream(env, reserved_cus: int = 0, low_priority: bool = False):
     return _SIDE_STREAMS[key]
 
 
-_CONCURRENT = {}          # device index -> a torch stream whose kernels were SEEN to run beside the stepping stream's
+_CONCURRENT = {}          # (device index, stepping stream) -> a torch stream whose kernels were SEEN to run beside it
 
 
 def concurrent_stream(env):
@@ -45,9 +45,10 @@ def concurrent_stream(env):
     import ctypes as C
     import torch
     from ._lib import check
-    if env._index in _CONCURRENT:
-        return _CONCURRENT[env._index]
     d, main = env.device, torch.cuda.current_stream(env.device)
+    key = (env._index, main.cuda_stream)                   # tested against THIS stepping stream
+    if key in _CONCURRENT:
+        return _CONCURRENT[key]
     L, M, count = min(env.L, 16), env.M, 64
     rows = torch.empty((count, 20), dtype=torch.int16, device=d)
     pieces = torch.empty((count, M + 1), dtype=torch.uint8, device=d)
@@ -73,7 +74,7 @@ def concurrent_stream(env):
         chosen = cand
         if overlapped:
             break
-    _CONCURRENT[env._index] = chosen
+    _CONCURRENT[key] = chosen
     return chosen
 
 
