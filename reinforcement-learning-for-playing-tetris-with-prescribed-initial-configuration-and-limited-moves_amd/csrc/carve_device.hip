@@ -4,13 +4,16 @@
 // generator in carve_generator.hip (`tpl_generate_configs`); it exists because the container of a GPU box may use
 // only a handful of host CPUs, while the pool of a million-board environment wants refreshing on the device.
 //
-// Per lane: the board as ten column words in registers (the four columns under the piece come out of the same
-// blend network as in the step kernel, carving is an AND with the piece's column patterns moved into place by one
-// 64-bit shift), the 7-bag as seven 3-bit fields of one register, and a slice of `work` memory holding the piece
-// list, the solution and the checkpoints.  The lists are kept in REVERSE order: the reference prepends each carved
-// piece (`insert(0, ...)`, :258-260), so the list at any checkpoint is a suffix of every later list; appending to
-// the reversed arrays and truncating on a reload gives the same lists without ever copying them, and a checkpoint
-// is just the ten columns and a length.
+// Per lane: the board as ten column words in LDS, lane-major (column k of lane l at word 64 k + l: whatever column a lane
+// asks for, its bank is its lane number), because LDS is memory a lane can INDEX: a carve reads the four columns under
+// the piece at a per-lane address, works on that local copy -- everything a carve looks at lies in those four columns --
+// and writes them back when it stands (through round 2 the columns sat in registers: a 23-blend network to pick the four,
+// a 64-bit shift and ten extracts to put the piece back).  The number of filled cells in the bottom row, which ends the
+// search at eight (:234), is kept as a count.  The 7-bag is seven 3-bit fields of one register, and a slice of `work`
+// memory holds the piece list, the solution and the checkpoints.  The lists are kept in REVERSE order: the reference
+// prepends each carved piece (`insert(0, ...)`, :258-260), so the list at any checkpoint is a suffix of every later list;
+// appending to the reversed arrays and truncating on a reload gives the same lists without ever copying them, and a
+// checkpoint is just the ten columns, a length and the bottom-row count.
 //
 // The search loop is data dependent per lane -- a configuration takes 2,400 iterations on average at L = 10 and ten times
 // that now and then -- so a wave that held 64 configurations for their whole life would run at the pace of its slowest
@@ -49,21 +52,8 @@ __device__ __forceinline__ DShape shape_of(uint32_t piece, uint32_t rotations) {
     return DShape{sw.x & 0xFFFFu, (sw.x >> 16) & 7u, (sw.x >> 19) & 7u, sw.y};
 }
 
-// c[loc .. loc+3] (see move_board in tpl_device.h)
-__device__ __forceinline__ void select4(const uint32_t* c, uint32_t loc, uint32_t* d) {
-    const uint32_t m0 = 0u - (loc & 1u), m1 = 0u - ((loc >> 1) & 1u), m2 = 0u - ((loc >> 2) & 1u), m3 = 0u - ((loc >> 3) & 1u);
-    uint32_t a[10], b[10];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) a[k] = blend(m0, c[k + 1], c[k]);
-    a[9] = c[9];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) b[k] = blend(m1, a[k + 2], a[k]);
-    b[8] = a[8]; b[9] = a[9];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) d[k] = blend(m2, b[k + 4], b[k]);
-    d[0] = blend(m3, b[8], d[0]);
-    d[1] = blend(m3, b[9], d[1]);
-}
+constexpr int kPadCols = 3;                // empty columns behind column 9, for pieces narrower than four at the right edge
+constexpr int kColStride = 64;             // words between consecutive columns of a lane
 
 // calculate_drop_deltas + calculate_drop (:424-433) on the four columns under the piece (d = c[loc .. loc+3]): drop, and
 // reverse_topography of the first column that attains the minimum (np.argmin, :298)
@@ -79,56 +69,50 @@ __device__ __forceinline__ int drop_of(const uint32_t* d, const DShape& s, uint3
     return (int)best - 4;
 }
 
-// the piece's column patterns, shifted down by `drop`, spread over the ten columns
-__device__ __forceinline__ void piece_columns(const DShape& s, uint32_t loc, uint32_t drop, uint32_t* m) {
-    const uint64_t placed = (uint64_t)s.pat16 << (4u * loc);
-    const uint32_t lo = (uint32_t)placed, hi = (uint32_t)(placed >> 32);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) m[k] = ((lo >> (4 * k)) & 0xFu) << drop;
-    m[8] = (hi & 0xFu) << drop;
-    m[9] = ((hi >> 4) & 0xFu) << drop;
-}
-
-// calculate_carve (:313-352).  Everything a carve looks at lies in the piece's own four columns, so the attempt is made on
-// the local copy d (no second trip through the select network for the check of :341-349); the board is touched only when
-// the carve stands.
-__device__ __forceinline__ bool try_carve(uint32_t* c, const uint32_t* d, int drop, uint32_t loc, const DShape& s, bool allow_partial) {
+// calculate_carve (:313-352) on the local copy d of the piece's four columns; `after` = the columns with the piece taken out
+__device__ __forceinline__ bool try_carve(const uint32_t* d, int drop, const DShape& s, bool allow_partial, uint32_t* after) {
     if (drop + (int)s.h > kRows || drop < 0) return false;                  // :317-318
-    uint32_t m[4], after[4], missing = 0;
+    uint32_t missing = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        m[k] = ((s.pat16 >> (4 * k)) & 0xFu) << (uint32_t)drop;
-        missing |= m[k] & ~d[k];
-        after[k] = d[k] & ~m[k];                                            // :332-337
+        const uint32_t m = ((s.pat16 >> (4 * k)) & 0xFu) << (uint32_t)drop;
+        missing |= m & ~d[k];
+        after[k] = d[k] & ~m;                                               // :332-337
     }
     if (!allow_partial && missing) return false;                            // :321-329
     uint32_t unused;
-    if (drop_of(after, s, unused) != drop) return false;                    // :341-349: the piece must come to rest there
-    uint32_t all[10];
-    piece_columns(s, loc, (uint32_t)drop, all);
-#pragma unroll
-    for (int k = 0; k < kCols; ++k) c[k] &= ~all[k];
-    return true;
+    return drop_of(after, s, unused) == drop;                               // :341-349: the piece must come to rest there
 }
 
-// carve (:286-311)
-__device__ __forceinline__ bool carve(uint32_t* c, const DShape& s, uint32_t loc, bool allow_partial) {
-    uint32_t d[4];
-    select4(c, loc, d);
+// carve (:286-311) on the lane's columns in LDS; `bottom` = filled cells of the bottom row, kept up to date
+__device__ __forceinline__ bool carve(uint32_t* col, uint32_t& bottom, const DShape& s, uint32_t loc, bool allow_partial) {
+    uint32_t* under = col + loc * kColStride;
+    uint32_t d[4], after[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = under[k * kColStride];
     uint32_t revtopo;
     int drop = drop_of(d, s, revtopo);
     drop += (int)revtopo + 1;                                               // :298-301
     const int tries = allow_partial ? (int)s.h : 1;                         // :304
-    for (int k = 0; k < tries; ++k, --drop)
-        if (try_carve(c, d, drop, loc, s, allow_partial)) return true;
+    for (int t = 0; t < tries; ++t, --drop) {
+        if (try_carve(d, drop, s, allow_partial, after)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                under[k * kColStride] = after[k];
+                bottom -= ((d[k] ^ after[k]) >> (kRows - 1)) & 1u;
+            }
+            return true;
+        }
+    }
     return false;
 }
 
 constexpr uint32_t kFullBag = 0u | 1u << 3 | 2u << 6 | 3u << 9 | 4u << 12 | 5u << 15 | 6u << 18;
 
-// one configuration under construction, in the registers of its lane
+// one configuration under construction: the board's columns in LDS, the rest in the registers of its lane
 struct Search {
-    uint32_t c[kCols];          // the board's columns
+    uint32_t* col;              // this lane's column 0 in LDS; column k at col[64 k]
+    uint32_t bottom;            // filled cells of the bottom row (the search ends at eight, :234)
     uint32_t bag;               // the 7-bag as 3-bit fields
     int n_bag, n, n_cp, attempts, uses;
     int64_t iters;
@@ -137,23 +121,19 @@ struct Search {
 };
 
 // this lane's slice of the work memory: reversed piece list, reversed solution, checkpoints (entries of 11 words: ten
-// columns, list length)
+// columns, then list length | bottom-row count << 16)
 struct Slice { uint8_t* pieces_rev; uint8_t* sol_rev; uint32_t* cps; };
 
 __device__ __forceinline__ void begin_search(Search& g, const CarveArgs& p, int64_t k) {
     const uint32_t filled = p.L >= kRows ? kColMask : (((1u << p.L) - 1u) << (kRows - p.L));
     g.key = decision_key(p.seed, (uint64_t)(p.first + k));
 #pragma unroll
-    for (int x = 0; x < kCols; ++x) g.c[x] = filled;                        // :228
+    for (int x = 0; x < kCols; ++x) g.col[x * kColStride] = filled;         // :228
+    g.bottom = (uint32_t)kCols;                                             // L >= 1: the bottom row is full
     g.bag = 0; g.n_bag = 0; g.n = 0; g.n_cp = 0; g.attempts = 0; g.uses = 0; g.iters = 0;
 }
 
-__device__ __forceinline__ bool solved(const Search& g) {
-    int bottom = 0;
-#pragma unroll
-    for (int x = 0; x < kCols; ++x) bottom += (g.c[x] >> (kRows - 1)) & 1u;
-    return bottom <= 8;                                                     // :234
-}
+__device__ __forceinline__ bool solved(const Search& g) { return g.bottom <= 8u; }     // :234
 
 // one trip of the reference's while loop (:234-279)
 __device__ __forceinline__ void search_iteration(Search& g, const Slice& w, const CarveArgs& p) {
@@ -165,14 +145,14 @@ __device__ __forceinline__ void search_iteration(Search& g, const Slice& w, cons
     if (fresh && g.n_cp < max_cps) {                                        // :239-247
         uint32_t* e = w.cps + g.n_cp * 11;
 #pragma unroll
-        for (int x = 0; x < kCols; ++x) e[x] = g.c[x];
-        e[10] = (uint32_t)g.n;
+        for (int x = 0; x < kCols; ++x) e[x] = g.col[x * kColStride];
+        e[10] = (uint32_t)g.n | (g.bottom << 16);
         ++g.n_cp;
     }
     const int rotations = g.randint(0, 3);                                  // :250
     const DShape s = shape_of(piece, (uint32_t)rotations);
     const int loc = g.randint(0, kCols - (int)s.w);                         // :253
-    if (g.n < p.M && carve(g.c, s, (uint32_t)loc, g.n == 0)) {              // :257
+    if (g.n < p.M && carve(g.col, g.bottom, s, (uint32_t)loc, g.n == 0)) {  // :257
         w.pieces_rev[g.n] = (uint8_t)piece;                                 // insert(0, ...) (:258-260), reversed
         w.sol_rev[2 * g.n] = (uint8_t)rotations;
         w.sol_rev[2 * g.n + 1] = (uint8_t)loc;
@@ -186,8 +166,9 @@ __device__ __forceinline__ void search_iteration(Search& g, const Slice& w, cons
         else ++g.uses;
         const uint32_t* e = w.cps + (g.n_cp - 1) * 11;
 #pragma unroll
-        for (int x = 0; x < kCols; ++x) g.c[x] = e[x];                      // :275-276
-        g.n = (int)e[10];
+        for (int x = 0; x < kCols; ++x) g.col[x * kColStride] = e[x];       // :275-276
+        g.n = (int)(e[10] & 0xFFFFu);
+        g.bottom = e[10] >> 16;
         g.bag = kFullBag; g.n_bag = 7;                                      // :278
     }
 }
@@ -220,9 +201,12 @@ __device__ __forceinline__ void write_configuration(Search& g, const Slice& w, c
         n += take; need -= take;
         g.n_bag = 0;                                                        // :100
     }
+    uint32_t c[kCols];
+#pragma unroll
+    for (int x = 0; x < kCols; ++x) c[x] = g.col[x * kColStride];
     uint16_t* rows = p.rows + k * kRows;
 #pragma unroll
-    for (int r = 0; r < kRows; ++r) rows[r] = (uint16_t)row_of_cols(g.c, r);
+    for (int r = 0; r < kRows; ++r) rows[r] = (uint16_t)row_of_cols(c, r);
 }
 
 __global__ __launch_bounds__(64) void carve_kernel(const CarveArgs p) {
@@ -233,7 +217,11 @@ __global__ __launch_bounds__(64) void carve_kernel(const CarveArgs p) {
     w.cps = (uint32_t*)(w.sol_rev + 512);
     const int64_t cap = p.max_iters > 0 ? p.max_iters : kHardIterationCap;
 
+    __shared__ uint32_t s_col[kCols + kPadCols][kColStride];
     Search g;
+    g.col = &s_col[0][threadIdx.x];
+#pragma unroll
+    for (int x = kCols; x < kCols + kPadCols; ++x) g.col[x * kColStride] = 0u;
     begin_search(g, p, 0);
     int64_t k = 0;                                                          // the configuration this lane is building
     bool busy = false, dry = false;                                         // dry: this lane found the queue empty
