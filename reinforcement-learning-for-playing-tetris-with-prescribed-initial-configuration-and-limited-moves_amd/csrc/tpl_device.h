@@ -330,8 +330,11 @@ __device__ __forceinline__ void lds_load_cols(const uint32_t* cols, uint32_t (&c
 // kernel keeps as lane masks -- its tallies, its reward and its reset test are then scalar-unit work.
 struct MoveEnd { bool topout, won, limit; };
 
+// `after_drop(topout)` runs as soon as the drop is known -- before the lock and the full-row test: the multi-step kernel
+// uses it to send for a topped-out board's next configuration a lock, five LDS reads and a full-row test earlier.
+template <typename AfterDrop>
 __device__ __forceinline__ uint32_t move_board_lds(Board& s, uint32_t* cols, const ShapeWord* shape, uint32_t rot, uint32_t loc,
-                                                   uint32_t L, uint32_t M, MoveEnd& end) {
+                                                   uint32_t L, uint32_t M, MoveEnd& end, AfterDrop&& after_drop) {
     const ShapeWord sh = shape[(s.window & 7u) * 4u + (rot & 3u)];                 // get_tetromino (:60-61, :359-360)
     loc = min(loc, (sh.x >> 22) & 15u);                                            // right clamp only (:363-364)
 
@@ -346,6 +349,7 @@ __device__ __forceinline__ uint32_t move_board_lds(Board& s, uint32_t* cols, con
     const int drop = (int)best - 4;                                                // calculate_drop (:424-425)
     const bool topout = drop < 0;                                                  // (:372-374)
     const uint32_t dshift = topout ? 0u : (uint32_t)drop;
+    after_drop(topout);
 
     // lock (:377-378): the four columns go back with the piece's column patterns ORed in (nothing on a top-out)
     const uint32_t pattern = topout ? 0u : sh.x;
@@ -381,6 +385,11 @@ __device__ __forceinline__ uint32_t move_board_lds(Board& s, uint32_t* cols, con
     end.won = !topout && n != 0u && s.lines >= L;
     end.limit = !topout && !end.won && s.moves >= M;
     return n;
+}
+
+__device__ __forceinline__ uint32_t move_board_lds(Board& s, uint32_t* cols, const ShapeWord* shape, uint32_t rot, uint32_t loc,
+                                                   uint32_t L, uint32_t M, MoveEnd& end) {
+    return move_board_lds(s, cols, shape, rot, loc, L, M, end, [](bool) {});
 }
 
 // the same with the state written, for the kernels that make one move per launch

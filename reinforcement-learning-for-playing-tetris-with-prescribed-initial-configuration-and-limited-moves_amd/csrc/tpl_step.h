@@ -225,8 +225,20 @@ __device__ __forceinline__ bool advance_board_lds(Board& s, uint32_t* cols, cons
         next_word += 8;
         until_refill = (uint32_t)kWindowStride;
     }
+    // A board that tops out (nineteen finishes in twenty under random play) is known to have finished as soon as its drop
+    // is: its next configuration's side record is sent for THEN, and travels under the rest of the move.
     MoveEnd end;
-    const uint32_t n_clear = move_board_lds(s, cols, shape, rot, loc, p.L, p.M, end);
+    uint4 s0 = make_uint4(0, 0, 0, 0), s1 = s0, s2 = s0;
+    uint32_t cfg = 0;
+    const auto send_for_next = [&]() {
+        // the new episode's first move is the next step; the board comes from the side record, already unpacked
+        cfg = config_of(p, i, clock + 1u, p.cur_slot);
+        const uint4* side = (const uint4*)((p.cur_slot ? p.side[1] : p.side[0]) + ((size_t)cfg << kSideShift));
+        s0 = side[0]; s1 = side[1]; s2 = side[2];
+    };
+    const uint32_t n_clear = move_board_lds(s, cols, shape, rot, loc, p.L, p.M, end, [&](bool topout) {
+        if (kAutoReset && topout) send_for_next();
+    });
     next_window(s, refill, word);
     const bool done = end.topout || end.won || end.limit;
     if (!kAutoReset) s.state = end.topout ? ST_LOST_TOPOUT : end.won ? ST_WON : end.limit ? ST_LOST_LIMIT : ST_RUNNING;
@@ -250,11 +262,11 @@ __device__ __forceinline__ bool advance_board_lds(Board& s, uint32_t* cols, cons
             tally.limits += 1u;
         }
         if (kAutoReset) {
-            // the new episode's first move is the next step; the board comes from the side record, already unpacked
-            const uint32_t cfg = config_of(p, i, clock + 1u, p.cur_slot);
+            if (!end.topout) {                    // won, or lost at the move limit: known only now
+                asm volatile("");
+                send_for_next();
+            }
             next_word = ((p.cur_slot ? p.pool[1] : p.pool[0]) + 32) + ((size_t)cfg << p.stride_shift);   // piece word 1 of the record
-            const uint4* side = (const uint4*)((p.cur_slot ? p.side[1] : p.side[0]) + ((size_t)cfg << kSideShift));
-            const uint4 s0 = side[0], s1 = side[1], s2 = side[2];
             const uint32_t c[kCols] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y};
             lds_store_cols(cols, c);
             s.window = s2.z; s.window_hi = s2.w;
