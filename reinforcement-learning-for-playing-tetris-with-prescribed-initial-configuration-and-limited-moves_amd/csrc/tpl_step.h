@@ -219,7 +219,8 @@ __device__ __forceinline__ bool advance_board_lds(Board& s, uint32_t* cols, cons
     // window is down to its last two entries and the next piece word replaces it
     until_refill -= 1u;
     const bool refill = until_refill == 0u && (p.n_cfg[0] | p.n_cfg[1]) != 0u;
-    uint64_t word = 0;
+    // (read only where `refill` is set: any value will do elsewhere -- initialising it costs two instructions a step)
+    uint64_t word;
     if (refill) {
         word = *(const uint64_t*)next_word;
         next_word += 8;
@@ -228,12 +229,14 @@ __device__ __forceinline__ bool advance_board_lds(Board& s, uint32_t* cols, cons
     // A board that tops out (nineteen finishes in twenty under random play) is known to have finished as soon as its drop
     // is: its next configuration's side record is sent for THEN, and travels under the rest of the move.
     MoveEnd end;
-    uint4 s0 = make_uint4(0, 0, 0, 0), s1 = s0, s2 = s0;
-    uint32_t cfg = 0;
+    // (each of these is written on the one path that reads it: left to any value, not zeroed six times a step)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 s0, s1, s2;
+    uint32_t cfg;
     const auto send_for_next = [&]() {
         // the new episode's first move is the next step; the board comes from the side record, already unpacked
         cfg = config_of(p, i, clock + 1u, p.cur_slot);
-        const uint4* side = (const uint4*)((p.cur_slot ? p.side[1] : p.side[0]) + ((size_t)cfg << kSideShift));
+        const u32x4* side = (const u32x4*)((p.cur_slot ? p.side[1] : p.side[0]) + ((size_t)cfg << kSideShift));
         s0 = side[0]; s1 = side[1]; s2 = side[2];
     };
     const uint32_t n_clear = move_board_lds(s, cols, shape, rot, loc, p.L, p.M, end, [&](bool topout) {
