@@ -52,6 +52,13 @@ def test_integration_stub_runs_as_documented():
         stub.move(rot.data_ptr(), loc.data_ptr(), reward.data_ptr(), done.data_ptr())
         torch.cuda.synchronize()
         assert torch.equal(reward, r_ref) and torch.equal(done.view(torch.bool), d_ref)
+    obs = torch.empty((n, 217), dtype=torch.float32, device=dev)
+    for t in range(12, 16):                                          # step(action) -> (obs, reward, done) in one launch
+        a = ref.synthetic_actions(t)
+        o_ref, r_ref, d_ref, _ = ref.step(a)
+        stub.step(a.data_ptr(), reward.data_ptr(), done.data_ptr(), obs.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(reward, r_ref) and torch.equal(done.view(torch.bool), d_ref) and torch.equal(obs, o_ref)
     out = {k: torch.empty(n, dtype=torch.uint8, device=dev) for k in ("cur", "nxt", "lines", "moves", "state")}
     rows_out = torch.empty((n, 20), dtype=torch.int16, device=dev)
     stub.get_state(rows_out.data_ptr(), *(out[k].data_ptr() for k in ("cur", "nxt", "lines", "moves", "state")))
