@@ -210,7 +210,7 @@ def measure_config_supply(torch, T, dev, L, M, seed):
     import numpy as np
     env = T.BatchedTetris(L, M, 64, device=dev, seed=seed)
     count = 1 << 20                                              # a pool's worth: the batch is as long as its slowest configuration
-    env.carved_configs(4096)                                     # load the kernel
+    env.carved_configs(count)                                    # load the kernel, and let torch's allocator keep the buffers
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     rows, _ = env.carved_configs(count)                           # returns after the status check (host sync)
