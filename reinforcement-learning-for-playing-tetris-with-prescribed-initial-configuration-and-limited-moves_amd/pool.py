@@ -74,6 +74,10 @@ def concurrent_stream(env):
         chosen = cand
         if overlapped:
             break
+    else:
+        import warnings
+        warnings.warn("no stream was seen to run beside the stepping stream: the supply generator will serialise with the steps "
+                      "(a stall of one generator launch per pool swap)")
     _CONCURRENT[key] = chosen
     return chosen
 
