@@ -57,50 +57,43 @@ def test_f1_plumbing_with_reference_style_object(T, prefix):
     game.terminate()
 
 
-def test_reference_test_carving_invertability_verbatim(T):
-    """The reference's own TestTetris.test_carving_invertability (game/main.py:49-57), with `tetris.Tetris` swapped
-    for this build's class and nothing else changed."""
-    tetris = T
-    L, M = 15, 40
-
-    game = tetris.Tetris(L, M, warm_reset=False, debug=True)
-
-    for i in range(0, len(game.solution)):
-        rotations, location = game.solution[i]
-        game.move(rotations, location)
-    assert game.state, 'Carving inversion failed'
-    # and again after reset(): the next prescribed configuration, counters zeroed
-    game.reset()
-    assert game.state is None and game.lines_cleared == 0 and game.moves_used == 0 and len(game.pieces) == M + 1
-    for rotations, location in game.solution:
-        game.move(rotations, location)
-    assert game.state is True and game.lines_cleared >= L
-    board, cur, nxt, l_rem, m_rem, state = game.get_state()
-    assert board.shape == (20, 10) and board.dtype == bool and l_rem <= 0 and state is True
+@pytest.mark.parametrize("L,M", [(15, 40), (5, 20)])
+def test_carved_solution_replays_to_a_win_and_reset_loads_the_next_game(T, L, M):
+    """Property behind the reference's test_carving_invertability (game/main.py:49-57), on the single-board class: the
+    recorded solution of a carved game, replayed from move 0, ends in `state is True` with at least L lines cleared,
+    within the M moves; reset() then loads the NEXT prescribed configuration with the counters zeroed."""
+    game = T.Tetris(L, M, warm_reset=False, debug=True)
+    for episode in range(2):
+        assert game.state is None and game.lines_cleared == 0 and game.moves_used == 0 and len(game.pieces) == M + 1
+        assert 1 <= len(game.solution) <= M
+        for used, (rotations, location) in enumerate(game.solution, start=1):
+            assert game.state is None, "won or lost before the solution was played out"
+            game.move(rotations, location)
+            assert game.moves_used == used
+        assert game.state is True and game.lines_cleared >= L
+        board, cur, nxt, l_rem, m_rem, state = game.get_state()
+        assert board.shape == (20, 10) and board.dtype == bool and l_rem <= 0 and m_rem >= 0 and state is True
+        game.reset()
     game.terminate()
 
 
-def test_reference_test_carving_repeatability_verbatim(T):
-    """The reference's own TestTetris.test_carving_repeatability (game/main.py:32-47): carving a full stack with a
-    game's solution, last piece first, rebuilds that game's board.  `tetris.Tetris` swapped, nothing else changed
-    (self.assertTrue -> assert)."""
-    tetris = T
+def test_recarving_a_solution_rebuilds_the_board(T):
+    """Property behind the reference's test_carving_repeatability (game/main.py:32-47): take a full stack of L rows and
+    carve a game's pieces out of it in reverse order at the solution's (rotation, location) -- every carve succeeds and
+    what is left is that game's prescribed board, cell for cell."""
     L, M = 15, 40
-    game = tetris.Tetris(L, M, warm_reset=False, debug=True)
-
-    comparative_game = tetris.Tetris(L, M, warm_reset=False, debug=True)
-    comparative_game.board[-L:, :] = True
-
-
-    for i in range(len(game.solution) - 1, -1, -1):
-        piece = game.pieces[i]
-        rotations, location = game.solution[i]
-        assert comparative_game.carve(piece, rotations, location, i==(len(game.solution) - 1)), 'Carving with solution failed'
-
+    game = T.Tetris(L, M, warm_reset=False, debug=True)
+    stack = T.Tetris(L, M, warm_reset=False, debug=True)
+    stack.board[:] = False
+    stack.board[20 - L:, :] = True
+    last = len(game.solution) - 1
+    for k in range(last, -1, -1):
+        rotations, location = game.solution[k]
+        assert stack.carve(game.pieces[k], rotations, location, k == last), f"carve {k} refused"
+    assert stack.board.sum() == 10 * L - 4 * len(game.solution)
+    assert np.array_equal(stack.board, game.board)
     game.terminate()
-
-    assert np.array_equal(game.board, comparative_game.board), 'Carving repeat failed'
-    comparative_game.terminate()
+    stack.terminate()
 
 
 # ------------------------------------------------------------------------------------------------- F2

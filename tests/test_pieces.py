@@ -1,41 +1,41 @@
-"""RandomPieceGenerator: the reference's own two tests (game/main.py:6-29) as it wrote them, and equality with the
-reference's output under the same random.seed (tests/golden/pieces.npz, made by make_golden_pieces.py)."""
+"""RandomPieceGenerator: the two properties the reference tests (game/main.py:6-29), stated here in this repo's own
+words, and equality with the reference's output under the same random.seed (tests/golden/pieces.npz, made by
+make_golden_pieces.py)."""
 import os
 import random
 import sys
-import unittest
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import tetris_piclim as tetris  # noqa: E402
 
 
-class TestRandomPieceGeneration(unittest.TestCase):
-    def test_regenerate(self):
-        random_piece_generator = tetris.RandomPieceGenerator()
+def test_bag_refills_every_seventh_draw_and_shrinks_by_one_per_deletion():
+    """Property of the reference's bag (game/tetris.py:64-108; its test_regenerate checks the same thing): a draw reports
+    a refill exactly when the bag was empty, i.e. on draws 0, 7, 14, ...; drawing does not remove, delete_index does."""
+    bag = tetris.RandomPieceGenerator()
+    for draw in range(23):
+        left_in_bag = 7 - draw % 7
+        (piece, index), refilled = bag.get_random_piece()
+        assert bool(refilled) == (left_in_bag == 7), draw
+        assert 0 <= piece <= 6 and 0 <= index < left_in_bag
+        assert len(bag) == left_in_bag                      # the draw itself leaves the bag as it is
+        bag.delete_index(index)
+        assert len(bag) == left_in_bag - 1
 
-        for i in range(16):
-            (random_piece, random_piece_index), regenerated = random_piece_generator.get_random_piece()
-            self.assertEqual(regenerated, i % 7 == 0, 'Regeneration notification failed')
 
-            self.assertEqual(len(random_piece_generator), 7 - (i % 7), 'Regeneration failed')
-
-            random_piece_generator.delete_index(random_piece_index)
-
-            self.assertEqual(len(random_piece_generator), 7 - (i % 7) - 1, 'Deletion failed')
-
-    def test_sequence(self):
-        random_piece_generator = tetris.RandomPieceGenerator()
-        sequence_length = 16
-        sequence = random_piece_generator.get_random_sequence(sequence_length)
-
-        self.assertEqual(len(sequence), sequence_length, 'Sequence of wrong length')
-
-        for i in range(0, len(sequence), 7):
-            permutation_group = sequence[i:i+7]
-            self.assertEqual(len(permutation_group), len(set(permutation_group)), 'Groups contain duplicates')
+@pytest.mark.parametrize("length", [1, 7, 16, 41])
+def test_sequence_is_made_of_whole_bags(length):
+    """get_random_sequence(n) (game/tetris.py:95-102): n ids, every aligned group of seven a permutation of 0..6 and
+    the ragged tail free of repeats."""
+    seq = tetris.RandomPieceGenerator().get_random_sequence(length)
+    assert len(seq) == length and all(0 <= p <= 6 for p in seq)
+    groups = [seq[i:i + 7] for i in range(0, length, 7)]
+    assert all(sorted(g) == list(range(7)) for g in groups if len(g) == 7)
+    assert all(len(set(g)) == len(g) for g in groups)
 
 
 def test_same_pieces_as_the_reference_under_the_same_seed():
