@@ -5,10 +5,14 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one lockstep pass of the hot path (tpl_step: one Tetris.move per board, auto-reset of finished
-boards from the device pool) over one batch of synthetic actions.  Workload = BASELINE.json configs[2]:
-1,048,576 boards per GPU, L=10, M=40, synthetic boards / 7-bag piece lists / uniform actions,
-all resident in HBM before the timed region.  N > 1 shards boards by global index, one process per GPU, no
-data-path collective; one RCCL all-reduce of the episodic-return counters closes the timed region.
+boards from the device pool) over one batch of synthetic actions.  Workload = BASELINE.json configs[2] at N = 1 and
+configs[3] at N > 1: 1,048,576 boards IN TOTAL, L=10, M=40, synthetic boards / 7-bag piece lists / uniform actions
+(SURVEY 8d), all resident in HBM before the timed region.  N > 1 shards that one batch by global board index
+(1,048,576 / N boards per GPU: fixed total work, "scaling": "strong"), one process per GPU, the same pool on every
+rank, no data-path collective; one RCCL all-reduce of the episodic-return counters closes the timed region.  The N-GPU
+job is the one-GPU job sharded: same episodes, same mean return.  Side keys: `fused_rollout` (the same job, K steps per
+launch), `shard_run` (N = 1: rank 0's shard of an 8-GPU run, measured on this GPU), `weak_scaling_job` (N > 1:
+1,048,576 boards on EVERY rank -- a different, larger job, never `value`).
 
 `python bench.py --gpus N` with N > 1 and no RANK in the environment starts the N ranks itself (a child
 `python -m torch.distributed.run`, spawned before anything touches the GPU) and exits with the child's status.
@@ -137,22 +141,17 @@ def measure_fused_rollout(torch, T, env, actions, first, K, chunk):
     return timed(torch, dev, run, 1) / (launches * chunk)
 
 
-def measure_strong_scaling(torch, T, dev, rank, world, L, M, total, seed, K, chunk, barrier, max_over_ranks):
-    """BASELINE configs[3]: ONE batch of `total` boards sharded by global board index over the ranks (fixed total
-    work).  Side figure only; `value` stays the weak-scaling job.  It is the G = 1 job, sharded: every rank loads the
-    SAME pool (entry e is synthetic configuration e, for any number of ranks), actions and configuration assignment are
-    keyed by the global board index, and the number of steps depends on the arguments only -- so `episodes` and
-    `mean_episodic_return` are the same numbers for every G (tests/test_multi_rank_gpu.py checks G = 2 against G = 1).
-    Reported both ways: one launch per step (where the per-launch dispatch gap dominates a shard of 131,072 boards)
-    and `chunk` steps per launch."""
-    shard = T.sharding.strong_shard(rank, world, total)
+def measure_weak_job(torch, T, dev, rank, world, L, M, per_gpu, seed, K, barrier, max_over_ranks):
+    """Side figure for N > 1 (the headline is BASELINE configs[3], fixed total work): `per_gpu` boards on EVERY rank,
+    i.e. a job that grows with the node.  Same pool on every rank, everything keyed by the global board index."""
+    shard = T.sharding.weak_shard(rank, world, per_gpu)
     env = T.BatchedTetris(L, M, shard.boards, device=dev, seed=seed, global_offset=shard.global_offset,
                           auto_reset=True, assign="hash")
-    rows, pieces = env.synthetic_configs(total, first=0)          # the whole pool on every rank: 128 B per entry
+    rows, pieces = env.synthetic_configs(per_gpu, first=0)
     env.load_configs(rows, pieces)
     del rows, pieces
     env.reset()
-    S = max(chunk, min(K, 500) // chunk * chunk)
+    S = max(1, min(K, 200))
     actions = torch.empty((S, shard.boards), dtype=torch.uint8, device=dev)
     for t in range(S):
         env.synthetic_actions(t, out=actions[t])
@@ -163,17 +162,58 @@ def measure_strong_scaling(torch, T, dev, rank, world, L, M, total, seed, K, chu
     torch.cuda.synchronize(dev)
     barrier()
     step = iter(range(S))
-    ms_step = max_over_ranks(timed(torch, dev, lambda: env.step_into(actions[next(step)], reward, done), S))
-    barrier()
-    ms_fused = max_over_ranks(measure_fused_rollout(torch, T, env, actions, 0, S, chunk))
-    steps_made = 20 + S + 2 * S                                   # warm-up, single steps, the fused pass twice (warm + timed)
-    mean_return, episodes = T.sharding.mean_episodic_return(env.stats_tensor(), env.reward_params)
+    ms = max_over_ranks(timed(torch, dev, lambda: env.step_into(actions[next(step)], reward, done), S))
     env.terminate()
-    return {"global_boards": total, "boards_per_gpu": shard.boards, "unit": "env-steps/s", "pool_entries": total,
-            "pool": "the same on every rank: entry e = synthetic configuration e",
-            "steps_made": steps_made, "episodes": episodes, "mean_episodic_return": mean_return if episodes else None,
-            "one_launch_per_step": {"value": float(total) / (ms_step * 1e-3), "ms_per_step": ms_step},
-            "fused_rollout": {"value": float(total) / (ms_fused * 1e-3), "ms_per_step": ms_fused, "steps_per_launch": chunk}}
+    gbs = ALGO_BYTES_PER_BOARD_STEP * per_gpu / (ms * 1e-3) / 1e9
+    return {"scaling": "weak", "boards_per_gpu": per_gpu, "global_boards": shard.global_boards, "unit": "env-steps/s",
+            "value": float(shard.global_boards) / (ms * 1e-3), "ms_per_step": ms, "steps": S,
+            "per_gpu_roofline_frac": gbs / HBM_PEAK_GBS,
+            "note": "NOT the BASELINE workload for N > 1 (that is 1,048,576 boards in total): a job N times as large"}
+
+
+def measure_shard_run(torch, T, dev, L, M, seed, total, ranks, chunk):
+    """What ONE rank of an 8-GPU run of BASELINE configs[3] does, measured on this one GPU: rank 0's shard of `total`
+    boards over `ranks` GPUs (131,072 boards at the defaults), over the whole `total`-entry pool, in the three forms the
+    library offers: one tpl_step launch per step (the headline's form), `chunk` such steps as one replayed HIP graph, and
+    `chunk` steps per launch (tpl_rollout, same per-step outputs).  `frac` prices each against HBM at the canonical
+    96 B per board-step ON THE SHARD's boards."""
+    shard = T.sharding.strong_shard(0, ranks, total)
+    n = shard.boards
+    env = T.BatchedTetris(L, M, n, device=dev, seed=seed, global_offset=shard.global_offset, auto_reset=True, assign="hash")
+    rows, pieces = env.synthetic_configs(total, first=0)
+    env.load_configs(rows, pieces)
+    del rows, pieces
+    env.reset()
+    S = 8 * chunk
+    actions = torch.empty((S, n), dtype=torch.uint8, device=dev)
+    for t in range(S):
+        env.synthetic_actions(t, out=actions[t])
+    reward = torch.empty(n, dtype=torch.float32, device=dev)
+    done = torch.empty(n, dtype=torch.uint8, device=dev)
+    for t in range(50):
+        env.step_into(actions[t % S], reward, done)
+    torch.cuda.synchronize(dev)
+
+    def leg(ms, **more):
+        gbs = ALGO_BYTES_PER_BOARD_STEP * n / (ms * 1e-3) / 1e9
+        return dict({"us_per_step": ms * 1e3, "value_per_gpu": float(n) / (ms * 1e-3), "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
+                     f"value_x{ranks}_if_every_rank_matches": float(n) * ranks / (ms * 1e-3)}, **more)
+    step = iter(range(S))
+    ms_step = timed(torch, dev, lambda: env.step_into(actions[next(step)], reward, done), S)
+    rs = torch.empty((chunk, n), dtype=torch.float32, device=dev)
+    ds = torch.empty((chunk, n), dtype=torch.uint8, device=dev)
+    replay = env.capture_steps(actions[:chunk], rs, ds)
+    replay()
+    torch.cuda.synchronize(dev)
+    ms_graph = timed(torch, dev, replay, 8) / chunk
+    ms_fused = measure_fused_rollout(torch, T, env, actions, 0, S, chunk)
+    env.terminate()
+    return {"workload": f"rank 0's shard of {total} boards over {ranks} GPUs = {n} boards, {total}-entry pool, L={L} M={M}",
+            "boards": n, "global_boards": total, "ranks": ranks, "unit": "env-steps/s",
+            "tpl_step": leg(ms_step, launches_per_step=1),
+            "capture_steps": leg(ms_graph, steps_per_graph=chunk),
+            "tpl_rollout": leg(ms_fused, steps_per_launch=chunk, outputs="per-step reward f32 + done u8 written"),
+            "note": "measured on ONE GPU; an N-GPU run's headline is global_boards / (the slowest rank's tpl_step period)"}
 
 
 def measure_out_of_cache(torch, T, dev, L, M, seed, boards=1 << 23, pool=1 << 21, steps=100):
@@ -419,10 +459,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--boards", type=int, default=1 << 20, help="boards per GPU")
+    ap.add_argument("--boards", type=int, default=1 << 20,
+                    help="boards of the job, IN TOTAL: sharded by global board index over the --gpus ranks (BASELINE configs[3])")
     ap.add_argument("--L", type=int, default=10)
     ap.add_argument("--M", type=int, default=40)
-    ap.add_argument("--pool", type=int, default=0, help="pool size per GPU (default: one config per board)")
+    ap.add_argument("--pool", type=int, default=0, help="pool entries, the same pool on every rank (default: one per board of the job)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--actor-boards", type=int, default=262144, help="boards of the config-5 actor-loop side measurement (0 = skip)")
@@ -430,8 +471,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=50, help="steps per launch of the fused-rollout side measurement (0 = skip)")
     ap.add_argument("--sustained", type=int, default=2000, help="launches of the sustained pass after the timed region (0 = skip)")
     ap.add_argument("--no-config1", action="store_true", help="skip the BASELINE configs[1] side line")
-    ap.add_argument("--strong-scaling", action="store_true",
-                    help="run the strong-scaling side figure for N = 1 too (for N > 1 it always runs): the G = 1 job")
+    ap.add_argument("--shard-ranks", type=int, default=8,
+                    help="N = 1 only: also run rank 0's shard of the job over this many GPUs (`shard_run`; 0 = skip)")
+    ap.add_argument("--no-weak-job", action="store_true", help="N > 1: skip the weak-scaling side figure (--boards per GPU)")
     ap.add_argument("--no-out-of-cache", action="store_true", help="skip the 2^23-board side run (N = 1 only)")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
@@ -492,10 +534,13 @@ def main():
         dist.all_gather(got, t)
         return [float(g.item()) for g in got]
 
-    n, L, M, K, W = args.boards, args.L, args.M, args.steps, args.warmup
+    # BASELINE configs[2] (N = 1) / configs[3] (N > 1): ONE batch of `total` boards, sharded by global board index
+    total, L, M, K, W = args.boards, args.L, args.M, args.steps, args.warmup
+    shard = T.sharding.strong_shard(rank, world, total)           # contiguous blocks of global board indices
+    n = shard.boards                                              # this rank's boards
 
     # ---- side figures that own their boards (never part of `value`) run first
-    actor = supply = config1 = strong = None
+    actor = supply = config1 = weak = shard_run = None
     if world == 1:
         if args.actor_boards > 0:
             actor = measure_actor_loop(torch, T, dev, L, M, args.actor_boards, args.seed)
@@ -503,15 +548,17 @@ def main():
             supply = measure_config_supply(torch, T, dev, L, M, args.seed)
         if not args.no_config1:
             config1 = measure_config1(torch, T, dev, args.seed, args.chunk)
-    if args.chunk > 0 and (world > 1 or args.strong_scaling):
-        strong = measure_strong_scaling(torch, T, dev, rank, world, L, M, n, args.seed, K, args.chunk, barrier, max_over_ranks)
+        if args.shard_ranks > 1 and args.chunk > 0:
+            shard_run = measure_shard_run(torch, T, dev, L, M, args.seed, total, args.shard_ranks, args.chunk)
+    elif not args.no_weak_job:
+        weak = measure_weak_job(torch, T, dev, rank, world, L, M, total, args.seed, K, barrier, max_over_ranks)
 
-    pool = args.pool or n
-    shard = T.sharding.weak_shard(rank, world, n)               # batch-index sharding: contiguous blocks
+    pool = args.pool or total
     env = T.BatchedTetris(L, M, n, device=dev, seed=args.seed, global_offset=shard.global_offset, auto_reset=True,
                           assign="hash")
     # the same pool on every rank (entry e = synthetic configuration e): with actions and assignment keyed by the
-    # global board index, the N-GPU job is ONE job of N x n boards over this pool, sharded
+    # global board index, the N-GPU job is the one-GPU job of `total` boards over this pool, sharded -- the same
+    # episodes and the same mean return for every N (tests/test_multi_rank_gpu.py)
     rows, pieces = env.synthetic_configs(pool, first=0)
     env.load_configs(rows, pieces)
     del rows, pieces
@@ -578,7 +625,7 @@ def main():
         sustained = {"launches": groups * 50, "kernel_ms_mean": max_over_ranks(evs[0].elapsed_time(evs[-1]) / (groups * 50)),
                      "kernel_ms_median_of_50s": statistics.median(per), "kernel_ms_min_of_50s": min(per),
                      "kernel_ms_max_of_50s": max(per)}
-        sustained["value"] = float(n) * world / (sustained["kernel_ms_mean"] * 1e-3)
+        sustained["value"] = float(total) / (sustained["kernel_ms_mean"] * 1e-3)
         sustained["frac"] = ALGO_BYTES_PER_BOARD_STEP * n / (sustained["kernel_ms_median_of_50s"] * 1e-3) / 1e9 / HBM_PEAK_GBS
 
     # ---- side figures on the main boards (after the timed region)
@@ -591,13 +638,13 @@ def main():
                 env.synthetic_actions(t, out=actions[t])
         barrier()
         ms = max_over_ranks(measure_fused_rollout(torch, T, env, actions, 0, S // args.chunk * args.chunk, args.chunk))
-        fused = {"value": float(n) * world / (ms * 1e-3), "unit": "env-steps/s", "steps_per_launch": args.chunk,
+        fused = {"value": float(total) / (ms * 1e-3), "unit": "env-steps/s", "steps_per_launch": args.chunk,
                  "ms_per_step": ms, "outputs": "per-step reward f32 + done u8 written", "kernel": "rollout_kernel<auto_reset>"}
         # the same kernel under the uniform random policy drawn on the device (no actions staged, no per-step outputs)
         env.rollout_random(100, seed=args.seed)
         torch.cuda.synchronize(dev)
         ms_r = max_over_ranks(timed(torch, dev, lambda: env.rollout_random(100, seed=args.seed), 4) / 100)
-        fused["device_random_policy"] = {"value": float(n) * world / (ms_r * 1e-3), "ms_per_step": ms_r, "steps_per_launch": 100,
+        fused["device_random_policy"] = {"value": float(total) / (ms_r * 1e-3), "ms_per_step": ms_r, "steps_per_launch": 100,
                                          "outputs": "reward sums and episode counts only"}
     carved = live = None
     if args.carved_pool > 0 and world == 1:
@@ -618,49 +665,55 @@ def main():
     out_of_cache = None
     if world == 1 and not args.no_out_of_cache:
         out_of_cache = measure_out_of_cache(torch, T, dev, L, M, args.seed)
-    per_rank_roofline = [{"rank": r, "kernel_ms": ms_r, "achieved": ALGO_BYTES_PER_BOARD_STEP * n / (ms_r * 1e-3) / 1e9,
-                          "frac": ALGO_BYTES_PER_BOARD_STEP * n / (ms_r * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                         for r, ms_r in enumerate(per_rank_ms)]
+    # each rank's kernel priced on the boards of ITS shard
+    per_rank_roofline = []
+    for r, ms_r in enumerate(per_rank_ms):
+        nb = T.sharding.strong_shard(r, world, total).boards
+        gbs = ALGO_BYTES_PER_BOARD_STEP * nb / (ms_r * 1e-3) / 1e9
+        per_rank_roofline.append({"rank": r, "boards": nb, "kernel_ms": ms_r, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS})
 
     if rank == 0:
         achieved = ALGO_BYTES_PER_BOARD_STEP * n / (steady_ms * 1e-3) / 1e9
         # HBM bytes per launch by the PMC counters: these cannot be read from inside this process (rocprofv3 collects them
         # in passes of their own), so the figure comes from the committed profile of this same command and says so
-        traffic = traffic_source = None
+        traffic = traffic_source = traffic_dec = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 # measured at 1,048,576 boards per launch; the kernel's traffic is linear in the board count
                 traffic = tj.get("hbm_bytes_per_launch") * (n / float(1 << 20))
+                if tj.get("decomposed_estimate_bytes"):
+                    traffic_dec = tj["decomposed_estimate_bytes"] * (n / float(1 << 20))
                 traffic_source = (f"NOT measured in this run: rocprofv3 --pmc passes of this command, {tj.get('source')}"
-                                  f" (commit {tj.get('commit')}), scaled to {n} boards")
+                                  f" (commit {tj.get('commit')}, source digest {str(tj.get('source_digest'))[:12]}), scaled to {n} boards")
             except Exception:
-                traffic = traffic_source = None
+                traffic = traffic_source = traffic_dec = None
         out = {
             "metric": "env-steps/sec (whole node) at 1M parallel 20x10 boards",
-            "value": float(n) * world * K / (region_ms * 1e-3),
+            "value": float(total) * K / (region_ms * 1e-3),
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
             "ms_per_step": region_ms / K,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": f"{n} boards per GPU x {world} GPU, random initial configs, L={L} M={M}, "
-                                   f"uniform random actions, auto-reset from a {pool}-entry device pool "
-                                   "(BASELINE configs[2])",
-                       "boards_per_gpu": n, "L": L, "M": M, "parallelism": f"batch-shard x{world}"},
+            "config": {"workload": f"{total} boards in total" + (f", batch-sharded over {world} GPUs ({n} on rank 0)" if world > 1 else " on 1 GPU")
+                                   + f", random initial configs, L={L} M={M}, uniform random actions, auto-reset from a "
+                                   f"{pool}-entry device pool (the same pool on every rank), one tpl_step launch per step "
+                                   + ("(BASELINE configs[3])" if world > 1 else "(BASELINE configs[2])"),
+                       "global_boards": total, "boards_per_gpu": n, "L": L, "M": M, "parallelism": f"batch-shard x{world}"},
             "timing": {"clock": "HIP events on the launch stream around the K launches, max over ranks",
                        "warmup_placement": f"{max(W - 1, 0)} warm-up step(s) before the synchronize, {min(W, 1)} after it directly "
                                            "ahead of the first timed launch (it takes the wake-up of the idle queue)",
                        "per_rank_ms_per_step": per_rank_ms, "wall_ms_per_step": wall_ms / K, "collective_ms": collective_ms,
                        "launch_after_synchronize_ms": wake_ms,
-                       "order": "side figures that own their boards (actor loop, config supply, configs[1]; strong scaling for "
-                                "N > 1) ran BEFORE the timed region; those on the main boards (sustained pass, fused rollout, "
+                       "order": "side figures that own their boards (actor loop, config supply, configs[1], shard_run; the weak job "
+                                "for N > 1) ran BEFORE the timed region; those on the main boards (sustained pass, fused rollout, "
                                 "carved pool, live supply), the out-of-cache run and the C leg of the CPU baseline after it "
                                 "(its NumPy leg runs in child processes before this process touches the GPU)",
                        "note": "launch_after_synchronize_ms = the last warm-up launch, the one that finds the queue empty "
@@ -672,17 +725,26 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          # counter bytes over the same launch period: what the memory system delivered, against the peak
                          "frac_traffic": (traffic / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         # the same counters read request by request: 128-B requests for the coalesced streams, 64-B for
+                         # the gathers (the guide's formula doubles every read request)
+                         "traffic_decomposed": traffic_dec,
+                         "frac_traffic_decomposed": (traffic_dec / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic_dec else None,
                          "out_of_cache": out_of_cache,
-                         "kernel": "step_kernel<action, auto_reset>", "kernel_ms": steady_ms,
+                         "kernel": "step_kernel<action, auto_reset>", "kernel_ms": steady_ms, "boards_per_launch": n,
+                         "priced_on": "rank 0's shard of the job over the slowest rank's launch period",
                          "kernel_ms_source": "launch period over the K timed launches (HIP events on the launch stream)",
                          "kernel_ms_mean": steady_ms,
                          "kernel_ms_median": (sustained or {}).get("kernel_ms_median_of_50s"),
                          "frac_median": (sustained or {}).get("frac"),
                          "launch_after_synchronize_ms": wake_ms,
                          "sustained": sustained,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BOARD_STEP * n},
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BOARD_STEP * n,
+                         "node": {"achieved": ALGO_BYTES_PER_BOARD_STEP * total / (steady_ms * 1e-3) / 1e9,
+                                  "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                                  "frac": ALGO_BYTES_PER_BOARD_STEP * total / (steady_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)}},
             "fused_rollout": fused,
-            "strong_scaling": strong,
+            "shard_run": shard_run,
+            "weak_scaling_job": weak,
             "carved_pool_run": carved,
             "live_supply_run": live,
             "config1_run": config1,

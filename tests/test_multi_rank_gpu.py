@@ -68,27 +68,45 @@ def _bench(gpus, extra=()):
 
 
 @pytest.mark.gpu
-def test_bench_gpus_2_starts_its_own_ranks_and_its_strong_run_is_the_one_rank_job_sharded():
+def test_bench_gpus_2_headline_is_the_one_gpu_job_sharded():
     """`python bench.py --gpus 2` outside torchrun (the form the driver uses for N = 1): the parent starts two ranks.
     On a one-GPU box they share cuda:0 and use gloo (TPL_BENCH_ONE_GPU / TPL_BENCH_BACKEND exist for this rehearsal).
-    The strong-scaling figure (BASELINE configs[3]) must be the G = 1 job sharded: the same episodes and the same mean
-    episodic return as the one-rank run of the same command."""
+    The HEADLINE of an N > 1 run is BASELINE configs[3] -- `--boards` boards IN TOTAL, sharded -- so it must be the
+    one-GPU job sharded: the same episodes and the same mean episodic return as `--gpus 1` of the same command, with
+    "scaling": "strong".  The job that grows with the node is a side key."""
     out = _bench(2)
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["backend"] == "gloo"      # what dist.get_backend() says
     assert out["steps"] == 20 and out["warmup"] == 5 and len(out["timing"]["per_rank_ms_per_step"]) == 2
-    assert [r["rank"] for r in out["per_rank_roofline"]] == [0, 1] and all(r["frac"] > 0 for r in out["per_rank_roofline"])
-    strong = out["strong_scaling"]
-    assert strong["global_boards"] == 65536 and strong["boards_per_gpu"] == 32768 and strong["pool_entries"] == 65536
-    assert out["value"] > 0 and out["episodes"] > 0
+    assert out["scaling"] == "strong"
+    cfg = out["config"]
+    assert cfg["global_boards"] == 65536 and cfg["boards_per_gpu"] == 32768 and "65536 boards in total" in cfg["workload"]
+    assert "configs[3]" in cfg["workload"]
+    assert [(r["rank"], r["boards"]) for r in out["per_rank_roofline"]] == [(0, 32768), (1, 32768)]
+    assert all(r["frac"] > 0 for r in out["per_rank_roofline"])
+    # value = GLOBAL boards x steps / time (never boards-per-GPU x ranks of a larger job)
+    assert out["value"] == pytest.approx(65536 / (out["ms_per_step"] * 1e-3), rel=1e-9)
+    assert out["roofline"]["boards_per_launch"] == 32768
+    assert out["roofline"]["frac"] == pytest.approx(96 * 32768 / (out["ms_per_step"] * 1e-3) / 8e12, rel=1e-6)
+    assert out["fused_rollout"]["value"] == pytest.approx(65536 / (out["fused_rollout"]["ms_per_step"] * 1e-3), rel=1e-9)
+    weak = out["weak_scaling_job"]
+    assert weak["scaling"] == "weak" and weak["boards_per_gpu"] == 65536 and weak["global_boards"] == 131072
+    assert out["shard_run"] is None
     # the line of a multi-rank run carries the CPU baseline too (rank 0's host cores)
     assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] >= 1 and out["cpu_baseline"]["cpu_model"]
-    one = _bench(1, ["--strong-scaling", "--no-cpu-baseline"])
-    assert one["n_gpus"] == 1 and one["backend"] is None and one["strong_scaling"]["boards_per_gpu"] == 65536
-    for k in ("steps_made", "episodes", "mean_episodic_return"):
-        assert strong[k] == one["strong_scaling"][k], k
-    assert strong["episodes"] > 65536
-    # the weak job on two ranks is one job of 2 x 65536 boards over the same pool: twice the boards, about twice the episodes
-    assert 1.8 < out["episodes"] / one["episodes"] < 2.2
+    one = _bench(1, ["--no-cpu-baseline", "--shard-ranks", "2"])
+    assert one["n_gpus"] == 1 and one["backend"] is None and one["scaling"] == "strong"
+    assert one["config"]["global_boards"] == 65536 and one["config"]["boards_per_gpu"] == 65536
+    assert "configs[2]" in one["config"]["workload"] and one["weak_scaling_job"] is None
+    assert out["episodes"] > 65536
+    for k in ("episodes", "mean_episodic_return"):
+        assert out[k] == one[k], k
+    # shard_run of the one-GPU line = what one rank of the two-rank run does: the same shard, all three forms
+    sr = one["shard_run"]
+    assert sr["boards"] == 32768 and sr["global_boards"] == 65536 and sr["ranks"] == 2
+    for form in ("tpl_step", "capture_steps", "tpl_rollout"):
+        assert sr[form]["us_per_step"] > 0 and 0 < sr[form]["frac"] < 1
+        assert sr[form]["frac"] == pytest.approx(96 * 32768 / (sr[form]["us_per_step"] * 1e-6) / 8e12, rel=1e-6)
+    assert sr["tpl_rollout"]["us_per_step"] < sr["tpl_step"]["us_per_step"]
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():

@@ -13,30 +13,4 @@ for P in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VA
   tag=$(echo $P | cut -d" " -f1)
   timeout -k 10 200 rocprofv3 --pmc $P --output-format csv -d $OUT/pmc_$tag -- $B > $OUT/pmc_$tag.log 2>&1 || echo "pmc $tag failed"
 done
-python3 - $OUT <<'PY'
-import collections, csv, glob, json, os, sys
-d = sys.argv[1]
-out = {"kernel_stats": [], "counters_per_launch": {}}
-for f in glob.glob(os.path.join(d, "kt", "*", "*_kernel_stats.csv")):
-    for row in csv.DictReader(open(f)):
-        if "carve_kernel" in row["Name"]:
-            out["kernel_stats"].append({k: row[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "Percentage")})
-for f in sorted(glob.glob(os.path.join(d, "pmc_*", "*", "*_counter_collection.csv"))):
-    acc = collections.defaultdict(list)
-    rows = [r for r in csv.DictReader(open(f)) if "carve_kernel" in r["Kernel_Name"]]
-    if not rows:
-        continue
-    full = max(int(r["Grid_Size"]) for r in rows)                  # the probe's full-size launches, not its 4096 warm-up
-    for r in rows:
-        if int(r["Grid_Size"]) == full:
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        out["counters_per_launch"][k] = sum(v) / len(v)
-c = out["counters_per_launch"]
-if "SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_ACTIVE_INST_VALU"):
-    out["thread_cycles_per_active_valu_cycle"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]
-if "SQ_ACTIVE_INST_VALU" in c and c.get("SQ_WAVE_CYCLES"):
-    out["valu_active_share_of_wave_cycles"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
-json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)
-print(json.dumps(out, indent=1))
-PY
+python3 tools/summarise_profile.py $OUT carve_kernel

@@ -12,24 +12,4 @@ for P in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
   tag=$(echo $P | cut -d" " -f1)
   timeout -k 10 300 rocprofv3 --pmc $P --output-format csv -d $OUT/pmc_$tag -- $B > $OUT/pmc_$tag.log 2>&1 || echo "pmc $tag failed"
 done
-python3 - "$OUT" <<'PY'
-import collections, csv, glob, json, os, sys
-d = sys.argv[1]
-out = {"counters_per_launch": {}, "kernel_stats": []}
-for f in sorted(glob.glob(os.path.join(d, "pmc_*", "*", "*_counter_collection.csv"))):
-    acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for row in csv.DictReader(open(f)):
-        name = row["Kernel_Name"]
-        if "tpl::" in name and any(k in name for k in ("step_kernel", "rollout_kernel", "policy_kernel", "policy_f32_kernel")):
-            acc[name.split("(")[0][-60:]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    for k, cs in acc.items():
-        for c, v in cs.items():
-            v = v[2:] or v
-            out["counters_per_launch"].setdefault(k, {})[c] = sum(v) / len(v)
-for f in glob.glob(os.path.join(d, "kt", "*", "*_kernel_stats.csv")):
-    for row in csv.DictReader(open(f)):
-        if "tpl::" in row["Name"]:
-            out["kernel_stats"].append({k: row[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "Percentage")})
-json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)
-print(json.dumps(out["kernel_stats"], indent=1))
-PY
+python3 tools/summarise_profile.py $OUT step_kernel rollout_kernel policy_kernel policy_f32_kernel actor_rollout
