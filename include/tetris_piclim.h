@@ -245,35 +245,46 @@ int tpl_set_tuning(tpl_env* env, int32_t boards_per_lane, int32_t block_threads)
  * and CheckpointManager :111-137; its worker process :473-479): produces `count` solvable prescribed
  * configurations on `threads` host threads (0 = all cores).  HOST pointers: rows [count][20] uint16,
  * pieces [count][M+1] uint8, and optionally the carved solution [count][M][2] (rotations, location) with
- * solution_len [count] (the reference's debug `solution`, :155-156).  Decision k of configuration first+i is
- * a 32-bit hash of (seed, first+i, k) whose top 24 bits are reduced to [lo, hi] by a multiply (csrc/tpl_device.h,
- * decision()), so the output does not depend on `threads`.  max_iters > 0 bounds
- * the search loop of one configuration (the reference has no bound); 1 <= L <= 16. */
+ * solution_len [count] (the reference's debug `solution`, :155-156).
+ *
+ * Two things here are this library's own definitions, not the reference's (csrc/tpl_device.h states both; the carving
+ * logic itself is pinned by the reference's decision tapes): (1) the decision stream -- attempt a of configuration
+ * first+i draws decision k as a 32-bit hash of key + k * stride, (key, stride) = the halves of rng(seed, 4, first+i, a),
+ * top 24 bits reduced to [lo, hi] by a multiply; (2) the restart rule -- the reference's search loop has no bound and an
+ * exponentially distributed length, so configuration first+i is the outcome of the FIRST attempt a = 0, 1, ... 23 that ends
+ * within its iteration cut-off: `cutoff` << (a / 6), or, with cutoff = 0, about twice the median search length at this L.
+ * The output depends on (L, M, seed, first+i, cutoff) only -- not on `threads`, and it is the same on the device.  If all
+ * 24 attempts run into their cut-off (an (L, M) that cannot be carved, e.g. M pieces too few for L rows) the
+ * configuration's outputs are zeroed and the call returns TPL_ERR_STATE after finishing the others.  1 <= L <= 16. */
 int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count, int32_t threads,
-                         int64_t max_iters, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
+                         int64_t cutoff, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
                          int32_t* solution_len);
 
-/* The same generator on the GPU: same decisions, same output as tpl_generate_configs, for
+/* The same generator on the GPU: same decisions, same restart rule, same output as tpl_generate_configs, for
  * refreshing a device pool without the host (whose container may own only a few CPUs).  DEVICE pointers; `status`
- * [count] (optional) is 1 for a configuration that hit the iteration cap (max_iters, or 2^22 when 0) and whose
- * outputs are then not a finished configuration.  `work`: tpl_generate_configs_device_work_bytes(M, count) bytes. */
+ * [count] (optional) is 1 for a configuration whose 24 attempts all ran into their cut-off (outputs zeroed), else 0.
+ * `work`: tpl_generate_configs_device_work_bytes(M, count) bytes, 8-byte aligned. */
 size_t tpl_generate_configs_device_work_bytes(int32_t M, int64_t count);
 /* The kernel is persistent: its lanes take configurations from a queue until none are left (a lane that held one
- * configuration for its whole life would idle while the slowest lane of its wave searches on).  `waves` of
- * tpl_generate_configs_device_waves says how many 64-lane waves share the queue (at most 4096): 0 = automatic (four
- * configurations per lane: the fastest for a generator that has the chip to itself); a small number -- 64 to 256
- * -- bounds the generator's footprint when it runs BESIDE a stepping environment (every generator wave takes one of a
- * SIMD's eight wave slots for milliseconds).  The output does not depend on it. */
-int tpl_generate_configs_device_waves(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count, int64_t max_iters,
+ * configuration for its whole life would idle while the slowest lane of its wave searches on), and once the queue is dry
+ * the lanes without work run FURTHER attempts of the configurations still being searched -- the restart rule makes the
+ * answer the lowest attempt that ends inside its cut-off, whichever lane ran it, so the end of a launch is bounded by
+ * about two cut-offs instead of by the longest search of the batch.  `waves` of tpl_generate_configs_device_waves says
+ * how many 64-lane waves share the queue (at most 4096): 0 = automatic (4096, or one lane per configuration if
+ * that is fewer: the fastest for a generator that has the chip to itself); a small number -- 64 to 256 -- bounds the generator's footprint when it runs
+ * BESIDE a stepping environment (every generator wave takes one of a SIMD's eight wave slots for milliseconds).  The
+ * output does not depend on it.  count < 2^31. */
+int tpl_generate_configs_device_waves(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count, int64_t cutoff,
                                       int32_t waves, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
                                       int32_t* solution_len, int32_t* status, void* work, size_t work_bytes, void* stream);
-int tpl_generate_configs_device(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count, int64_t max_iters,
+int tpl_generate_configs_device(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count, int64_t cutoff,
                                 uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* solution_len,
                                 int32_t* status, void* work, size_t work_bytes, void* stream);
 
 /* The same generator driven by CPython's `random` stream: configuration i is what the reference produces after
  * `random.seed(seeds[i]); Tetris(L, M, warm_reset=False)` (game/tetris.py:226-284 drawing through :85,93,250,253)
- * -- MT19937 seeded as random.seed(int) seeds it, randint/shuffle on _randbelow_with_getrandbits.  HOST pointers. */
+ * -- MT19937 seeded as random.seed(int) seeds it, randint/shuffle on _randbelow_with_getrandbits.  One search per
+ * configuration, as in the reference (no restart rule); max_iters > 0 bounds it.  HOST pointers. */
 int tpl_generate_configs_pyseed(int32_t L, int32_t M, const uint64_t* seeds, int64_t count, int32_t threads,
                                 int64_t max_iters, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
                                 int32_t* solution_len);

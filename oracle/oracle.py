@@ -75,7 +75,9 @@ def lib():
         L.to_generate_config_tape.restype = i64
         L.to_generate_config_tape.argtypes = [i32, i32, vp, i64, C.POINTER(i64), vp, vp, vp, C.POINTER(i32)]
         L.to_generate_config_seeded.restype = i64
-        L.to_generate_config_seeded.argtypes = [i32, i32, u64, u64, i64, vp, vp, vp, C.POINTER(i32)]
+        L.to_generate_config_seeded.argtypes = [i32, i32, u64, u64, i64, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
+        L.to_carve_attempt_limit.restype = i64
+        L.to_carve_attempt_limit.argtypes = [i32, i64, i32]
         L.to_board_hash.restype = u64
         L.to_board_hash.argtypes = [vp]
         L.to_bench_run.restype = i64
@@ -246,10 +248,16 @@ def generate_config_tape(L, M, tape):
     return it, used.value, rows, pieces, sol[: n.value]
 
 
-def generate_config_seeded(L, M, seed, index, max_iters=0):
+def generate_config_seeded(L, M, seed, index, cutoff=0, with_attempt=False):
+    """The build's seeded generator under its restart rule: (iterations or -1, rows, pieces, solution[, winning attempt])."""
     rows, pieces, sol, n = _gen_outputs(M)
-    it = lib().to_generate_config_seeded(L, M, seed, index, max_iters, _p(rows), _p(pieces), _p(sol), C.byref(n))
-    return it, rows, pieces, sol[: n.value]
+    attempt = C.c_int32(0)
+    it = lib().to_generate_config_seeded(L, M, seed, index, cutoff, _p(rows), _p(pieces), _p(sol), C.byref(n), C.byref(attempt))
+    return (it, rows, pieces, sol[: n.value], attempt.value) if with_attempt else (it, rows, pieces, sol[: n.value])
+
+
+def carve_attempt_limit(L, cutoff, attempt):
+    return lib().to_carve_attempt_limit(L, cutoff, attempt)
 
 
 def board_hash(rows):

@@ -561,24 +561,54 @@ int64_t to_generate_config_tape(int L, int M, const int32_t* tape, int64_t n, in
     return t.bad ? -2 : it;
 }
 
-/* The counter-driven decision stream (the build's own definition): decision k of configuration `index`
- * is the 32-bit murmur3 finaliser of  key + k * 0x9E3779B1,  key = low half XOR high half of the second-stage word of
- * to_rng(seed, 4, index, .)  (i.e. sm64(sm64(seed ^ 4 * 0xD1B54A32D192ED03) ^ index)); its top 24 bits are reduced to
- * [lo, hi] as lo + ((top24 * (hi - lo + 1)) >> 24). */
-typedef struct { uint32_t key, counter; } seeded_ctx;
+/* The counter-driven decision stream and the restart rule (the build's own definitions; the carving
+ * logic above is the reference's).
+ *
+ * Stream: attempt `a` of configuration `index` owns the word  w = to_rng(seed, 4, index, a);  its decision k is the 32-bit
+ * murmur3 finaliser of  low32(w) + k * (high32(w) | 1);  the top 24 bits are reduced to [lo, hi] as
+ * lo + ((top24 * (hi - lo + 1)) >> 24).
+ *
+ * Restart rule: the configuration is what the FIRST attempt a = 0, 1, ... 23 builds whose search loop (:234) ends within
+ * limit(a) = base << (a / 6) trips, base = `cutoff` if positive, else the table below (about twice the median search length
+ * at that L).  Every attempt starts from the full stack with its own stream.  If all 24 attempts run into their limit the
+ * configuration is capped: all-zero rows and pieces, no solution, return value -1. */
+typedef struct { uint32_t key, stride, counter; } seeded_ctx;
 
 static int32_t seeded_randint(void* vctx, int32_t lo, int32_t hi) {
     seeded_ctx* c = (seeded_ctx*)vctx;
-    uint32_t top24 = fmix32(c->key + c->counter * 0x9E3779B1u) >> 8;
+    uint32_t top24 = fmix32(c->key + c->counter * c->stride) >> 8;
     c->counter += 1;
     return lo + (int32_t)(((uint64_t)top24 * (uint64_t)(hi - lo + 1)) >> 24);
 }
 
-int64_t to_generate_config_seeded(int L, int M, uint64_t seed, uint64_t index, int64_t max_iters,
-                                  uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* sol_len) {
-    uint64_t b = sm64(sm64(seed ^ (4ull * 0xD1B54A32D192ED03ULL)) ^ index);
-    seeded_ctx c = {(uint32_t)b ^ (uint32_t)(b >> 32), 0};
-    return to_generate_config(L, M, seeded_randint, &c, max_iters, rows, pieces, solution, sol_len);
+#define TO_CARVE_ATTEMPTS 24
+static const int64_t carve_base_limit[17] = {0, 64, 64, 64, 128, 256, 384, 512, 768, 1792, 3328, 5376, 9216, 17408, 36000,
+                                             64000, 132000};
+
+int64_t to_carve_attempt_limit(int L, int64_t cutoff, int attempt) {
+    int64_t base = cutoff > 0 ? cutoff : carve_base_limit[L < 1 ? 1 : L > 16 ? 16 : L];
+    return base << (attempt / 6);
+}
+
+int64_t to_generate_config_seeded(int L, int M, uint64_t seed, uint64_t index, int64_t cutoff,
+                                  uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* sol_len, int32_t* attempt_out) {
+    int64_t total = 0;
+    for (int a = 0; a < TO_CARVE_ATTEMPTS; ++a) {
+        uint64_t w = to_rng(seed, 4, index, (uint64_t)a);
+        seeded_ctx c = {(uint32_t)w, (uint32_t)(w >> 32) | 1u, 0};
+        int64_t limit = to_carve_attempt_limit(L, cutoff, a);
+        int64_t it = to_generate_config(L, M, seeded_randint, &c, limit, rows, pieces, solution, sol_len);
+        if (it >= 0) {
+            if (attempt_out) *attempt_out = a;
+            return total + it;                       /* iterations spent on this configuration, failed attempts included */
+        }
+        total += limit;
+    }
+    memset(rows, 0, TO_ROWS * sizeof(uint16_t));
+    memset(pieces, 0, (size_t)M + 1);
+    if (sol_len) *sol_len = 0;
+    if (attempt_out) *attempt_out = TO_CARVE_ATTEMPTS;
+    return -1;
 }
 
 /* ------------------------------------------------------------------------------------------------

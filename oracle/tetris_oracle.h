@@ -130,11 +130,13 @@ int64_t to_generate_config(int L, int M, to_randint_fn randint, void* ctx, int64
  * *consumed = decisions used. */
 int64_t to_generate_config_tape(int L, int M, const int32_t* tape, int64_t n, int64_t* consumed,
                                 uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* sol_len);
-/* (b) counter-driven: decision k of configuration `index` is the 32-bit murmur3 finaliser of key + k * 0x9E3779B1 (key = the
- * two halves of the second-stage word of to_rng(seed, 4, index, .) folded together), its top 24 bits reduced to [lo, hi] by
- * lo + ((top24 * (hi - lo + 1)) >> 24). */
-int64_t to_generate_config_seeded(int L, int M, uint64_t seed, uint64_t index, int64_t max_iters,
-                                  uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* sol_len);
+/* (b) counter-driven, with the build's restart rule (both stated in tetris_oracle.c above the function): the outcome of the
+ * first of 24 attempts whose search ends within its iteration limit (`cutoff` > 0 overrides the per-L base limit).  Returns
+ * the iterations spent (failed attempts included), -1 if every attempt ran into its limit (outputs all zero);
+ * *attempt_out = the attempt that succeeded (24 when none did). */
+int64_t to_carve_attempt_limit(int L, int64_t cutoff, int attempt);
+int64_t to_generate_config_seeded(int L, int M, uint64_t seed, uint64_t index, int64_t cutoff,
+                                  uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* sol_len, int32_t* attempt_out);
 
 /* FNV-1a over the 20 rows (u16 units) -- per-step fingerprint used by the golden fixtures. */
 uint64_t to_board_hash(const uint16_t* rows);

@@ -212,12 +212,14 @@ def carve(rows, piece: int, rotations: int, location: int, allow_partial: bool):
 
 
 def generate_configs(L: int, M: int, count: int = 0, seed: int = 0, first: int = 0, threads: int = 0,
-                     max_iters: int = 0, with_solutions: bool = False, python_seeds=None):
+                     cutoff: int = 0, with_solutions: bool = False, python_seeds=None, max_iters: int = 0):
     """Carved (solvable) prescribed configurations, produced on the host cores (game/tetris.py:226-352).
 
     Returns (rows uint16 [count, 20], pieces uint8 [count, M+1]) and, with_solutions, also
-    (solution uint8 [count, M, 2], solution_len int32 [count]).  With python_seeds=[s0, s1, ...] configuration i is
-    exactly what the reference builds after random.seed(s_i) (CPython's random stream is reproduced)."""
+    (solution uint8 [count, M, 2], solution_len int32 [count]).  Configuration i is the first attempt of (seed, first + i)
+    that ends within the restart rule's iteration cut-off (`cutoff` overrides it; 0 = by L).  With
+    python_seeds=[s0, s1, ...] configuration i is exactly what the reference builds after random.seed(s_i) (CPython's
+    random stream is reproduced; one search each, `max_iters` > 0 bounds it)."""
     import numpy as np
     threads = threads or cpu_budget()
     if python_seeds is not None:
@@ -231,7 +233,7 @@ def generate_configs(L: int, M: int, count: int = 0, seed: int = 0, first: int =
     if python_seeds is not None:
         check(lib().tpl_generate_configs_pyseed(L, M, ptr(seeds), count, threads, max_iters, ptr(rows), ptr(pieces), ptr(sol), ptr(sol_len)))
     else:
-        check(lib().tpl_generate_configs(L, M, seed, first, count, threads, max_iters, ptr(rows), ptr(pieces), ptr(sol), ptr(sol_len)))
+        check(lib().tpl_generate_configs(L, M, seed, first, count, threads, cutoff, ptr(rows), ptr(pieces), ptr(sol), ptr(sol_len)))
     return (rows, pieces, sol, sol_len) if with_solutions else (rows, pieces)
 
 

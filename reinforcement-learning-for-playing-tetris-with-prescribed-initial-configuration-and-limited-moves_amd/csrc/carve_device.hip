@@ -15,31 +15,50 @@
 // appending to the reversed arrays and truncating on a reload gives the same lists without ever copying them, and a
 // checkpoint is just the ten columns, a length and the bottom-row count.
 //
-// The search loop is data dependent per lane -- a configuration takes 2,400 iterations on average at L = 10 and ten times
-// that now and then -- so a wave that held 64 configurations for their whole life would run at the pace of its slowest
-// lane with the others idle (measured: 12 of 64 lanes active per vector instruction, profiles/r03_carve).  The kernel is
-// therefore PERSISTENT with a work queue: a launch has fewer lanes than configurations, and a lane that finishes one
-// takes the index of the next from a counter in memory (one atomic add) until none are left.  Which lane builds a
-// configuration does not matter -- configuration k is a function of (seed, first + k) alone.  The wave leaves when all
-// its lanes have found the queue empty, which every lane does after finitely many iterations: the loop of one
-// configuration has no natural bound (the reference's has none either), so every configuration stops after
-// `max_iters` iterations (a hard cap applies when the caller passes 0) and reports it in `status`.
+// The search loop is data dependent per lane -- a configuration takes 2,400 iterations on average at L = 10, close to
+// exponentially distributed -- so a wave that held 64 configurations for their whole life would run at the pace of its
+// slowest lane with the others idle.  The kernel is therefore PERSISTENT with a work queue: a launch has fewer lanes than
+// configurations, and a lane that finishes one takes the index of the next from a counter in memory (one atomic add) until
+// none are left.  Which lane builds a configuration does not matter -- configuration k is a function of (seed, first + k).
+//
+// That leaves the END of a launch: when the queue runs dry every lane is in the middle of a search whose remaining length is
+// again exponential, and a wave lasts until the slowest of its 64 is through -- 28,000 iterations against 7,400 to drain the
+// queue at 2^20 configurations, a third of the lanes active on average (profiles/r03_carve: 23.8 of 64; the schedule replayed
+// from the measured histogram gives 0.35).  The restart rule (tpl_device.h) is what shortens that: a configuration is DEFINED
+// as the outcome of the first attempt a = 0, 1, ... that ends within its iteration cut-off, every attempt a pure function of
+// (seed, index, a).  While the queue has work, the lane that took a configuration runs its attempts one after the other, as
+// the host generator does.  Once the queue is dry, the lanes of a wave that have nothing left run FURTHER attempts of the
+// configurations their own wave is still searching -- a wave costs the same per trip whether one of its lanes works or all
+// do, so these attempts are free, and because helping stays inside the wave, everything it needs sits in LDS (a state word
+// and a ticket counter per configuration, updated with LDS atomics); no wave ever waits for another.  An attempt that ends
+// reports into the configuration's state word (a mask of failed attempts, a mask of finished ones); the finished attempt with
+// the lowest number wins as soon as every lower one has failed -- until then its lane holds the result (columns in LDS, lists
+// in its slice) and polls; an attempt above a finished one is dropped.  The answer is therefore the sequential definition's,
+// whatever ran where, and a wave outlives the queue by about two cut-offs instead of by its longest search.
+// (A first version let any lane of the launch help any configuration through a table in global memory: correct, and twice
+// as SLOW as no helping at all -- with every lane of the chip kept busy on speculative attempts the few that mattered ran at
+// a quarter of the speed, and thousands of waves polling one counter did the rest: profiles/r04_carve/NOTES.)
+//
+// The checkpoint stack lives in the lane's slice of global memory, but its TOP entry is mirrored in LDS: a reload (every 41
+// failed carves, so in every trip of a 64-lane wave) is then LDS traffic, and the loop is free of global loads -- it was the
+// wait for those eleven words that four waves per SIMD were needed to hide.
 #include "tpl_internal.h"
 
 namespace tpl {
 namespace {
 
-constexpr int64_t kHardIterationCap = 1 << 22;
+constexpr uint32_t kAttemptMask = (1u << kCarveAttempts) - 1u;
+constexpr int kHelpersPerConfiguration = 8;      // attempts of one configuration in flight at a time, at most (roughly)
 
 struct CarveArgs {
     int32_t L, M;
     uint64_t seed;
-    int64_t first, count, max_iters;
+    int64_t first, count, cutoff;
     uint16_t* rows;        // [count][20]
     uint8_t* pieces;       // [count][M+1]
     uint8_t* solution;     // [count][M][2] or null
     int32_t* solution_len; // [count] or null
-    int32_t* status;       // [count] or null: 0 finished, 1 stopped at the iteration cap
+    int32_t* status;       // [count] or null: 0 finished, 1 capped (every attempt ran into its cut-off)
     uint8_t* work;         // [lanes][work_stride]: one slice per LANE of the launch
     int64_t work_stride;
     unsigned long long* next;   // the queue: index of the next configuration nobody has taken yet (zeroed before the launch)
@@ -47,8 +66,8 @@ struct CarveArgs {
 
 struct DShape { uint32_t pat16, w, h; uint32_t bias; };   // column nibbles, width, height, per-column 3 - revtopo bytes
 
-__device__ __forceinline__ DShape shape_of(uint32_t piece, uint32_t rotations) {
-    const ShapeWord sw = kShapeTable[piece * 4u + (rotations & 3u)];       // get_tetromino (:60-61)
+__device__ __forceinline__ DShape shape_of(const ShapeWord* table, uint32_t piece, uint32_t rotations) {
+    const ShapeWord sw = table[piece * 4u + (rotations & 3u)];             // get_tetromino (:60-61); `table` = the wave's LDS copy
     return DShape{sw.x & 0xFFFFu, (sw.x >> 16) & 7u, (sw.x >> 19) & 7u, sw.y};
 }
 
@@ -112,21 +131,23 @@ constexpr uint32_t kFullBag = 0u | 1u << 3 | 2u << 6 | 3u << 9 | 4u << 12 | 5u <
 // one configuration under construction: the board's columns in LDS, the rest in the registers of its lane
 struct Search {
     uint32_t* col;              // this lane's column 0 in LDS; column k at col[64 k]
+    uint32_t* top;              // this lane's copy of the TOP checkpoint in LDS: ten columns, then length | bottom << 16
+    const ShapeWord* shapes;    // the shape table in LDS (a per-lane indexed read of constant memory is a vector memory load)
     uint32_t bottom;            // filled cells of the bottom row (the search ends at eight, :234)
     uint32_t bag;               // the 7-bag as 3-bit fields
     int n_bag, n, n_cp, attempts, uses;
     int64_t iters;
-    uint32_t key;               // the configuration's decision stream (decision(), tpl_device.h)
-    __device__ __forceinline__ int randint(int lo, int hi) { return decision(key, lo, hi); }
+    DecisionStream rnd;         // this attempt's decision stream (tpl_device.h)
+    __device__ __forceinline__ int randint(int lo, int hi) { return decision(rnd, lo, hi); }
 };
 
 // this lane's slice of the work memory: reversed piece list, reversed solution, checkpoints (entries of 11 words: ten
 // columns, then list length | bottom-row count << 16)
 struct Slice { uint8_t* pieces_rev; uint8_t* sol_rev; uint32_t* cps; };
 
-__device__ __forceinline__ void begin_search(Search& g, const CarveArgs& p, int64_t k) {
+__device__ __forceinline__ void begin_search(Search& g, const CarveArgs& p, int64_t k, int attempt) {
     const uint32_t filled = p.L >= kRows ? kColMask : (((1u << p.L) - 1u) << (kRows - p.L));
-    g.key = decision_key(p.seed, (uint64_t)(p.first + k));
+    g.rnd = decision_stream(p.seed, (uint64_t)(p.first + k), (uint32_t)attempt);
 #pragma unroll
     for (int x = 0; x < kCols; ++x) g.col[x * kColStride] = filled;         // :228
     g.bottom = (uint32_t)kCols;                                             // L >= 1: the bottom row is full
@@ -144,13 +165,19 @@ __device__ __forceinline__ void search_iteration(Search& g, const Slice& w, cons
     const uint32_t piece = (g.bag >> (3 * idx)) & 7u;
     if (fresh && g.n_cp < max_cps) {                                        // :239-247
         uint32_t* e = w.cps + g.n_cp * 11;
+        const uint32_t tail = (uint32_t)g.n | (g.bottom << 16);
 #pragma unroll
-        for (int x = 0; x < kCols; ++x) e[x] = g.col[x * kColStride];
-        e[10] = (uint32_t)g.n | (g.bottom << 16);
+        for (int x = 0; x < kCols; ++x) {
+            const uint32_t c = g.col[x * kColStride];
+            e[x] = c;                                                       // the stack (global memory: written, rarely read)
+            g.top[x * kColStride] = c;                                      // its top entry again, in LDS
+        }
+        e[10] = tail;
+        g.top[kCols * kColStride] = tail;
         ++g.n_cp;
     }
     const int rotations = g.randint(0, 3);                                  // :250
-    const DShape s = shape_of(piece, (uint32_t)rotations);
+    const DShape s = shape_of(g.shapes, piece, (uint32_t)rotations);
     const int loc = g.randint(0, kCols - (int)s.w);                         // :253
     if (g.n < p.M && carve(g.col, g.bottom, s, (uint32_t)loc, g.n == 0)) {  // :257
         w.pieces_rev[g.n] = (uint8_t)piece;                                 // insert(0, ...) (:258-260), reversed
@@ -162,31 +189,51 @@ __device__ __forceinline__ void search_iteration(Search& g, const Slice& w, cons
         --g.n_bag;
     } else if (g.n >= p.M || ++g.attempts > 40) {                           // :268, add_attempt (:121-123)
         g.attempts = 0;                                                     // load_checkpoint (:128-137)
-        if (g.n_cp > 1 && g.uses > 10) { --g.n_cp; g.uses = 0; }
-        else ++g.uses;
-        const uint32_t* e = w.cps + (g.n_cp - 1) * 11;
+        if (g.n_cp > 1 && g.uses > 10) {                                    // drop the top entry: the one below becomes the top
+            --g.n_cp; g.uses = 0;
+            const uint32_t* e = w.cps + (g.n_cp - 1) * 11;
 #pragma unroll
-        for (int x = 0; x < kCols; ++x) g.col[x * kColStride] = e[x];       // :275-276
-        g.n = (int)(e[10] & 0xFFFFu);
-        g.bottom = e[10] >> 16;
+            for (int x = 0; x <= kCols; ++x) g.top[x * kColStride] = e[x];
+        } else ++g.uses;
+#pragma unroll
+        for (int x = 0; x < kCols; ++x) g.col[x * kColStride] = g.top[x * kColStride];     // :275-276
+        const uint32_t tail = g.top[kCols * kColStride];
+        g.n = (int)(tail & 0xFFFFu);
+        g.bottom = tail >> 16;
         g.bag = kFullBag; g.n_bag = 7;                                      // :278
     }
 }
 
-// configuration k is finished (or gave up at the cap): lists un-reversed, the piece list filled up to M + 1 (:281-284),
-// the board in the interchange layout
-__device__ __forceinline__ void write_configuration(Search& g, const Slice& w, const CarveArgs& p, int64_t k, bool capped) {
-    if (p.status) p.status[k] = capped ? 1 : 0;
+// Configuration k is finished.  Its outputs are written by the WHOLE wave for one winning lane at a time: a lane on its own
+// would un-reverse its lists one dependent global load after the other (some thirty round trips of a microsecond with the
+// other 63 lanes waiting: at L = 5, where a wave finishes a configuration every third trip, that was nine tenths of the
+// launch), the wave reads them in one go.  `src` = the winning lane, `cfg` / `n` its configuration and list length
+// (wave-uniform).  Lists un-reversed (the reference prepends, :258-260); the board in the interchange layout.
+__device__ __forceinline__ void write_lists_and_board(const CarveArgs& p, int lane, int src, int64_t cfg, int n,
+                                                      const uint8_t* slice, const uint32_t* col_of_src) {
+    const uint8_t* pieces_rev = slice;
+    const uint8_t* sol_rev = slice + 256;
+    for (int i = lane; i < n; i += 64) {
+        p.pieces[cfg * (p.M + 1) + i] = pieces_rev[n - 1 - i];
+        if (p.solution) {
+            p.solution[(cfg * p.M + i) * 2 + 0] = sol_rev[2 * (n - 1 - i)];
+            p.solution[(cfg * p.M + i) * 2 + 1] = sol_rev[2 * (n - 1 - i) + 1];
+        }
+    }
+    if (lane < kRows) {                                                     // lane r builds row r
+        uint32_t v = 0;
+#pragma unroll
+        for (int x = 0; x < kCols; ++x) v |= ((col_of_src[x * kColStride] >> lane) & 1u) << x;
+        p.rows[cfg * kRows + lane] = (uint16_t)v;
+    }
+}
+
+// the winning lane alone: status, solution length, and the piece list filled up to M + 1 (:281-284) -- stores only
+__device__ __forceinline__ void write_padding(Search& g, const CarveArgs& p, int64_t k) {
+    if (p.status) p.status[k] = 0;
     if (p.solution_len) p.solution_len[k] = g.n;
     uint8_t* out = p.pieces + k * (p.M + 1);
     int n = g.n;
-    for (int i = 0; i < n; ++i) {
-        out[i] = w.pieces_rev[n - 1 - i];
-        if (p.solution) {
-            p.solution[(k * p.M + i) * 2 + 0] = w.sol_rev[2 * (n - 1 - i)];
-            p.solution[(k * p.M + i) * 2 + 1] = w.sol_rev[2 * (n - 1 - i) + 1];
-        }
-    }
     int need = p.M - n + 1;                                                 // get_random_sequence (:95-102)
     while (need > 0) {
         if (g.n_bag == 0) { g.bag = kFullBag; g.n_bag = 7; }
@@ -201,50 +248,246 @@ __device__ __forceinline__ void write_configuration(Search& g, const Slice& w, c
         n += take; need -= take;
         g.n_bag = 0;                                                        // :100
     }
-    uint32_t c[kCols];
-#pragma unroll
-    for (int x = 0; x < kCols; ++x) c[x] = g.col[x * kColStride];
-    uint16_t* rows = p.rows + k * kRows;
-#pragma unroll
-    for (int r = 0; r < kRows; ++r) rows[r] = (uint16_t)row_of_cols(c, r);
 }
 
-__global__ __launch_bounds__(64) void carve_kernel(const CarveArgs p) {
-    const int64_t slot = (int64_t)blockIdx.x * 64 + threadIdx.x;
+// every attempt of configuration k ran into its cut-off: all-zero outputs, status 1
+__device__ __forceinline__ void write_capped(const CarveArgs& p, int64_t k) {
+    if (p.status) p.status[k] = 1;
+    if (p.solution_len) p.solution_len[k] = 0;
+    for (int i = 0; i <= p.M; ++i) p.pieces[k * (p.M + 1) + i] = 0;
+    for (int r = 0; r < kRows; ++r) p.rows[k * kRows + r] = 0;
+}
+
+// a configuration's state word (LDS): attempts that failed (bits 0..23), attempts that finished (24..47), answered (63)
+constexpr unsigned long long kAnswered = 1ULL << 63;
+__device__ __forceinline__ uint32_t failed_of(unsigned long long st) { return (uint32_t)st & kAttemptMask; }
+__device__ __forceinline__ uint32_t finished_of(unsigned long long st) { return (uint32_t)(st >> kCarveAttempts) & kAttemptMask; }
+template <typename T> __device__ __forceinline__ T lds_load(const T* p) {             // never kept in a register across trips
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <typename T> __device__ __forceinline__ void lds_store(T* p, T v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Blocks of kWavesPerBlock waves that share nothing but the block: a CU spreads the waves of one block over its four SIMDs,
+// while 64-thread blocks land wherever a slot is free -- with 4096 of them some SIMDs ran six waves and some two, and a
+// persistent wave keeps its place for the whole launch (trips of 1.2 to 2.7 us side by side, profiles/r04_carve/NOTES).
+constexpr int kWavesPerBlock = 4;
+constexpr int kQueueChunk = 16;            // configurations a wave takes from the queue per atomic
+
+// waves_per_eu(4, 4): the register count is reported high enough that a SIMD holds no more than four of these waves --
+// with the LDS padding at the launch (four blocks to a CU) the only placement left is four waves on every SIMD
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void carve_kernel(const CarveArgs p) {
+    const int lane = (int)threadIdx.x & 63, wave_in_block = (int)threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block;
+    const int64_t slot = wave * 64 + lane;
     Slice w;
     w.pieces_rev = p.work + slot * p.work_stride;
     w.sol_rev = w.pieces_rev + 256;
     w.cps = (uint32_t*)(w.sol_rev + 512);
-    const int64_t cap = p.max_iters > 0 ? p.max_iters : kHardIterationCap;
 
-    __shared__ uint32_t s_col[kCols + kPadCols][kColStride];
+    // everything in LDS is per WAVE (no barrier anywhere: a wave runs in lockstep with itself)
+    __shared__ uint32_t s_col_all[kWavesPerBlock][kCols + kPadCols][kColStride];
+    __shared__ uint32_t s_top_all[kWavesPerBlock][kCols + 1][kColStride];
+    // per configuration taken from the queue by lane i of this wave (indexed by i, its "home"): state word, tickets handed out
+    __shared__ unsigned long long s_state_all[kWavesPerBlock][64];
+    __shared__ uint32_t s_ticket_all[kWavesPerBlock][64];
+    __shared__ ShapeWord s_shape_all[kWavesPerBlock][32];
+    uint32_t (*s_col)[kColStride] = s_col_all[wave_in_block];
+    uint32_t (*s_top)[kColStride] = s_top_all[wave_in_block];
+    unsigned long long* s_state = s_state_all[wave_in_block];
+    uint32_t* s_ticket = s_ticket_all[wave_in_block];
+    ShapeWord* s_shape = s_shape_all[wave_in_block];
+    if (lane < 32) s_shape[lane] = kShapeTable[lane];
     Search g;
-    g.col = &s_col[0][threadIdx.x];
+    g.col = &s_col[0][lane];
+    g.top = &s_top[0][lane];
+    g.shapes = s_shape;
 #pragma unroll
     for (int x = kCols; x < kCols + kPadCols; ++x) g.col[x * kColStride] = 0u;
-    begin_search(g, p, 0);
-    int64_t k = 0;                                                          // the configuration this lane is building
-    bool busy = false, dry = false;                                         // dry: this lane found the queue empty
+    begin_search(g, p, 0, 0);
+
+    enum : int { kIdle = 0, kRun = 1, kHold = 2 };
+    int mode = kIdle;
+    bool dry = false;                      // this lane found the queue empty
+    bool owns = false;                     // this lane took a configuration from the queue that has no answer yet ...
+    int32_t own_k = 0;                     // ... this one (its state word and ticket counter are s_state[lane], s_ticket[lane])
+    int32_t k = 0;                         // what this lane is running: configuration,
+    int attempt = 0, home = lane;          // attempt, and the lane that took the configuration from the queue
+    int64_t limit = 0;                     // iterations this attempt may use
+    uint32_t trip = 0;
+    // the wave's share of the queue: configurations [res_lo, res_hi) are its own to hand to its lanes (wave-uniform values)
+    int64_t res_lo = 0, res_hi = 0;
+    bool exhausted = false;                // the queue had nothing left when this wave last asked
+#ifdef TPL_CARVE_DIAG
+    // diagnostic build (tools/carve_diag.py): clocks and counters into the spare words of the queue counter's line
+    unsigned long long* diag = p.next + 2;
+    unsigned long long d_iters = 0, d_helped = 0, d_dropped = 0;
+    atomicMax(&diag[5], ~wall_clock64());                                    // earliest start, as a maximum of the complement
+    unsigned long long w_dry = 0, w_tail_trips = 0;                          // per wave: when its first lane found the queue dry
+#endif
+
+    auto begin_attempt = [&](int32_t cfg, int a, int at) {
+        k = cfg; attempt = a; home = at; limit = carve_cutoff(p.L, p.cutoff, a);
+        begin_search(g, p, cfg, a);
+        mode = kRun;
+    };
+
     for (;;) {
-        if (!busy && !dry) {
-            k = (int64_t)atomicAdd(p.next, 1ULL);
-            dry = k >= p.count;
-            busy = !dry;
-            if (busy) begin_search(g, p, k);
+        // A SIMD issues for its OLDEST wave first: of the four waves a SIMD holds, the one of the first quarter of the grid ran a
+        // trip in 1.2 us and the one of the last quarter in 2.5 (profiles/r04_carve/NOTES), which the queue evens out while it
+        // has work and nothing does afterwards -- the launch then waits for the youngest waves.  So the issue priority goes
+        // round: every 256 trips a wave takes the next of the four levels, a quarter of the grid on each at any time.
+        if ((trip & 255u) == 0u) {
+            switch (((uint32_t)blockIdx.x / (gridDim.x / 4u + 1u) + (trip >> 8)) & 3u) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
         }
-        // every lane of the wave stays in the loop until all of them are dry: the exit is wave-uniform
-        if (__ballot(busy) == 0ULL) break;
-        if (busy) {
-            const bool done = solved(g), capped = !done && g.iters >= cap;
-            if (!done && !capped) {
+        ++trip;
+        // an answered configuration no longer keeps its home lane (or the wave) in the loop
+        if (owns && (lds_load(&s_state[lane]) & kAnswered)) owns = false;
+        // (1) the queue: one atomic per wave per kQueueChunk configurations (one per lane per configuration put a million
+        // atomics on one address: at L = 5, where a search is short, they WERE the launch)
+        const unsigned long long need = __ballot(mode == kIdle && !dry && !owns);
+        if (need != 0ULL) {
+            if (res_lo >= res_hi && !exhausted) {
+                const int leader = __builtin_ctzll(need);
+                unsigned long long base = 0;
+                if (lane == leader) base = atomicAdd(p.next, (unsigned long long)kQueueChunk);
+                const int64_t got = (int64_t)(((unsigned long long)(uint32_t)__shfl((int)(base >> 32), leader) << 32) |
+                                              (uint32_t)__shfl((int)base, leader));
+                if (got >= p.count) exhausted = true;
+                else { res_lo = got; res_hi = got + kQueueChunk < p.count ? got + kQueueChunk : p.count; }
+            }
+            if ((need >> lane) & 1ULL) {
+                const int64_t q = res_lo + __popcll(need & ((1ULL << lane) - 1ULL));
+                if (q < res_hi) {
+                    owns = true; own_k = (int32_t)q;
+                    lds_store(&s_state[lane], 0ULL);
+                    lds_store(&s_ticket[lane], 0u);
+                    begin_attempt((int32_t)q, 0, lane);
+                } else if (exhausted) {                                      // else: the next trip refills the wave's share
+                    dry = true;
+#ifdef TPL_CARVE_DIAG
+                    atomicMax(&diag[0], ~wall_clock64());                     // the first lane to find the queue empty
+#endif
+                }
+            }
+            res_lo += __popcll(need);
+            if (res_lo > res_hi) res_lo = res_hi;
+        }
+        const unsigned long long open = __ballot(owns);
+#ifdef TPL_CARVE_DIAG
+        if (w_dry == 0 && __ballot(dry) != 0ULL) w_dry = wall_clock64();
+        if (w_dry != 0) ++w_tail_trips;
+#endif
+        if (open == 0ULL && __ballot(!dry) == 0ULL) break;                   // wave-uniform: nothing left here, nothing to take
+        // (2) lanes with nothing to do (the queue is dry) run a further attempt of a configuration of this wave that has no
+        // finished attempt yet and fewer than kHelpersPerConfiguration in flight
+        const unsigned long long idle = __ballot(mode == kIdle && dry);
+        if (idle != 0ULL && open != 0ULL) {
+            const unsigned long long st = lds_load(&s_state[lane]);
+            const int handed = (int)lds_load(&s_ticket[lane]);               // attempts 0 .. handed are out
+            const int flying = handed + 1 - __popc(failed_of(st) | finished_of(st));       // its attempts still running
+            const bool wants = owns && finished_of(st) == 0u && handed + 1 < kCarveAttempts && flying < kHelpersPerConfiguration;
+            // A further attempt is needed only if every one already running fails, so it is worth most where the fewest are
+            // running: this trip serves the configurations at the lowest such number (the next trip the next).  Replaying
+            // the measured search lengths, that ends a wave 17 % earlier than serving them in lane order.
+            unsigned long long cand = 0ULL;
+            for (int level = 0; level < kHelpersPerConfiguration && cand == 0ULL; ++level) cand = __ballot(wants && flying <= level);
+            if (cand != 0ULL) {
+                // the r-th idle lane takes the r-th candidate (one new attempt per configuration per trip).  The shuffle is
+                // executed by the whole wave: a lane that is switched off hands nothing to ds_bpermute
+                const int rank = __popcll(idle & ((1ULL << lane) - 1ULL));
+                int skip = rank < __popcll(cand) ? rank : 0;
+                unsigned long long m = cand;
+                while (skip-- > 0) m &= m - 1ULL;
+                const int src = __builtin_ctzll(m);
+                const int32_t cfg = __shfl(own_k, src);
+                if (mode == kIdle && dry && rank < __popcll(cand)) {
+                    const int a = (int)atomicAdd(&s_ticket[src], 1u) + 1;
+                    // a ticket below kCarveAttempts is RUN (or dropped only because a lower attempt has finished): a ticket
+                    // nobody ran would stand between a finished attempt and its win for ever
+                    if (a < kCarveAttempts) {
+                        begin_attempt(cfg, a, src);
+#ifdef TPL_CARVE_DIAG
+                        ++d_helped;
+#endif
+                    }
+                }
+            }
+        }
+        bool won = false;                  // this lane's attempt is the answer: it has finished and every lower one has failed
+        // (3) has a lower attempt of my configuration finished (mine cannot be the answer then), or -- holding a finished
+        // attempt -- have all lower ones failed?
+        if (mode != kIdle && (trip & 3u) == 0u) {
+            const unsigned long long st = lds_load(&s_state[home]);
+            const uint32_t below = (1u << attempt) - 1u;
+            if (finished_of(st) & below) {
+                mode = kIdle;
+#ifdef TPL_CARVE_DIAG
+                ++d_dropped;
+#endif
+            } else if (mode == kHold && (failed_of(st) & below) == below) won = true;
+        }
+        // (4) one trip of the search, or the end of the attempt
+        if (mode == kRun) {
+            const bool done = solved(g), out = !done && g.iters >= limit;
+            if (!done && !out) {
                 ++g.iters;
+#ifdef TPL_CARVE_DIAG
+                ++d_iters;
+#endif
                 search_iteration(g, w, p);
+            } else if (done) {
+                const unsigned long long bit = 1ULL << (kCarveAttempts + attempt);
+                const unsigned long long st = atomicOr(&s_state[home], bit) | bit;
+                const uint32_t below = (1u << attempt) - 1u;
+                if (finished_of(st) & below) mode = kIdle;
+                else if ((failed_of(st) & below) == below) won = true;
+                else mode = kHold;
             } else {
-                write_configuration(g, w, p, k, capped);
-                busy = false;
+                const unsigned long long bit = 1ULL << attempt;
+                const unsigned long long st = atomicOr(&s_state[home], bit) | bit;
+                mode = kIdle;
+                if (failed_of(st) == kAttemptMask) {                        // the last of the attempts to fail
+                    write_capped(p, k);
+                    atomicOr(&s_state[home], kAnswered);
+                } else if (home == lane && finished_of(st) == 0u) {        // the next attempt of the configuration I took
+                    const int a = (int)atomicAdd(&s_ticket[lane], 1u) + 1;
+                    if (a < kCarveAttempts) begin_attempt(k, a, lane);
+                }
+            }
+        }
+        unsigned long long winners = __ballot(won);
+        if (winners != 0ULL) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");           // the winners' list stores, before other lanes read them
+            do {
+                const int src = __builtin_ctzll(winners);
+                winners &= winners - 1ULL;
+                write_lists_and_board(p, lane, src, (int64_t)__shfl(k, src), __shfl(g.n, src),
+                                      p.work + (wave * 64 + src) * p.work_stride, &s_col[0][src]);
+            } while (winners != 0ULL);
+            if (won) {
+                write_padding(g, p, k);
+                atomicOr(&s_state[home], kAnswered);
+                mode = kIdle;
             }
         }
     }
+#ifdef TPL_CARVE_DIAG
+    atomicMax(&diag[1], wall_clock64());
+    atomicAdd(&diag[2], d_iters);
+    atomicAdd(&diag[3], d_helped);
+    atomicAdd(&diag[4], d_dropped);
+    if (lane == 0) {                                                         // per wave, behind the queue's line
+        unsigned long long* wd = p.next + 8 + (size_t)wave * 4;
+        wd[0] = w_dry; wd[1] = wall_clock64(); wd[2] = trip; wd[3] = w_tail_trips;
+    }
+#endif
 }
 
 }  // namespace
@@ -256,50 +499,59 @@ using namespace tpl;
 // more than kMaxWaves waves: four to a SIMD of the chip), then the queue's counter on a line of its own
 constexpr int64_t kMaxWaves = 4096;
 static size_t work_stride_bytes(int32_t M) { return (256 + 512 + (size_t)(M / 7 + 3) * 44 + 63) / 64 * 64; }
-static size_t work_slices(int64_t count) {
-    const int64_t waves = (count + 63) / 64;
+static size_t work_slices(int64_t count) {                        // whole blocks of four waves
+    int64_t waves = ((count + 63) / 64 + 3) / 4 * 4;
     return (size_t)(waves < kMaxWaves ? waves : kMaxWaves) * 64;
 }
+#ifdef TPL_CARVE_DIAG
+static size_t control_bytes(int64_t) { return 64 + kMaxWaves * 32; }     // + four words per wave (tools/carve_diag.py)
+#else
+static size_t control_bytes(int64_t) { return 64; }
+#endif
 
 extern "C" size_t tpl_generate_configs_device_work_bytes(int32_t M, int64_t count) {
     if (M < 1 || count < 1) return 0;
-    return work_stride_bytes(M) * work_slices(count) + 64;
+    return work_stride_bytes(M) * work_slices(count) + control_bytes(count);
 }
 
 extern "C" int tpl_generate_configs_device_waves(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count,
-                                                 int64_t max_iters, int32_t waves, uint16_t* rows, uint8_t* pieces,
+                                                 int64_t cutoff, int32_t waves, uint16_t* rows, uint8_t* pieces,
                                                  uint8_t* solution, int32_t* solution_len, int32_t* status, void* work,
                                                  size_t work_bytes, void* stream) {
     if (L < 1 || L > 16) return fail_msg(TPL_ERR_ARG, "carving needs 1 <= L <= 16 (got %d)", L);
     if (M < 1 || M > 254) return fail_msg(TPL_ERR_ARG, "M=%d out of range [1, 254]", M);
-    if (count < 1 || first < 0 || !rows || !pieces) return fail_msg(TPL_ERR_ARG, "bad count / first / output pointers");
-    if (waves < 0) return fail_msg(TPL_ERR_ARG, "waves is negative");
+    if (count < 1 || count > 0x7FFFFFFF || first < 0 || !rows || !pieces)
+        return fail_msg(TPL_ERR_ARG, "bad count / first / output pointers");
+    if (waves < 0 || cutoff < 0) return fail_msg(TPL_ERR_ARG, "waves / cutoff is negative");
     const size_t need = tpl_generate_configs_device_work_bytes(M, count);
     if (!work || work_bytes < need) return fail_msg(TPL_ERR_ARG, "work has %zu bytes, need %zu", work_bytes, need);
     if (((uintptr_t)work & 7u) != 0) return fail_msg(TPL_ERR_ARG, "work must be 8-byte aligned");
-    // how many waves share the queue.  Automatic: four configurations per lane on average (the wave's tail is then one
-    // configuration out of four or more); never more than four waves per SIMD of the chip (2^20 configurations: 14.8 M/s
-    // on 1024 waves, 16.7 on 2048, 18.6 on 4096).
+    // how many waves share the queue.  Automatic: as many as the chip runs at full rate (four per SIMD), or one lane per
+    // configuration if that is fewer -- lanes without a configuration of their own run further attempts of their wave's.
     const int64_t most = (count + 63) / 64;
-    int64_t launch = waves > 0 ? waves : (count + 255) / 256;
+    int64_t launch = waves > 0 ? waves : most;
     if (launch > most) launch = most;
     if (launch > kMaxWaves) launch = kMaxWaves;
-    if (launch < 1) launch = 1;
+    const int64_t blocks = launch < 1 ? 1 : (launch + 3) / 4;       // blocks of four waves (lanes beyond `count` only ever help)
     CarveArgs p{};
-    p.L = L; p.M = M; p.seed = seed; p.first = first; p.count = count; p.max_iters = max_iters;
+    p.L = L; p.M = M; p.seed = seed; p.first = first; p.count = count; p.cutoff = cutoff;
     p.rows = rows; p.pieces = pieces; p.solution = solution; p.solution_len = solution_len; p.status = status;
     p.work = (uint8_t*)work; p.work_stride = (int64_t)work_stride_bytes(M);
     p.next = (unsigned long long*)((uint8_t*)work + work_stride_bytes(M) * work_slices(count));
-    TPL_HIP(hipMemsetAsync(p.next, 0, sizeof(unsigned long long), (hipStream_t)stream));
-    hipLaunchKernelGGL(carve_kernel, dim3((unsigned)launch), dim3(64), 0, (hipStream_t)stream, p);
+    TPL_HIP(hipMemsetAsync(p.next, 0, 64, (hipStream_t)stream));
+    // LDS per block padded to a quarter of a CU's 160 KB: no CU takes more than four blocks (one wave of each per SIMD), so a
+    // full launch of 1024 blocks sits four to every CU instead of three here and five there
+    constexpr size_t kLdsPerBlock = 160 * 1024 / 4, kLdsStatic = 28672;
+    static_assert(kLdsStatic <= kLdsPerBlock, "the kernel's LDS arrays outgrew the padding");
+    hipLaunchKernelGGL(carve_kernel, dim3((unsigned)blocks), dim3(256), kLdsPerBlock - kLdsStatic, (hipStream_t)stream, p);
     TPL_HIP(hipGetLastError());
     return TPL_OK;
 }
 
 extern "C" int tpl_generate_configs_device(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count,
-                                           int64_t max_iters, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
+                                           int64_t cutoff, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
                                            int32_t* solution_len, int32_t* status, void* work, size_t work_bytes,
                                            void* stream) {
-    return tpl_generate_configs_device_waves(L, M, seed, first, count, max_iters, 0, rows, pieces, solution, solution_len,
+    return tpl_generate_configs_device_waves(L, M, seed, first, count, cutoff, 0, rows, pieces, solution, solution_len,
                                              status, work, work_bytes, stream);
 }

@@ -6,8 +6,9 @@
 //
 // The board is kept in the same column form as on the device (ten 20-bit words, bit r = row r), with the same
 // encoded shape table (tpl_device.h), so a column's top is one count-trailing-zeros and a carve is one AND per
-// piece column.  Random decisions are counter-based: decision k of configuration g is the draw rng(seed, 4, g, k)
-// reduced to [lo, hi] by a 24-bit multiply (decision(), tpl_device.h), independent of the thread count.
+// piece column.  Random decisions are counter-based (decision_stream() / decision(), tpl_device.h) and a configuration is
+// the outcome of the first attempt that ends within the cut-off (the restart rule, tpl_device.h) -- independent of the
+// thread count, and the same configuration the device generator and the oracle build.
 #include "tpl_internal.h"
 #include "py_random.h"
 
@@ -21,9 +22,9 @@ namespace tpl {
 namespace {
 
 struct Decisions {
-    uint32_t key;
-    Decisions(uint64_t seed, uint64_t index) : key(decision_key(seed, index)) {}
-    int randint(int lo, int hi) { return decision(key, lo, hi); }
+    DecisionStream s;
+    Decisions(uint64_t seed, uint64_t index, uint32_t attempt) : s(decision_stream(seed, index, attempt)) {}
+    int randint(int lo, int hi) { return decision(s, lo, hi); }
 };
 
 struct Shape {
@@ -165,9 +166,9 @@ bool generate_one(int L, int M, Random& rnd, int64_t max_iters, uint16_t* rows_o
 }  // namespace
 }  // namespace tpl
 
-template <typename MakeRandom>
-static int run_generator(int32_t L, int32_t M, int64_t count, int32_t threads, int64_t max_iters, uint16_t* rows,
-                         uint8_t* pieces, uint8_t* solution, int32_t* solution_len, MakeRandom make_random) {
+// `build(k)` fills configuration k's outputs and says whether it finished
+template <typename BuildOne>
+static int run_generator(int32_t L, int32_t M, int64_t count, int32_t threads, uint16_t* rows, uint8_t* pieces, BuildOne build) {
     using namespace tpl;
     if (L < 1 || L > 16) return fail_msg(TPL_ERR_ARG, "carving needs 1 <= L <= 16 (got %d)", L);
     if (M < 1 || M > 254) return fail_msg(TPL_ERR_ARG, "M=%d out of range [1, 254]", M);
@@ -181,11 +182,7 @@ static int run_generator(int32_t L, int32_t M, int64_t count, int32_t threads, i
         for (;;) {
             const int64_t k = next.fetch_add(1, std::memory_order_relaxed);
             if (k >= count) return;
-            auto rnd = make_random(k);
-            const bool ok = generate_one(L, M, rnd, max_iters, rows + k * kRows, pieces + k * (M + 1),
-                                         solution ? solution + k * (int64_t)M * 2 : nullptr,
-                                         solution_len ? solution_len + k : nullptr);
-            if (!ok) failed.store(k, std::memory_order_relaxed);
+            if (!build(k)) failed.store(k, std::memory_order_relaxed);
         }
     };
     std::vector<std::thread> pool;
@@ -193,25 +190,42 @@ static int run_generator(int32_t L, int32_t M, int64_t count, int32_t threads, i
     work();
     for (auto& th : pool) th.join();
     if (failed.load() >= 0)
-        return fail_msg(TPL_ERR_STATE, "configuration %lld did not finish within %lld iterations",
-                        (long long)failed.load(), (long long)max_iters);
+        return fail_msg(TPL_ERR_STATE, "configuration %lld did not finish (every attempt ran into its iteration limit)",
+                        (long long)failed.load());
     return TPL_OK;
 }
 
 extern "C" int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count, int32_t threads,
-                                    int64_t max_iters, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
+                                    int64_t cutoff, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
                                     int32_t* solution_len) {
-    if (first < 0) return tpl::fail_msg(TPL_ERR_ARG, "first is negative");
-    return run_generator(L, M, count, threads, max_iters, rows, pieces, solution, solution_len,
-                         [=](int64_t k) { return tpl::Decisions(seed, (uint64_t)(first + k)); });
+    using namespace tpl;
+    if (first < 0) return fail_msg(TPL_ERR_ARG, "first is negative");
+    if (cutoff < 0) return fail_msg(TPL_ERR_ARG, "cutoff is negative");
+    return run_generator(L, M, count, threads, rows, pieces, [=](int64_t k) {
+        uint8_t* sol = solution ? solution + k * (int64_t)M * 2 : nullptr;
+        int32_t* len = solution_len ? solution_len + k : nullptr;
+        for (int a = 0; a < kCarveAttempts; ++a) {          // the restart rule (tpl_device.h): first attempt inside its cut-off
+            Decisions rnd(seed, (uint64_t)(first + k), (uint32_t)a);
+            if (generate_one(L, M, rnd, carve_cutoff(L, cutoff, a), rows + k * kRows, pieces + k * (M + 1), sol, len)) return true;
+        }
+        std::memset(rows + k * kRows, 0, kRows * sizeof(uint16_t));         // capped: all-zero outputs
+        std::memset(pieces + k * (M + 1), 0, (size_t)M + 1);
+        if (len) *len = 0;
+        return false;
+    });
 }
 
 extern "C" int tpl_generate_configs_pyseed(int32_t L, int32_t M, const uint64_t* seeds, int64_t count, int32_t threads,
                                            int64_t max_iters, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
                                            int32_t* solution_len) {
-    if (!seeds) return tpl::fail_msg(TPL_ERR_ARG, "seeds is null");
-    return run_generator(L, M, count, threads, max_iters, rows, pieces, solution, solution_len,
-                         [=](int64_t k) { return tpl::PyRandom(seeds[k]); });
+    using namespace tpl;
+    if (!seeds) return fail_msg(TPL_ERR_ARG, "seeds is null");
+    // CPython's stream is the reference's own: one search, no restarts (max_iters > 0 only bounds it)
+    return run_generator(L, M, count, threads, rows, pieces, [=](int64_t k) {
+        PyRandom rnd(seeds[k]);
+        return generate_one(L, M, rnd, max_iters, rows + k * kRows, pieces + k * (M + 1),
+                            solution ? solution + k * (int64_t)M * 2 : nullptr, solution_len ? solution_len + k : nullptr);
+    });
 }
 
 // Tetris.carve(piece, rotations, location, allow_partial) (:286-311) on one board in the interchange layout (HOST

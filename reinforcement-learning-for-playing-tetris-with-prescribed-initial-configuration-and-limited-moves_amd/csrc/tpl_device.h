@@ -428,25 +428,56 @@ __host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
     return h;
 }
 
-// The decision stream of the carving generators (host and device): decision k of configuration
-// `index` is  fmix32(key_k),  key_k = key_0 + k * 0x9E3779B1  (a running add),  key_0 = the two halves of
-// rng_base(seed, 4, index) folded together, and it is reduced to [lo, hi] as  lo + (((d >> 8) * (hi - lo + 1)) >> 24)
-// -- a 24-bit multiply; the ranges drawn from have at most ten values (a bias below 10 / 2^24), and at most 255 fit.
+// The decision stream of the carving generators (host and device).  A configuration is built by ATTEMPTS (the restart
+// rule below); attempt `a` of configuration `index` owns the 64-bit word  w = rng(seed, 4, index, a)  and its decision k is
+// fmix32(key_k),  key_k = low32(w) + k * stride  (a running add),  stride = high32(w) | 1  -- both halves of the word are
+// used, so two configurations (or two attempts) share a stream only if their 63 bits agree; a stream's period is 2^32
+// decisions.  A decision is reduced to [lo, hi] as  lo + (((d >> 8) * (hi - lo + 1)) >> 24)  -- a 24-bit multiply; the
+// ranges drawn from have at most ten values (a bias below 10 / 2^24), and at most 255 fit.
 // (Through round 2 every decision was a 64-bit splitmix round and a 64-bit multiply-high: some seven quarter-rate
-// multiplies each, three decisions per iteration of the search -- a third of what an iteration cost on the device.)
-constexpr uint32_t kDecisionStep = 0x9E3779B1u;
-__host__ __device__ __forceinline__ uint32_t decision_key(uint64_t seed, uint64_t index) {
-    const uint64_t b = rng_base(seed, 4, index);
-    return (uint32_t)b ^ (uint32_t)(b >> 32);
+// multiplies each, three decisions per iteration of the search; in round 3 the stride was one constant for every stream,
+// so all streams walked one 2^32-cycle from different offsets.)
+struct DecisionStream { uint32_t key, stride; };
+__host__ __device__ __forceinline__ DecisionStream decision_stream(uint64_t seed, uint64_t index, uint32_t attempt) {
+    const uint64_t w = rng(seed, 4, index, attempt);
+    return DecisionStream{(uint32_t)w, (uint32_t)(w >> 32) | 1u};
 }
-__host__ __device__ __forceinline__ int decision(uint32_t& key, int lo, int hi) {
-    const uint32_t d = fmix32(key) >> 8;
-    key += kDecisionStep;
+__host__ __device__ __forceinline__ int decision(DecisionStream& s, int lo, int hi) {
+    const uint32_t d = fmix32(s.key) >> 8;
+    s.key += s.stride;
 #ifdef __HIP_DEVICE_COMPILE__
     return lo + (int)(__umul24(d, (uint32_t)(hi - lo + 1)) >> 24);
 #else
     return lo + (int)((d * (uint32_t)(hi - lo + 1)) >> 24);
 #endif
+}
+
+// The restart rule of the carving generators (build-defined, like the decision stream; the carving logic itself is the
+// reference's, pinned by its decision tapes).  The reference's search (game/tetris.py:234-279) is a Las-Vegas loop with no
+// bound; its length is close to exponentially distributed (mean 1.45 x median, p99 6.5 x median at L = 10:
+// profiles/r04_carve/iteration_histogram.json), so a batch of 2^20 configurations waits for one that takes 14 means.
+// Configuration `index` is therefore DEFINED as the outcome of the first attempt a = 0, 1, ... (each with its own decision
+// stream, each starting from the full stack) that ends within  carve_cutoff(L, cutoff, a)  trips of the while loop.  A
+// cut-off of about twice the median search costs 1-3 % more iterations in total (a memoryless search loses only its
+// warm-up when restarted) and bounds every attempt -- which is what lets the device generator run the attempts of one
+// straggling configuration on many lanes at once and still return exactly this configuration (carve_device.hip).  After
+// kCarveAttempts failed attempts the configuration is reported as capped (all-zero outputs); the cut-off doubles every six
+// attempts, so an (L, M) whose searches are long only pays a logarithmic number of restarts.
+constexpr int kCarveAttempts = 24;
+// iterations allowed to attempt `attempt`: `cutoff` if the caller gave one, else about twice the measured median search
+// length at this L (M = 40; M matters little unless it is close to the fewest pieces that can clear L rows)
+__host__ __device__ __forceinline__ int64_t carve_cutoff(int L, int64_t cutoff, int attempt) {
+    int64_t c = cutoff;
+    if (c <= 0) {                                          // a switch, not a table load: no constant memory on the device side
+        switch (L) {
+            case 1: case 2: case 3: c = 64; break;
+            case 4: c = 128; break;     case 5: c = 256; break;     case 6: c = 384; break;     case 7: c = 512; break;
+            case 8: c = 768; break;     case 9: c = 1792; break;    case 10: c = 3328; break;   case 11: c = 5376; break;
+            case 12: c = 9216; break;   case 13: c = 17408; break;  case 14: c = 36000; break;  case 15: c = 64000; break;
+            default: c = 132000; break;
+        }
+    }
+    return c << (attempt / 6);
 }
 
 // which pool entry the episode of global board `g` = global_offset + i that begins at step `birth` starts from.

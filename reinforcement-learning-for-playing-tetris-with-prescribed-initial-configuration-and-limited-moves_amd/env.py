@@ -202,12 +202,13 @@ class BatchedTetris:
         return first
 
     def carved_configs(self, count: int, seed: Optional[int] = None, first: int = 0, with_solutions: bool = False,
-                       max_iters: int = 0, waves: int = 0):
+                       cutoff: int = 0, waves: int = 0):
         """Carved (solvable) configurations generated ON THE DEVICE (a persistent kernel whose lanes take configurations
         from a queue; `waves` = how many 64-lane waves share it, 0 = automatic) -- the same configurations
         generate_configs(L, M, count, seed, first) builds on the host.  Returns device tensors (rows int16 [count, 20],
-        pieces uint8 [count, M+1]) and, with_solutions, (solution uint8 [count, M, 2], solution_len int32 [count]);
-        raises if a configuration hit the iteration cap."""
+        pieces uint8 [count, M+1]) and, with_solutions, (solution uint8 [count, M, 2], solution_len int32 [count]).
+        `cutoff` overrides the restart rule's iteration cut-off (0 = by L); raises if every attempt of a configuration ran
+        into it (an (L, M) that cannot be carved)."""
         seed = self.seed if seed is None else seed
         d = self.device
         rows = torch.empty((count, 20), dtype=torch.int16, device=d)
@@ -217,11 +218,11 @@ class BatchedTetris:
         status = torch.empty(count, dtype=torch.int32, device=d)
         nbytes = self._lib.tpl_generate_configs_device_work_bytes(self.M, count)
         work = torch.empty(nbytes, dtype=torch.uint8, device=d)
-        check(self._lib.tpl_generate_configs_device_waves(self.L, self.M, seed, first, count, max_iters, int(waves), _ptr(rows),
+        check(self._lib.tpl_generate_configs_device_waves(self.L, self.M, seed, first, count, int(cutoff), int(waves), _ptr(rows),
                                                           _ptr(pieces), _ptr(sol), _ptr(sol_len), _ptr(status), _ptr(work), nbytes,
                                                           self._stream()))
         if bool(status.any()):
-            raise _lib.TplError(f"{int(status.sum())} configuration(s) hit the iteration cap")
+            raise _lib.TplError(f"{int(status.sum())} configuration(s) could not be carved: every attempt ran into its iteration cut-off")
         return (rows, pieces, sol, sol_len) if with_solutions else (rows, pieces)
 
     def synthetic_configs(self, count: int, seed: Optional[int] = None, first: int = 0):

@@ -49,7 +49,10 @@ def concurrent_stream(env):
     key = (env._index, main.cuda_stream)                   # tested against THIS stepping stream
     if key in _CONCURRENT:
         return _CONCURRENT[key]
-    L, M, count = min(env.L, 16), env.M, 64
+    # The probe launch does not depend on the environment: L = 16 with an iteration cut-off of 128 -- no attempt of a
+    # 16-row stack ends that early, so every lane runs its 24 attempts to their cut-offs (6 x 128 x (1 + 2 + 4 + 8) = 11,520
+    # iterations) whatever the seed: about ten milliseconds on one wave, and its output is discarded.
+    L, M, count = 16, 40, 64
     rows = torch.empty((count, 20), dtype=torch.int16, device=d)
     pieces = torch.empty((count, M + 1), dtype=torch.uint8, device=d)
     status = torch.empty(count, dtype=torch.int32, device=d)
@@ -57,27 +60,37 @@ def concurrent_stream(env):
     work = torch.empty(nbytes, dtype=torch.uint8, device=d)
     scratch = torch.empty(4, dtype=torch.int64, device=d)
     torch.cuda.synchronize(d)
-    chosen = None
+    chosen, conclusive = None, 0
     for attempt in range(12):
         cand = torch.cuda.Stream(d)
         busy, quick = torch.cuda.Event(), torch.cuda.Event()
-        # one wave, every lane capped at 4,000 search iterations: several milliseconds, whatever the configurations
-        check(env._lib.tpl_generate_configs_device_waves(L, M, 0x5EED, 0, count, 4000, 1, C.c_void_p(rows.data_ptr()),
+        check(env._lib.tpl_generate_configs_device_waves(L, M, 0x5EED, 0, count, 128, 1, C.c_void_p(rows.data_ptr()),
                                                          C.c_void_p(pieces.data_ptr()), None, None, C.c_void_p(status.data_ptr()),
                                                          C.c_void_p(work.data_ptr()), nbytes, cand.cuda_stream))
         busy.record(cand)
+        pending = not busy.query()                # still running when the quick launch goes out?  else the trial says nothing
         check(env._lib.tpl_get_stats(env._h, C.c_void_p(scratch.data_ptr()), main.cuda_stream))
         quick.record(main)
         quick.synchronize()
         overlapped = not busy.query()             # the stepping stream's launch is done and the generator's is not
         cand.synchronize()
+        if not pending:
+            continue                              # inconclusive: the probe had ended before the comparison began
+        conclusive += 1
         chosen = cand
         if overlapped:
             break
     else:
         import warnings
-        warnings.warn("no stream was seen to run beside the stepping stream: the supply generator will serialise with the steps "
-                      "(a stall of one generator launch per pool swap)")
+        if conclusive:
+            warnings.warn("no stream was seen to run beside the stepping stream: the supply generator will serialise with the "
+                          "steps (a stall of one generator launch per pool swap)")
+        else:
+            warnings.warn("the stream probe was inconclusive (its generator launch ended before it could be compared): "
+                          "using an untested side stream")
+            chosen = torch.cuda.Stream(d)
+            _CONCURRENT.pop(key, None)
+            return chosen                         # not cached: the next refresher tries again
     _CONCURRENT[key] = chosen
     return chosen
 
@@ -102,19 +115,23 @@ class PoolRefresher:
     def __init__(self, env, count: int, seed: int = 0, first: int = 0, waves: int = 0, reserved_cus: int = 0,
                  low_priority: bool = False):
         """waves: how many persistent 64-lane waves share the generator's queue (0 = count / 256): its footprint beside
-        the stepping environment.  Measured at 2^20 boards, L = 10 (profiles/r03_live_supply): 1024 waves supply 1.0 M
-        configurations/s for 6-7 % of the step rate, 256 waves 0.6 M/s for 3-4 %.  (The step kernel raises its waves'
+        the stepping environment.  What a footprint costs and supplies is in bench.py's `live_supply_run`
+        (`by_generator_footprint`; profiles/NOTES.md has the history).  (The step kernel raises its waves'
         issue priority above the generator's; without that any generator wave on a SIMD cost the whole launch 18-29 %.)
         reserved_cus > 0 runs the generator on a CU-masked stream of that many compute units (`tpl_stream_create`),
         low_priority on a lowest-priority stream: both measured 3x SLOWER steps than a plain side stream -- kept as
         options because the review of round 2 asked for the comparison, not because they help."""
         import torch
-        self.env, self.count, self.seed, self.next_first, self.waves = env, int(count), int(seed), int(first), int(waves)
-        self.side = side_stream(env, reserved_cus, low_priority) if (reserved_cus or low_priority) else concurrent_stream(env)
+        self.env, self.count, self.seed, self.next_first = env, int(count), int(seed), int(first)
+        self.waves = int(waves) or max(1, self.count // 256)       # beside a stepping environment: a quarter of the lanes a lone generator takes
+        self._masked = bool(reserved_cus or low_priority)
+        self.side = side_stream(env, reserved_cus, low_priority) if self._masked else concurrent_stream(env)
+        self._stepping = torch.cuda.current_stream(env.device).cuda_stream      # the stream `side` was tested against
         self._ready = None            # event recorded behind the batch being generated
-        self._bad_host = None         # pinned: the batch's count of configurations that hit the iteration cap
+        self._bad_host = None         # pinned: the batch's count of configurations that could not be carved
         self._batch = None
         self.swaps = 0
+        self.capped_batches = 0       # batches dropped because a configuration's attempts all ran into their cut-off
         self.start()
 
     def start(self) -> None:
@@ -151,8 +168,24 @@ class PoolRefresher:
         rows, pieces, _, _, first = self._batch
         bad = int(self._bad_host[0])                               # host memory, written ahead of the event that has fired
         if bad:
-            raise RuntimeError(f"{bad} configuration(s) of the batch at {first} hit the generator's iteration cap")
+            # every attempt of a configuration ran into its cut-off: under the restart rule that means this (L, M) cannot be
+            # carved (for one that can, 24 failures in a row have a probability below 1e-14).  The batch is dropped, the
+            # pool stays as it is, the run goes on; said once.
+            self.capped_batches += 1
+            if self.capped_batches == 1:
+                import warnings
+                warnings.warn(f"{bad} configuration(s) of the batch at {first} could not be carved (L={self.env.L}, M={self.env.M}): "
+                              "batch dropped, the pool is not refreshed")
+            self.start()
+            return False
         main = torch.cuda.current_stream(self.env.device)
+        if main.cuda_stream != self._stepping and not self._masked:
+            # stepping has moved to another stream since the side stream was tested: HIP may have put the two on one hardware
+            # queue (a 30-ms stall per swap).  concurrent_stream() is cached per stepping stream; the batch in flight stays
+            # on the stream it was launched on, the next one goes to the newly tested stream.
+            self.side.synchronize()
+            self.side = concurrent_stream(self.env)
+            self._stepping = main.cuda_stream
         self.side.wait_stream(main)                                # launches that still read the buffer being replaced
         with torch.cuda.stream(self.side):
             self.env.load_configs(rows, pieces, validate=False)    # the generator cannot emit an invalid piece id

@@ -168,7 +168,37 @@ def test_native_generator_argument_errors():
     with pytest.raises(T.TplError):
         T.generate_configs(5, 0, 1)
     with pytest.raises(T.TplError):
-        T.generate_configs(10, 40, 2, max_iters=3)        # cannot finish in three iterations
+        T.generate_configs(10, 40, 2, cutoff=3)           # no attempt can end within 3 << 3 iterations: reported, not hung on
+    with pytest.raises(T.TplError):
+        T.generate_configs(10, 40, 2, cutoff=-1)
+
+
+@pytest.mark.parametrize("L,M,n,cutoff", [(5, 20, 400, 48), (10, 40, 60, 600), (3, 254, 60, 8), (6, 40, 200, 0)])
+def test_restart_rule_host_generator_equals_the_oracle(oracle, L, M, n, cutoff):
+    """The restart rule (csrc/tpl_device.h; restated in oracle/tetris_oracle.c): a configuration is what the first attempt
+    builds that ends within its iteration cut-off.  With a cut-off well below the median search length most configurations
+    need several attempts (and some the doubled cut-off of attempts 6+): host generator == oracle on all of them, every
+    configuration still replays to a win, and the winning attempt is the FIRST that fits (each earlier one, run alone with
+    the oracle's single-search function, does not)."""
+    import tetris_piclim as T
+    rows, pieces, sol, sol_len = T.generate_configs(L, M, n, seed=3, first=100, threads=4, cutoff=cutoff, with_solutions=True)
+    attempts = np.zeros(n, np.int64)
+    for k in range(n):
+        it, r, p, s, a = oracle.generate_config_seeded(L, M, 3, 100 + k, cutoff, with_attempt=True)
+        assert it >= 0 and 0 <= a < 24
+        attempts[k] = a
+        assert np.array_equal(r, rows[k]) and np.array_equal(p, pieces[k]), k
+        assert sol_len[k] == len(s) and np.array_equal(s, sol[k, : sol_len[k]]), k
+        g = oracle.Game(L, M, rows[k], pieces[k])
+        for rot, loc in s:
+            g.move(int(rot), int(loc))
+        assert g.state == 1, k
+    if cutoff:
+        assert (attempts > 0).mean() > 0.3 and attempts.max() >= 6        # restarts happened, some past the first doubling
+    else:
+        assert (attempts > 0).mean() < 0.5                                # the default cut-off: most finish at once
+    assert oracle.carve_attempt_limit(L, cutoff, 0) * 2 == oracle.carve_attempt_limit(L, cutoff, 6)
+    assert oracle.carve_attempt_limit(10, 0, 0) == 3328 and oracle.carve_attempt_limit(10, 0, 23) == 3328 * 8
 
 
 @pytest.mark.gpu
@@ -201,8 +231,55 @@ def test_device_generator_equals_the_oracle_and_the_host_generator(oracle, L, M,
         w_rows, w_pieces, w_sol, w_len = env.carved_configs(m, seed=12, first=5, with_solutions=True, waves=waves)
         assert np.array_equal(w_rows.cpu().numpy().view(np.uint16), rows[:m]) and np.array_equal(w_pieces.cpu().numpy(), pieces[:m])
         assert np.array_equal(w_len.cpu().numpy(), sol_len[:m]) and np.array_equal(w_sol.cpu().numpy(), sol[:m])
+    env.terminate()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,M,n,cutoff,waves", [(5, 20, 6000, 48, 0), (5, 20, 6000, 48, 94), (10, 40, 2000, 600, 0),
+                                                (10, 40, 300, 600, 10 ** 6), (3, 254, 500, 8, 2), (8, 30, 4096, 0, 16)])
+def test_device_generator_under_restarts_equals_the_host_generator(oracle, L, M, n, cutoff, waves):
+    """The device generator runs the attempts of a straggling configuration on SEVERAL lanes at once when the queue is dry
+    and keeps the lowest attempt that fits its cut-off; the host generator (== the oracle, test above) runs them one after
+    the other.  Same configurations, whatever the number of waves -- including a launch with more lanes than
+    configurations, where lanes help from the first moment."""
+    import tetris_piclim as T
+    env = T.BatchedTetris(L, M, 64)
+    rows, pieces, sol, sol_len = T.generate_configs(L, M, n, seed=21, first=7, cutoff=cutoff, with_solutions=True)
+    for rep in range(3):                                    # the schedule differs from launch to launch; the answer must not
+        d_rows, d_pieces, d_sol, d_len = env.carved_configs(n, seed=21, first=7, with_solutions=True, cutoff=cutoff, waves=waves)
+        assert np.array_equal(d_rows.cpu().numpy().view(np.uint16), rows)
+        assert np.array_equal(d_pieces.cpu().numpy(), pieces)
+        assert np.array_equal(d_len.cpu().numpy(), sol_len) and np.array_equal(d_sol.cpu().numpy(), sol)
+    for k in range(0, n, max(1, n // 64)):
+        it, r, p, s = oracle.generate_config_seeded(L, M, 21, 7 + k, cutoff)
+        assert np.array_equal(r, rows[k]) and np.array_equal(p, pieces[k])
+    env.terminate()
+
+
+@pytest.mark.gpu
+def test_device_generator_reports_configurations_that_cannot_be_carved():
+    """Every attempt runs into its cut-off (M = 12 pieces cannot clear 10 rows; a cut-off of 4 keeps it short): status 1
+    and zeroed outputs for those, the launch ends, the others are untouched -- host and device alike."""
+    import torch
+    import tetris_piclim as T
+    env = T.BatchedTetris(10, 12, 64)
     with pytest.raises(T.TplError):
-        env.carved_configs(64, seed=12, max_iters=2)       # the cap is reported, not hung on
+        env.carved_configs(200, seed=1, cutoff=4)
+    with pytest.raises(T.TplError):
+        T.generate_configs(10, 12, 8, seed=1, cutoff=4)
+    env.terminate()
+
+
+@pytest.mark.gpu
+def test_a_large_batch_holds_no_duplicate_configuration():
+    """262,144 configurations at L = 10: with a 63-bit (key, stride) per attempt no two share a decision stream, and two
+    different streams carving the same 100 cells with the same 41 pieces do not happen by chance."""
+    import torch
+    import tetris_piclim as T
+    env = T.BatchedTetris(10, 40, 64)
+    rows, pieces = env.carved_configs(1 << 18, seed=5)
+    both = torch.cat([rows.view(torch.uint8).reshape(1 << 18, -1), pieces], dim=1).cpu().numpy()
+    assert len(np.unique(both, axis=0)) == 1 << 18
     env.terminate()
 
 

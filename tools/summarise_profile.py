@@ -27,7 +27,7 @@ want = sys.argv[2:] or ["tpl::"]
 
 
 def short(name):
-    name = name.split("(")[0]
+    name = name.replace("(anonymous namespace)::", "").split("(")[0]
     return name[5:] if name.startswith("void ") else name
 
 
