@@ -8,7 +8,7 @@
 // encoded shape table (tpl_device.h), so a column's top is one count-trailing-zeros and a carve is one AND per
 // piece column.  Random decisions are counter-based (decision_stream() / decision(), tpl_device.h) and a configuration is
 // the outcome of the first attempt that ends within the cut-off (the restart rule, tpl_device.h) -- independent of the
-// thread count, and the same configuration the device generator and the oracle build.
+// thread count, and the same configuration the device generator builds.
 #include "tpl_internal.h"
 #include "py_random.h"
 
