@@ -122,17 +122,22 @@ def timed(torch, dev, fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-def measure_fused_rollout(torch, T, env, actions, first, K, chunk):
+def measure_fused_rollout(torch, T, env, actions, first, K, chunk, compact=False):
     """tpl_rollout over the same pre-staged actions, `chunk` steps per launch, writing the same
-    per-step reward/done outputs as the step loop."""
+    per-step reward/done outputs as the step loop -- or, `compact`, tpl_rollout_trajectory: one byte per board-step."""
     n, dev = env.num_envs, env.device
     rs = torch.empty((chunk, n), dtype=torch.float32, device=dev)
     ds = torch.empty((chunk, n), dtype=torch.uint8, device=dev)
+    traj = torch.empty(((chunk + 3) // 4, n), dtype=torch.int32, device=dev)
     launches = K // chunk
 
     def run():
         for c in range(launches):
             a = actions[first + c * chunk: first + (c + 1) * chunk]
+            if compact:
+                T._lib.check(env._lib.tpl_rollout_trajectory(env._h, ctypes.c_void_p(a.data_ptr()), a.stride(0), chunk,
+                                                             ctypes.c_void_p(traj.data_ptr()), None, env._stream()))
+                continue
             T._lib.check(env._lib.tpl_rollout(env._h, ctypes.c_void_p(a.data_ptr()), a.stride(0), chunk,
                                               ctypes.c_void_p(rs.data_ptr()), ctypes.c_void_p(ds.data_ptr()), None, None,
                                               env._stream()))
@@ -245,28 +250,41 @@ def measure_out_of_cache(torch, T, dev, L, M, seed, boards=1 << 23, pool=1 << 21
 
 def measure_config_supply(torch, T, dev, L, M, seed):
     """rates of the prescribed-configuration suppliers (side figures).  Carving on the device
-    (one configuration per lane) and on the host cores produce the same configurations; the forward generator +
-    solver is host code."""
+    (a persistent kernel: lanes take configurations from a queue, and once it is dry run further attempts of their wave's
+    stragglers under the restart rule) and on the host cores produce the same configurations; the forward generator +
+    solver is host code.  Device rates by batch size (a launch lasts as long as its slowest wave) and at the reference's
+    own test configuration L = 15, M = 40 (game/main.py:33,50)."""
     import numpy as np
     env = T.BatchedTetris(L, M, 64, device=dev, seed=seed)
-    count = 1 << 20                                              # a pool's worth: the batch is as long as its slowest configuration
-    env.carved_configs(count)                                    # load the kernel, and let torch's allocator keep the buffers
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    rows, _ = env.carved_configs(count)                           # returns after the status check (host sync)
-    dt_dev = time.perf_counter() - t0
+
+    def device_rate(e, count, reps=2):
+        e.carved_configs(count)                                  # load the kernel, and let torch's allocator keep the buffers
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for r in range(reps):
+            rows, _ = e.carved_configs(count, first=(r + 1) * count)     # returns after the status check (host sync)
+        return count * reps / (time.perf_counter() - t0), rows
+    count = 1 << 20                                              # a pool's worth
+    rate_big, _ = device_rate(env, count)
+    rate_small, _ = device_rate(env, 1 << 18)
+    rows = env.carved_configs(1 << 14, first=0)[0]
     host_count = 1 << 14
     t0 = time.perf_counter()
     hrows, _ = T.generate_configs(L, M, host_count, seed=seed)
     dt_host = time.perf_counter() - t0
-    same = bool(np.array_equal(rows[:host_count].cpu().numpy().view(np.uint16), hrows))
+    same = bool(np.array_equal(rows.cpu().numpy().view(np.uint16), hrows))
     env.terminate()
+    ref_env = T.BatchedTetris(15, 40, 64, device=dev, seed=seed)
+    rate_ref, _ = device_rate(ref_env, 1 << 18, reps=1)
+    ref_env.terminate()
     games = 4000
     t0 = time.perf_counter()
     fw = T.forward_generate(5, 20, np.arange(games))
     dt_fw = time.perf_counter() - t0
     return {"unit": "configurations/s", "L": L, "M": M,
-            "carve_device": {"value": count / dt_dev, "count": count},
+            "carve_device": {"value": rate_big, "count": count, "batch_of_262144": rate_small,
+                             "rate_ratio_2^20_over_2^18": rate_big / rate_small,
+                             "L15_M40_batch_of_262144": rate_ref},
             "carve_host": {"value": host_count / dt_host, "count": host_count, "threads": T._lib.cpu_budget(),
                            "equal_to_device_output": same},
             "forward_generator_solver_host": {"value": games / dt_fw, "games": games, "L": 5, "M": 20,
@@ -631,8 +649,8 @@ def main():
     # ---- side figures on the main boards (after the timed region)
     fused = None
     if args.chunk > 0:
-        if S < 2 * args.chunk:                                    # the fused form wants whole chunks of distinct steps
-            S = 2 * args.chunk
+        if S < max(2 * args.chunk, 200):                          # the fused form wants whole chunks of distinct steps
+            S = max(2 * args.chunk, 200)
             actions = torch.empty((S, n), dtype=torch.uint8, device=dev)
             for t in range(S):
                 env.synthetic_actions(t, out=actions[t])
@@ -640,6 +658,17 @@ def main():
         ms = max_over_ranks(measure_fused_rollout(torch, T, env, actions, 0, S // args.chunk * args.chunk, args.chunk))
         fused = {"value": float(total) / (ms * 1e-3), "unit": "env-steps/s", "steps_per_launch": args.chunk,
                  "ms_per_step": ms, "outputs": "per-step reward f32 + done u8 written", "kernel": "rollout_kernel<auto_reset>"}
+        # the same steps recorded as the compact trajectory (one byte per board-step, decoded on the learner's side)
+        ms_c = max_over_ranks(measure_fused_rollout(torch, T, env, actions, 0, S // args.chunk * args.chunk, args.chunk, compact=True))
+        fused["compact_trajectory"] = {"value": float(total) / (ms_c * 1e-3), "ms_per_step": ms_c, "steps_per_launch": args.chunk,
+                                       "outputs": "one byte per board-step (rows cleared, how the move ended, reset, frozen), "
+                                                  "a dword per board every fourth step; tpl_decode_trajectory -> reward f32, done u8"}
+        # ... and with 200 steps per launch (a launch's fixed part -- the 64 B per board of state in and out, the launch gap --
+        # is some 20 us: a quarter of a 50-step launch's step time, a fifteenth of a 200-step one's)
+        ms_c200 = max_over_ranks(measure_fused_rollout(torch, T, env, actions, 0, 200, 200, compact=True))
+        ms_o200 = max_over_ranks(measure_fused_rollout(torch, T, env, actions, 0, 200, 200))
+        fused["at_200_steps_per_launch"] = {"compact_trajectory": float(total) / (ms_c200 * 1e-3),
+                                            "reward_f32_and_done_u8": float(total) / (ms_o200 * 1e-3)}
         # the same kernel under the uniform random policy drawn on the device (no actions staged, no per-step outputs)
         env.rollout_random(100, seed=args.seed)
         torch.cuda.synchronize(dev)

@@ -162,6 +162,22 @@ int tpl_rollout(tpl_env* env, const uint8_t* actions, int64_t action_stride, int
 int tpl_rollout_random(tpl_env* env, uint64_t seed, uint32_t step0, int32_t num_steps, uint8_t* actions_out,
                        float* reward_steps, uint8_t* done_steps, float* reward_sum, uint32_t* finished, void* stream);
 
+/* tpl_rollout / tpl_rollout_random with the COMPACT TRAJECTORY as the per-step output -- the loop of
+ * game/performance_test.py:13-17 recorded for a learner at one byte per board-step instead of a float and a byte (which
+ * cost the fused kernel a quarter of its rate).  trajectory u32[(num_steps + 3) / 4][n] (device): byte j of word w of
+ * board i is step 4 w + j:  bits 0-2 rows cleared by the move (game/tetris.py:382-386), bits 3-4 how it ended (0 the game
+ * goes on, 1 won :415-417, 2 lost at the move limit :391,419-421, 3 topped out :372-374), bit 5 the board was
+ * re-initialised from the pool in this step (auto_reset), bit 6 the board was frozen (finished earlier, no auto_reset: no
+ * move made).  Bytes past num_steps in the last word are zero.  Same moves, same statistics, same final state as
+ * tpl_rollout.  tpl_decode_trajectory turns a trajectory into reward_steps f32[num_steps][n] / done_steps
+ * u8[num_steps][n] (either may be NULL) with the handle's reward parameters -- bit for bit what tpl_rollout writes. */
+int tpl_rollout_trajectory(tpl_env* env, const uint8_t* actions, int64_t action_stride, int32_t num_steps,
+                           uint32_t* trajectory, uint32_t* finished, void* stream);
+int tpl_rollout_random_trajectory(tpl_env* env, uint64_t seed, uint32_t step0, int32_t num_steps, uint8_t* actions_out,
+                                  uint32_t* trajectory, uint32_t* finished, void* stream);
+int tpl_decode_trajectory(tpl_env* env, const uint32_t* trajectory, int32_t num_steps, float* reward_steps,
+                          uint8_t* done_steps, void* stream);
+
 /* Replaces Tetris.get_state() (game/tetris.py:435-436) and the public attributes, batched and in the
  * interchange layout.  Any output may be NULL.  rows [n][20] u16; cur/nxt u8[n] (7 = no such piece);
  * lines/moves u8[n] (lines_cleared, moves_used -- L_rem = L - lines, M_rem = M - moves); state u8[n];

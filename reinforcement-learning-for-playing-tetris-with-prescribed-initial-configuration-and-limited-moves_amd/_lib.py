@@ -37,7 +37,7 @@ SYMBOLS = [
     "tpl_last_error", "tpl_version", "tpl_workspace_bytes", "tpl_pool_bytes", "tpl_create", "tpl_destroy",
     "tpl_set_options", "tpl_load_configs", "tpl_reset", "tpl_move", "tpl_step", "tpl_step_observe", "tpl_get_state",
     "tpl_expand_obs", "tpl_expand_states", "tpl_get_board", "tpl_carve", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
-    "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_rollout_random", "tpl_decode_actions", "tpl_generate_configs", "tpl_generate_configs_pyseed", "tpl_forward_generate",
+    "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_rollout_random", "tpl_rollout_trajectory", "tpl_rollout_random_trajectory", "tpl_decode_trajectory", "tpl_decode_actions", "tpl_generate_configs", "tpl_generate_configs_pyseed", "tpl_forward_generate",
     "tpl_generate_configs_device_work_bytes", "tpl_generate_configs_device", "tpl_generate_configs_device_waves",
     "tpl_policy_image_bytes", "tpl_policy_pack", "tpl_policy_act",
     "tpl_policy_image_bytes_f32", "tpl_policy_pack_f32", "tpl_policy_act_f32",
@@ -140,6 +140,9 @@ def lib() -> C.CDLL:
     L.tpl_step_observe.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp]
     L.tpl_rollout.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, vp]
     L.tpl_rollout_random.argtypes = [vp, u64, C.c_uint32, i32, vp, vp, vp, vp, vp, vp]
+    L.tpl_rollout_trajectory.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    L.tpl_rollout_random_trajectory.argtypes = [vp, u64, C.c_uint32, i32, vp, vp, vp, vp]
+    L.tpl_decode_trajectory.argtypes = [vp, vp, i32, vp, vp, vp]
     L.tpl_get_state.argtypes = [vp] * 9
     L.tpl_expand_obs.argtypes = [vp, vp, i32, vp]
     L.tpl_expand_states.argtypes = [vp, vp, vp, i64, vp, i32, vp]

@@ -314,9 +314,14 @@ struct RolloutArgs {
     uint8_t* done_steps;        // [K][n] or null
     float* reward_sum;          // [n] or null: sum over the K steps, accumulated in step order
     uint32_t* finished;         // [n] or null: episodes this board finished during the K steps
+    uint32_t* trajectory;       // compact form only: [ceil(K / 4)][n], byte j of word w = the step 4 w + j (tpl_step.h)
 };
 
-template <bool kAutoReset, bool kRandom>
+// kCompact: the per-step outputs are ONE byte per board-step (what happened, not what it was worth: trajectory_code in
+// tpl_step.h), gathered in a register and written as one dword per lane every fourth step -- against a float and a byte
+// per step, which cost the kernel a quarter of its rate (two stores, the reward's arithmetic and a running sum in every
+// wave-step of a loop that is bound by instruction issue).  No reward is computed in this form at all.
+template <bool kAutoReset, bool kRandom, bool kCompact>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
     const StepArgs& p = q.s;
     __shared__ ShapeWord s_shape[32];
@@ -362,7 +367,9 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
         uint8_t* act_out_row = q.actions_out + block_first;
         float* reward_row = q.reward_steps + block_first;
         uint8_t* done_row = q.done_steps + block_first;
-        const bool want_reward = q.reward_steps != nullptr, want_done = q.done_steps != nullptr;   // wave-uniform
+        const bool want_reward = !kCompact && q.reward_steps != nullptr, want_done = !kCompact && q.done_steps != nullptr;   // wave-uniform
+        uint32_t* traj_row = q.trajectory + block_first;
+        uint32_t traj_word = 0;
         // The first action must have ARRIVED before the loop is entered.  Otherwise its register is "possibly still
         // being loaded" at the loop header on one of the two ways in, and the compiler puts a full memory wait at
         // the top of every iteration -- right behind the requests (next action, window word) that iteration has
@@ -375,10 +382,15 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
         float reward_prev = 0.0f;
         bool done_prev = false;
         for (uint32_t k = 0; k < q.K; ++k) {
-            if (k > 0) {
+            if (!kCompact && k > 0) {
                 // (non-temporal: a trajectory is written once and consumed later, by someone else)
                 if (want_reward) { __builtin_nontemporal_store(reward_prev, reward_row + in_block); reward_row += p.n; }
                 if (want_done) { __builtin_nontemporal_store((uint8_t)(done_prev ? 1 : 0), done_row + in_block); done_row += p.n; }
+            }
+            if (kCompact && k > 0 && (k & 3u) == 0u) {                      // steps k-4 .. k-1 (a wave-uniform test)
+                __builtin_nontemporal_store(traj_word, traj_row + in_block);
+                traj_row += p.n;
+                traj_word = 0;
             }
             // next step's action is independent of the board: fetch it under this step's move
             uint32_t act_next = 0;
@@ -396,21 +408,26 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const RolloutArgs q) {
             uint32_t rot, loc;
             split_small_action(act, rot, loc);
             float reward;
+            uint32_t code;
             const bool done = advance_board_lds<kAutoReset>(s, cols, next_word, until_refill, rot, loc, p, (uint32_t)i, clock + k,
-                                                            s_shape, reward, tally);
-            rsum = rsum + reward;
-            reward_prev = reward;
-            done_prev = done;
+                                                            s_shape, reward, code, tally);
+            if (kCompact) traj_word |= code << (8u * (k & 3u));              // the shift is wave-uniform
+            else {
+                rsum = rsum + reward;
+                reward_prev = reward;
+                done_prev = done;
+            }
             act = act_next;
         }
         if (want_reward) __builtin_nontemporal_store(reward_prev, reward_row + in_block);
         if (want_done) __builtin_nontemporal_store((uint8_t)(done_prev ? 1 : 0), done_row + in_block);
+        if (kCompact) __builtin_nontemporal_store(traj_word, traj_row + in_block);      // the last word, whole or not
         lds_load_cols(cols, s.c);
         pack_board<true>(s, A, B);
         p.plane_a[i] = A;
         p.plane_b[i] = B;
         if ((threadIdx.x & (kClockGroup - 1)) == 0) p.clock[i >> kClockShift] = clock + q.K;
-        if (q.reward_sum) q.reward_sum[i] = rsum;
+        if (!kCompact && q.reward_sum) q.reward_sum[i] = rsum;
         if (q.finished) q.finished[i] = tally.episodes;
     }
     flush_tally(tally, s_stat, p.stats);
@@ -699,11 +716,35 @@ static int launch_step(tpl_env* e, const void* act0, const void* act1, int32_t d
     return TPL_OK;
 }
 
-template <bool kRandom>
+template <bool kRandom, bool kCompact = false>
 static void launch_rollout(const tpl_env* e, const RolloutArgs& q, hipStream_t stream) {
     const dim3 grid(blocks_for(e->n)), block(kBlock);
-    if (e->auto_reset) hipLaunchKernelGGL((rollout_kernel<true, kRandom>), grid, block, 0, stream, q);
-    else hipLaunchKernelGGL((rollout_kernel<false, kRandom>), grid, block, 0, stream, q);
+    if (e->auto_reset) hipLaunchKernelGGL((rollout_kernel<true, kRandom, kCompact>), grid, block, 0, stream, q);
+    else hipLaunchKernelGGL((rollout_kernel<false, kRandom, kCompact>), grid, block, 0, stream, q);
+}
+
+// the learner's side of the compact trajectory: byte -> (reward, done), the arithmetic of step_reward (one rounded multiply,
+// at most one rounded add)
+__global__ __launch_bounds__(kBlock) void decode_trajectory_kernel(const uint32_t* trajectory, int64_t n, uint32_t K, float r_line,
+                                                                  float r_win, float r_lose, float* reward_steps,
+                                                                  uint8_t* done_steps) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t words = (K + 3u) / 4u;
+    for (uint32_t w = 0; w < words; ++w) {
+        const uint32_t word = trajectory[(int64_t)w * n + i];
+        for (uint32_t j = 0; j < 4u && 4u * w + j < K; ++j) {
+            const uint32_t code = (word >> (8u * j)) & 0xFFu, end = (code >> 3) & 3u;
+            const bool frozen = (code & kTrajFrozen) != 0u;
+            float reward = r_line * (float)(code & 7u);
+            if (end == 1u) reward = reward + r_win;
+            if (end >= 2u) reward = reward + r_lose;
+            const int64_t at = (int64_t)(4u * w + j) * n + i;
+            if (reward_steps) reward_steps[at] = frozen ? 0.0f : reward;
+            if (done_steps) done_steps[at] = (uint8_t)((frozen || end != 0u) ? 1 : 0);
+        }
+    }
 }
 
 // The resets of the multi-step kernel read the current pool's side records: written once per pool, on first use (a
@@ -1023,6 +1064,56 @@ int tpl_rollout_random(tpl_env* e, uint64_t seed, uint32_t step0, int32_t num_st
     launch_rollout<true>(e, q, (hipStream_t)stream);
     TPL_HIP(hipGetLastError());
     count_steps(e, num_steps);
+    return TPL_OK;
+}
+
+int tpl_rollout_trajectory(tpl_env* e, const uint8_t* actions, int64_t action_stride, int32_t num_steps, uint32_t* trajectory,
+                           uint32_t* finished, void* stream) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!actions || !trajectory) return fail_msg(TPL_ERR_ARG, "actions / trajectory is null");
+    if (num_steps < 1) return fail_msg(TPL_ERR_ARG, "num_steps must be >= 1");
+    if (action_stride < e->n) return fail_msg(TPL_ERR_ARG, "action_stride %lld is smaller than num_envs", (long long)action_stride);
+    if (int rc = check_can_advance(e)) return rc;
+    DeviceGuard guard(e->device);
+    if (int rc = ensure_side_records(e, (hipStream_t)stream)) return rc;
+    RolloutArgs q{};
+    q.s = make_args(e);
+    q.actions = actions; q.action_stride = action_stride; q.K = (uint32_t)num_steps;
+    q.trajectory = trajectory; q.finished = finished;
+    launch_rollout<false, true>(e, q, (hipStream_t)stream);
+    TPL_HIP(hipGetLastError());
+    count_steps(e, num_steps);
+    return TPL_OK;
+}
+
+int tpl_rollout_random_trajectory(tpl_env* e, uint64_t seed, uint32_t step0, int32_t num_steps, uint8_t* actions_out,
+                                  uint32_t* trajectory, uint32_t* finished, void* stream) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!trajectory) return fail_msg(TPL_ERR_ARG, "trajectory is null");
+    if (num_steps < 1) return fail_msg(TPL_ERR_ARG, "num_steps must be >= 1");
+    if (int rc = check_can_advance(e)) return rc;
+    DeviceGuard guard(e->device);
+    if (int rc = ensure_side_records(e, (hipStream_t)stream)) return rc;
+    RolloutArgs q{};
+    q.s = make_args(e);
+    q.K = (uint32_t)num_steps;
+    q.random_seed = seed; q.step0 = step0; q.actions_out = actions_out;
+    q.trajectory = trajectory; q.finished = finished;
+    launch_rollout<true, true>(e, q, (hipStream_t)stream);
+    TPL_HIP(hipGetLastError());
+    count_steps(e, num_steps);
+    return TPL_OK;
+}
+
+int tpl_decode_trajectory(tpl_env* e, const uint32_t* trajectory, int32_t num_steps, float* reward_steps, uint8_t* done_steps,
+                          void* stream) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!trajectory) return fail_msg(TPL_ERR_ARG, "trajectory is null");
+    if (num_steps < 1) return fail_msg(TPL_ERR_ARG, "num_steps must be >= 1");
+    DeviceGuard guard(e->device);
+    hipLaunchKernelGGL(decode_trajectory_kernel, dim3(blocks_for(e->n)), dim3(kBlock), 0, (hipStream_t)stream, trajectory, e->n,
+                       (uint32_t)num_steps, e->r_line, e->r_win, e->r_lose, reward_steps, done_steps);
+    TPL_HIP(hipGetLastError());
     return TPL_OK;
 }
 

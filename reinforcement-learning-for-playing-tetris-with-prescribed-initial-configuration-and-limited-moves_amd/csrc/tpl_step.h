@@ -208,12 +208,21 @@ __device__ __forceinline__ bool advance_board(Board& s, uint32_t& cfg, uint32_t 
 //   * `until_refill` counts the moves left before the piece window runs out and `next_word` points at the piece word
 //     that will replace it: the test on the way in is one compare, the refill one load and one add;
 //   * the reward's conditional add happens where only the finished boards are active: one select between the two
-//     constants and one add (a finished board has won or lost, never both: the same single rounded add as step_reward).
+//     constants and one add (a finished board has won or lost, never both: the same single rounded add as step_reward);
+//   * `code` is the step's trajectory byte (trajectory_code below); a caller that uses only one of `reward` / `code` does not
+//     pay for the other (the function is inlined, the unused one's arithmetic is dropped).
+// The compact trajectory: what happened to a board in one step, in one byte -- rows cleared (bits 0-2), how the move ended
+// (bits 3-4: 0 the game goes on, 1 won, 2 lost at the move limit, 3 topped out), whether the board was re-initialised from
+// the pool in this step (bit 5), whether it was frozen, i.e. had finished earlier and is not auto-reset (bit 6: no move was
+// made, reward 0, done).  reward and done follow from it and the handle's reward parameters (decode_trajectory_kernel).
+constexpr uint32_t kTrajWon = 1u << 3, kTrajLimit = 2u << 3, kTrajTopout = 3u << 3, kTrajReset = 1u << 5, kTrajFrozen = 1u << 6;
+
 template <bool kAutoReset>
 __device__ __forceinline__ bool advance_board_lds(Board& s, uint32_t* cols, const uint8_t*& next_word, uint32_t& until_refill,
                                                   uint32_t rot, uint32_t loc, const StepArgs& p, uint32_t i, uint64_t clock,
-                                                  const ShapeWord* shape, float& reward, RareTally& tally) {
+                                                  const ShapeWord* shape, float& reward, uint32_t& code, RareTally& tally) {
     reward = 0.0f;
+    code = kTrajFrozen;
     if (s.state != ST_RUNNING) return true;      // frozen
     // pieces.pop(0) (:356) moves the cursor on by one whatever the move does; when it reaches a multiple of ten the
     // window is down to its last two entries and the next piece word replaces it
@@ -247,6 +256,7 @@ __device__ __forceinline__ bool advance_board_lds(Board& s, uint32_t* cols, cons
     if (!kAutoReset) s.state = end.topout ? ST_LOST_TOPOUT : end.won ? ST_WON : end.limit ? ST_LOST_LIMIT : ST_RUNNING;
     const float base_reward = p.r_line * (float)n_clear;
     reward = base_reward;
+    code = n_clear;
     if (done) {
 #pragma clang fp contract(off)
         tally.episodes += 1u;
@@ -255,13 +265,16 @@ __device__ __forceinline__ bool advance_board_lds(Board& s, uint32_t* cols, cons
         // under branches that a wave skips (on its lane mask) when none of its boards finished that way.  The empty asm
         // statements keep them branches: turned into selects they would cost every wave-step two instructions each.
         reward = base_reward + p.r_lose;
+        code = n_clear + (kTrajTopout | (kAutoReset ? kTrajReset : 0u));
         if (end.won) {
             asm volatile("");
             reward = base_reward + p.r_win;
+            code = n_clear + (kTrajWon | (kAutoReset ? kTrajReset : 0u));
             tally.wins += 1u;
         }
         if (end.limit) {
             asm volatile("");
+            code = n_clear + (kTrajLimit | (kAutoReset ? kTrajReset : 0u));
             tally.limits += 1u;
         }
         if (kAutoReset) {

@@ -371,6 +371,43 @@ class BatchedTetris:
                                     self._stream()))
         return (rsum, fin, rs, ds.view(torch.bool)) if per_step else (rsum, fin)
 
+    def rollout_trajectory(self, actions: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """rollout() recording the COMPACT TRAJECTORY: one byte per board-step -- rows cleared (bits 0-2), how the move ended
+        (bits 3-4: 0 goes on, 1 won, 2 lost at the move limit, 3 topped out), re-initialised from the pool (bit 5), frozen
+        (bit 6) -- as int32 words [ceil(K / 4), N], byte j of word w = step 4 w + j.  decode_trajectory() gives the
+        (reward, done) of rollout(per_step=True), bit for bit."""
+        if actions.dtype != torch.uint8 or actions.dim() != 2 or actions.shape[1] != self.num_envs or actions.stride(1) != 1 \
+                or actions.device != self.device:
+            raise ValueError(f"actions must be uint8 [K, {self.num_envs}] on {self.device} with unit inner stride")
+        K = actions.shape[0]
+        if out is None:
+            out = torch.empty(((K + 3) // 4, self.num_envs), dtype=torch.int32, device=self.device)
+        self._own(out, torch.int32, "out", ((K + 3) // 4, self.num_envs))
+        check(self._lib.tpl_rollout_trajectory(self._h, _ptr(actions), actions.stride(0), K, _ptr(out), None, self._stream()))
+        return out
+
+    def rollout_random_trajectory(self, steps: int, seed: int = 0, step0: int = 0, out: Optional[torch.Tensor] = None,
+                                  actions_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """rollout_random() recording the compact trajectory (and, into `actions_out` uint8 [steps, N], what was played)."""
+        if steps < 1:
+            raise ValueError("steps must be positive")
+        if out is None:
+            out = torch.empty(((steps + 3) // 4, self.num_envs), dtype=torch.int32, device=self.device)
+        self._own(out, torch.int32, "out", ((steps + 3) // 4, self.num_envs))
+        if actions_out is not None:
+            self._own(actions_out, torch.uint8, "actions_out", (steps, self.num_envs))
+        check(self._lib.tpl_rollout_random_trajectory(self._h, int(seed), int(step0), int(steps), _ptr(actions_out), _ptr(out), None,
+                                                      self._stream()))
+        return out
+
+    def decode_trajectory(self, trajectory: torch.Tensor, steps: int):
+        """(reward f32 [steps, N], done bool [steps, N]) of a compact trajectory, under this environment's reward parameters."""
+        self._own(trajectory, torch.int32, "trajectory", ((steps + 3) // 4, self.num_envs))
+        rs = torch.empty((steps, self.num_envs), dtype=torch.float32, device=self.device)
+        ds = torch.empty((steps, self.num_envs), dtype=torch.uint8, device=self.device)
+        check(self._lib.tpl_decode_trajectory(self._h, _ptr(trajectory), int(steps), _ptr(rs), _ptr(ds), self._stream()))
+        return rs, ds.view(torch.bool)
+
     def rollout_into(self, actions: torch.Tensor, K: int) -> None:
         """rollout() without outputs (statistics only): the throughput form used by bench.py."""
         if (actions.dtype != torch.uint8 or actions.dim() != 2 or actions.shape[1] != self.num_envs or actions.stride(1) != 1

@@ -531,6 +531,81 @@ def test_compat_tetris_pool_walk_freeze_and_forward_supplier(T):
     game.terminate()
 
 
+@pytest.mark.parametrize("auto,n,L,M,K", [(True, 10007, 5, 20, 57), (False, 4133, 3, 12, 30), (True, 65536, 5, 20, 43),
+                                          (True, 1 << 20, 10, 40, 10), (True, 777, 4, 9, 1), (True, 777, 4, 9, 4)])
+def test_compact_trajectory_decodes_to_the_per_step_outputs_and_the_oracle(T, oracle, auto, n, L, M, K):
+    """tpl_rollout_trajectory writes ONE byte per board-step (rows cleared | how the move ended | reset | frozen) as a dword
+    per lane every fourth step; tpl_decode_trajectory must give back, bit for bit, the reward f32 / done u8 that tpl_rollout
+    writes for the same steps (a reward with two roundings: per_line 0.1, lose -0.7) and that the oracle computes; the boards,
+    counters and statistics after the launch are tpl_rollout's; the bytes themselves say what the oracle saw happen."""
+    import torch
+    seed, reward = 23, (0.1, 1.5, -0.7)
+    envs = [T.BatchedTetris(L, M, n, seed=seed, auto_reset=auto, reward=reward) for _ in range(2)]
+    rows, pieces = envs[0].synthetic_configs(min(n, 5000))
+    for e in envs:
+        e.load_configs(rows, pieces)
+        e.reset()
+    actions = torch.stack([envs[0].synthetic_actions(t) for t in range(K)])
+    _, _, rs, ds = envs[0].rollout(actions, per_step=True)
+    traj = envs[1].rollout_trajectory(actions)
+    assert traj.shape == ((K + 3) // 4, n) and traj.dtype == torch.int32
+    rs2, ds2 = envs[1].decode_trajectory(traj, K)
+    assert torch.equal(rs.view(torch.int32), rs2.view(torch.int32)) and torch.equal(ds, ds2)
+    _assert_state_equal(_state(envs[1]), _state(envs[0]), "after the launch")
+    assert envs[0].stats() == envs[1].stats()
+    codes = _np(traj).view(np.uint8).reshape((K + 3) // 4, n, 4).transpose(0, 2, 1).reshape(-1, n)   # [step, board]
+    assert not codes[K:].any()                                  # bytes past the last step are zero
+    codes = codes[:K]
+    ended, cleared, was_reset, frozen = (codes >> 3) & 3, codes & 7, (codes >> 5) & 1, (codes >> 6) & 1
+    assert cleared.max() <= 4 and not (codes >> 7).any()
+    assert np.array_equal((ended != 0) | (frozen != 0), _np(ds))
+    assert np.array_equal(was_reset.astype(bool), (ended != 0) if auto else np.zeros_like(ended, bool))
+    if auto:
+        assert not frozen.any()
+    if n <= 70000:                                              # the oracle, step by step: what happened, not just what it was worth
+        cpu = oracle.Env(n, L, M, 0, seed)
+        cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
+        cpu.set_options(auto_reset=auto, assign_mode=0, per_line=reward[0], win=reward[1], lose=reward[2])
+        cpu.reset()
+        for t in range(K):
+            before = cpu.get_state()
+            r_c, d_c = cpu.step(_np(actions[t]))
+            assert np.array_equal(_np(rs2[t]), r_c) and np.array_equal(_np(ds2[t]).astype(np.uint8), d_c), t
+            assert np.array_equal(frozen[t].astype(bool), before["state"] != 0), t
+            if not auto:
+                after = cpu.get_state()
+                live = before["state"] == 0
+                assert np.array_equal(cleared[t][live], (after["lines"] - before["lines"])[live]), t
+                won, lost = after["state"] == 1, after["state"] == 2
+                assert np.array_equal(ended[t][live] == 1, won[live]) and np.array_equal(ended[t][live] >= 2, lost[live]), t
+    for e in envs:
+        e.terminate()
+
+
+def test_compact_trajectory_of_the_device_drawn_policy(T):
+    """tpl_rollout_random_trajectory == tpl_rollout_random: the same actions are played and recorded, the trajectory decodes
+    to the same per-step rewards and dones, a second launch continues the first (step0)."""
+    import torch
+    L, M, n, K = 6, 25, 9001, 41
+    envs = [T.BatchedTetris(L, M, n, seed=19, auto_reset=True, reward=(1.0, 2.0, -1.0)) for _ in range(2)]
+    rows, pieces = envs[0].synthetic_configs(2000)
+    for e in envs:
+        e.load_configs(rows, pieces)
+        e.reset()
+    for step0, steps in ((0, 17), (17, K - 17)):
+        _, _, acts, rs, ds = envs[0].rollout_random(steps, seed=5, step0=step0, record=True)
+        acts2 = torch.empty((steps, n), dtype=torch.uint8, device=envs[1].device)
+        traj = envs[1].rollout_random_trajectory(steps, seed=5, step0=step0, actions_out=acts2)
+        rs2, ds2 = envs[1].decode_trajectory(traj, steps)
+        assert torch.equal(acts, acts2) and torch.equal(rs, rs2) and torch.equal(ds, ds2)
+    _assert_state_equal(_state(envs[1]), _state(envs[0]))
+    assert envs[0].stats() == envs[1].stats()
+    with pytest.raises(ValueError):
+        envs[0].decode_trajectory(traj[:, :-1].contiguous(), steps)
+    for e in envs:
+        e.terminate()
+
+
 @pytest.mark.parametrize("auto", [True, False])
 def test_rollout_random_equals_explore_then_step_and_the_oracle(T, oracle, auto):
     """tpl_rollout_random (the uniform random policy drawn on the device, K steps per launch) == K x (tpl_explore_actions at

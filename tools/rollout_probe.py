@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A few fused-rollout launches at the bench size, for counting under rocprofv3 (--pmc) or timing:
-    python tools/rollout_probe.py [--steps-per-launch 100] [--launches 12] [--outputs 0|1]"""
+    python tools/rollout_probe.py [--steps-per-launch 100] [--launches 12] [--outputs 0|1|2]
+(outputs: 0 none, 1 reward f32 + done u8 per step, 2 the compact trajectory: one byte per board-step)"""
 import argparse
 import os
 import sys
@@ -30,9 +31,16 @@ def main():
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
+    traj = torch.empty(((K + 3) // 4, n), dtype=torch.int32, device=env.device)
+    rs = torch.empty((K, n), dtype=torch.float32, device=env.device)
+    ds = torch.empty((K, n), dtype=torch.uint8, device=env.device)
+    import ctypes
     for _ in range(args.launches):
-        if args.outputs:
-            env.rollout(actions, per_step=True)
+        if args.outputs == 2:
+            env.rollout_trajectory(actions, out=traj)
+        elif args.outputs:
+            T._lib.check(env._lib.tpl_rollout(env._h, ctypes.c_void_p(actions.data_ptr()), actions.stride(0), K,
+                                              ctypes.c_void_p(rs.data_ptr()), ctypes.c_void_p(ds.data_ptr()), None, None, env._stream()))
         else:
             env.rollout_into(actions, K)
     e1.record()
