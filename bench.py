@@ -359,6 +359,8 @@ def measure_actor_loop(torch, T, dev, L, M, boards, seed):
     out = {"boards": boards, "unit": "env-steps/s", "policy": "MLP 217-128-128-128-128-14, greedy, random init",
            "arithmetic": {"value": "bf16 operands, f32 accumulation (megakernel)", "fused_mfma_kernel": "bf16 operands, f32 accumulation",
                           "fused_f32_kernel": "float32 operands and accumulation: the reference's nn.Linear width (model/model.py:9-20)",
+                          "f32_megakernel": "float32 operands and accumulation (v_mfma_f32_16x16x4_f32), T steps per launch",
+                          "megakernel": "bf16 operands, f32 accumulation, T steps per launch",
                           "torch_linear_layers": "torch bf16 Linear layers (hipBLASLt)",
                           "torch_linear_layers_f32": "torch float32 Linear layers (hipBLASLt)"}}
     for name, use_fused, dtype in (("fused_mfma_kernel", True, torch.bfloat16), ("fused_f32_kernel", True, torch.float32),
@@ -380,6 +382,14 @@ def measure_actor_loop(torch, T, dev, L, M, boards, seed):
     out["megakernel"] = {"value": boards / (ms * 1e-3), "ms_per_step": ms, "steps_per_launch": iters,
                          "outputs": "per-step action u8 + reward f32 + done u8 written"}
     out["value"] = out["megakernel"]["value"]
+    # the same loop at the reference's arithmetic width: float32 operands and accumulation, T iterations per launch
+    image32m = T.actor.policy_image(T.PolicyMLP(), dev, f32=True)
+    iters32 = 10
+    env.actor_rollout(image32m, iters32)
+    torch.cuda.synchronize(dev)
+    ms = timed(torch, dev, lambda: env.actor_rollout(image32m, iters32), 3) / iters32
+    out["f32_megakernel"] = {"value": boards / (ms * 1e-3), "ms_per_step": ms, "steps_per_launch": iters32,
+                             "outputs": "per-step action u8 + reward f32 + done u8 written"}
     # the policy kernel alone against the dense bf16 MFMA peak: FLOPs it issues per board (K padded to 224, the
     # 14-row head run as one 16-row tile) over its own duration
     act = torch.empty(boards, dtype=torch.uint8, device=dev)

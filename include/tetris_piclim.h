@@ -238,6 +238,12 @@ int tpl_explore_actions(tpl_env* env, uint8_t* action, float epsilon, uint64_t s
  * resident state of every board BEFORE step t (a 32-byte observation for a replay buffer; layout in DESIGN.md). */
 int tpl_actor_rollout(tpl_env* env, const void* image, int32_t num_steps, float epsilon, uint64_t seed, uint32_t step0,
                       uint8_t* actions, float* rewards, uint8_t* dones, void* states_a, void* states_b, void* stream);
+/* tpl_actor_rollout for a float32 image (tpl_policy_pack_f32): num_steps iterations of (tpl_policy_act_f32,
+ * tpl_explore_actions(step0 + t), tpl_step) in ONE launch -- the reference's nn.Linear arithmetic width
+ * (model/model.py:9-20) as a multi-step loop: the boards stay in registers, the float32 weights (twice a CU's LDS) stream
+ * through it once per step.  Same outputs, same results as the step-by-step calls. */
+int tpl_actor_rollout_f32(tpl_env* env, const void* image, int32_t num_steps, float epsilon, uint64_t seed, uint32_t step0,
+                          uint8_t* actions, float* rewards, uint8_t* dones, void* states_a, void* states_b, void* stream);
 
 /* Statistics over episodes finished since the last full reset, reduced on the device into
  * out[4] (device pointer, uint64): {episodes, sum of lines_cleared at finish, wins, top-outs}. */

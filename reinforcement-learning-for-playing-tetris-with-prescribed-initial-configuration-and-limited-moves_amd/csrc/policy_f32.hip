@@ -21,6 +21,7 @@
 // made from the board's bits): k-step q takes internal feature 4q + g.
 #include "tpl_internal.h"
 #include "tpl_policy.h"
+#include "tpl_step.h"
 
 #include <cstring>
 #include <vector>
@@ -104,10 +105,16 @@ __device__ __forceinline__ void start_chunk(uint4* dst, const uint4* src, int by
     typedef __attribute__((address_space(1))) const void global_ptr;
     typedef __attribute__((address_space(3))) void lds_ptr;
     const int pieces = bytes / 16;
-    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int wave = (int)threadIdx.x >> 6;
+    // The lane's byte offset is made opaque HERE, at every call: the source addresses of a chunk are loop-invariant 64-bit
+    // values per lane, and left alone the compiler computes all of them (eight per chunk, six chunks) ahead of the pass loop
+    // and keeps them -- twenty-one registers' worth went to scratch in a kernel that has none to spare.
+    uint32_t lane_bytes = ((uint32_t)threadIdx.x & 63u) * 16u;
+    asm volatile("" : "+v"(lane_bytes));
+    const uint8_t* base = (const uint8_t*)src;
     for (int chunk = wave; chunk * 64 < pieces; chunk += kThreads / 64) {
-        const int i = chunk * 64 + lane;
-        if (i < pieces) __builtin_amdgcn_global_load_lds((global_ptr*)(src + i), (lds_ptr*)(dst + chunk * 64), 16, 0, 0);
+        if (chunk * 64 + (int)(lane_bytes >> 4) < pieces)
+            __builtin_amdgcn_global_load_lds((global_ptr*)(base + (size_t)chunk * 1024 + lane_bytes), (lds_ptr*)(dst + chunk * 64), 16, 0, 0);
     }
 }
 
@@ -208,6 +215,17 @@ __device__ __forceinline__ void dense_first(const uint8_t* w, const float* bias,
     }
 }
 
+// Between the two halves of layer 1 the feature words are made opaque: both halves turn the same bits into the same 112
+// float B values, and left alone the compiler computes them once and keeps them for the second half -- a hundred registers
+// held through a quarter of the pass, in a kernel whose two activation sets already take 128.  Recomputing costs two
+// vector instructions per value.
+__device__ __forceinline__ void forget_derived(uint32_t (&fb)[2][8]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(fb[t][k]));
+}
+
 struct PolicyF32Args {
     const uint4* plane_a;
     const uint4* plane_b;
@@ -252,6 +270,7 @@ __global__ __launch_bounds__(64 * kWaves) void policy_f32_kernel(const PolicyF32
         start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[1]), kChunkBytes[1]);
         dense_first<4>((const uint8_t*)s_buf[buf], s_bias, lane, g, fb, &xa[0][0], &xa[1][0]);
         __syncthreads(); buf ^= 1;
+        forget_derived(fb);
         // chunk 1: layer 1, tiles 4-7
         start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[2]), kChunkBytes[2]);
         dense_first<4>((const uint8_t*)s_buf[buf], s_bias + 64, lane, g, fb, &xa[0][4], &xa[1][4]);
@@ -290,6 +309,132 @@ __global__ __launch_bounds__(64 * kWaves) void policy_f32_kernel(const PolicyF32
     }
 }
 
+// T iterations of (float32 policy -> epsilon-greedy -> step) in ONE launch: the reference's arithmetic width
+// (model/model.py:9-20) as a multi-step loop.  The boards of a wave's tile stay in registers for the T steps; the 320 KB of
+// weights stream through the two LDS buffers once per step (L2 traffic: 82 MB per step over the chip, nothing beside
+// 2496 MFMAs per wave-step), the eight waves of the workgroup in lockstep through the six chunks as in policy_f32_kernel.
+// Exactly T x (tpl_policy_act_f32, tpl_explore_actions, tpl_step).  Between the policy and the move a board lives as its two
+// packed state words (8 registers instead of 16): the matrix part needs every register it can get.
+template <bool kAutoReset>
+__global__ __launch_bounds__(64 * kWaves) void actor_rollout_f32_kernel(const ActorArgs q) {
+    const StepArgs& p = q.s;
+    __shared__ uint4 s_buf[2][kBufBytes / 16];
+    __shared__ float s_bias[4 * kHidden + 16];
+    __shared__ ShapeWord s_shape[32];
+    __shared__ uint32_t s_stat[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const bool writer = (g & 1) == 0;
+    const int64_t tiles = (p.n + 31) / 32;
+    const int64_t tile_step = (int64_t)gridDim.x * kWaves;
+    // every wave of the workgroup makes the same number of passes (the chunk barriers need all of them)
+    const int64_t passes = (tiles - (int64_t)blockIdx.x * kWaves + tile_step - 1) / tile_step;
+    const uint8_t* image = (const uint8_t*)q.image;
+
+    if (threadIdx.x < 32) s_shape[threadIdx.x] = kShapeTable[threadIdx.x];
+    if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
+    for (int k = threadIdx.x; k < 4 * kHidden + 16; k += 64 * kWaves) s_bias[k] = ((const float*)(image + kOffB))[k];
+    start_chunk<64 * kWaves>(s_buf[0], (const uint4*)(image + kChunkOff[0]), kChunkBytes[0]);
+    __syncthreads();                                             // (its fence waits for the transfers)
+
+    int buf = 0;
+    for (int64_t pass = 0; pass < passes; ++pass) {
+        const int64_t tile = (int64_t)blockIdx.x * kWaves + wave + pass * tile_step;
+        const int64_t b = tile * 32 + (g >> 1) * 16 + c;
+        const bool valid = b < p.n;
+        uint4 A, B;                                               // the board between the steps' moves, packed
+        if (valid) {
+            A = p.plane_a[b];
+            B = p.plane_b[b];
+        } else {
+            Board filler;                                         // frozen: never moves, never resets
+#pragma unroll
+            for (int k = 0; k < kCols; ++k) filler.c[k] = 0;
+            filler.window = 0xFFFFFFFFu; filler.window_hi = 0xFu; filler.state = ST_LOST_LIMIT; filler.lines = 0; filler.moves = 0; filler.slot = 0;
+            pack_board(filler, A, B);
+        }
+        // the tile's 32 boards are one clock group (wave-uniform: kept in scalar registers)
+        unsigned long long clock = tile < tiles ? p.clock[tile] : 0ULL;
+        clock = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(clock >> 32)) << 32) |
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)clock);
+        for (uint32_t t = 0; t < q.T; ++t) {
+            if (q.states_a && valid && writer) {
+                q.states_a[(size_t)t * p.n + b] = A;
+                q.states_b[(size_t)t * p.n + b] = B;
+            }
+            f32x4 lg[2];
+            {
+                uint32_t own[8], fb[2][8];
+                {
+                    Board s;
+                    unpack_board(A, B, s);
+                    board_features(s, (int)p.L, (int)p.M, own);
+                }
+                both_features(own, g, fb);
+                f32x4 xa[2][kMt], xb[2][kMt];
+                start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[1]), kChunkBytes[1]);
+                dense_first<4>((const uint8_t*)s_buf[buf], s_bias, lane, g, fb, &xa[0][0], &xa[1][0]);
+                __syncthreads(); buf ^= 1;
+                forget_derived(fb);
+                start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[2]), kChunkBytes[2]);
+                dense_first<4>((const uint8_t*)s_buf[buf], s_bias + 64, lane, g, fb, &xa[0][4], &xa[1][4]);
+                __syncthreads(); buf ^= 1;
+                start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[3]), kChunkBytes[3]);
+                dense<kMt, kMt, true>((const uint8_t*)s_buf[buf], s_bias + 1 * kHidden, lane, g, xa, &xb[0][0], &xb[1][0]);
+                __syncthreads(); buf ^= 1;
+                start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[4]), kChunkBytes[4]);
+                dense<kMt, kMt, true>((const uint8_t*)s_buf[buf], s_bias + 2 * kHidden, lane, g, xb, &xa[0][0], &xa[1][0]);
+                __syncthreads(); buf ^= 1;
+                start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[5]), kChunkBytes[5]);
+                dense<kMt, kMt, true>((const uint8_t*)s_buf[buf], s_bias + 3 * kHidden, lane, g, xa, &xb[0][0], &xb[1][0]);
+                __syncthreads(); buf ^= 1;
+                // the head; the next step's (or pass's) first chunk arrives under it
+                if (t + 1 < q.T || pass + 1 < passes)
+                    start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[0]), kChunkBytes[0]);
+                dense<1, kMt, false>((const uint8_t*)s_buf[buf], s_bias + 4 * kHidden, lane, g, xb, &lg[0], &lg[1]);
+                __syncthreads(); buf ^= 1;
+            }
+            const uint32_t act0 = pick_action(lg[0], g, lane), act1 = pick_action(lg[1], g, lane);
+            uint32_t action = (g >> 1) ? act1 : act0;
+            action = explore(action, q.explore_seed, (uint64_t)(p.global_offset + b), q.step0 + t, q.eps_q24);
+            uint32_t rot, loc;
+            split_small_action(action, rot, loc);
+            float reward;
+            Tally mine;
+            Board s;
+            unpack_board(A, B, s);
+            // the pool entry of the board's episode is worked out again at every step (one hash) rather than carried through
+            // the matrix part
+            uint32_t cfg = current_config(s, p, (uint32_t)b, clock + t);
+            const bool done = advance_board<kAutoReset>(s, cfg, rot, loc, p, (uint32_t)b, clock + t, s_shape, reward, mine);
+            pack_board(s, A, B);
+            if (valid && writer) {
+                // finished episodes go straight to the block's counters in LDS (a board finishes every thirtieth step or
+                // so): four registers fewer to carry through the matrix part than a per-lane tally
+                if (mine.episodes) {
+                    atomicAdd(&s_stat[0], mine.episodes);
+                    if (mine.lines) atomicAdd(&s_stat[1], mine.lines);
+                    if (mine.wins) atomicAdd(&s_stat[2], mine.wins);
+                    if (mine.topouts) atomicAdd(&s_stat[3], mine.topouts);
+                }
+                if (q.actions) q.actions[(size_t)t * p.n + b] = (uint8_t)action;
+                if (q.rewards) q.rewards[(size_t)t * p.n + b] = reward;
+                if (q.dones) q.dones[(size_t)t * p.n + b] = done ? 1 : 0;
+            }
+        }
+        if (valid && writer) {
+            p.plane_a[b] = A;
+            p.plane_b[b] = B;
+            if ((b & (kClockGroup - 1)) == 0) p.clock[b >> kClockShift] = clock + q.T;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {                                        // as flush_tally: one sharded 64-bit atomic per counter
+        const uint32_t v = s_stat[threadIdx.x];
+        if (v) atomicAdd(&p.stats[(size_t)(blockIdx.x % kStatShards) * kStatStride + threadIdx.x], (unsigned long long)v);
+    }
+}
+
 }  // namespace pf32
 }  // namespace tpl
 
@@ -305,5 +450,30 @@ extern "C" int tpl_policy_act_f32(tpl_env* e, const void* image, uint8_t* action
     const int64_t groups = ((e->n + 31) / 32 + kWaves - 1) / kWaves;
     hipLaunchKernelGGL(policy_f32_kernel, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(64 * kWaves), 0, (hipStream_t)stream, p);
     TPL_HIP(hipGetLastError());
+    return TPL_OK;
+}
+
+extern "C" int tpl_actor_rollout_f32(tpl_env* e, const void* image, int32_t num_steps, float epsilon, uint64_t seed, uint32_t step0,
+                                     uint8_t* actions, float* rewards, uint8_t* dones, void* states_a, void* states_b,
+                                     void* stream) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!image) return fail_msg(TPL_ERR_ARG, "image is null");
+    if (((uintptr_t)image & 15u) != 0) return fail_msg(TPL_ERR_ARG, "image must be 16-byte aligned");
+    if (num_steps < 1) return fail_msg(TPL_ERR_ARG, "num_steps must be >= 1");
+    if (!(epsilon >= 0.0f && epsilon <= 1.0f)) return fail_msg(TPL_ERR_ARG, "epsilon must be in [0, 1]");
+    if ((states_a == nullptr) != (states_b == nullptr)) return fail_msg(TPL_ERR_ARG, "states_a and states_b go together");
+    if (int rc = check_can_advance(e)) return rc;
+    DeviceGuard guard(e->device);
+    ActorArgs q{};
+    q.s = make_args(e);
+    q.image = (const uint4*)image; q.T = (uint32_t)num_steps; q.step0 = step0;
+    q.eps_q24 = (uint32_t)(epsilon * 16777216.0f); q.explore_seed = seed;
+    q.actions = actions; q.rewards = rewards; q.dones = dones; q.states_a = (uint4*)states_a; q.states_b = (uint4*)states_b;
+    const int64_t groups = ((e->n + 31) / 32 + kWaves - 1) / kWaves;
+    const dim3 grid((unsigned)(groups < 256 ? groups : 256)), block(64 * kWaves);
+    if (e->auto_reset) hipLaunchKernelGGL(actor_rollout_f32_kernel<true>, grid, block, 0, (hipStream_t)stream, q);
+    else hipLaunchKernelGGL(actor_rollout_f32_kernel<false>, grid, block, 0, (hipStream_t)stream, q);
+    TPL_HIP(hipGetLastError());
+    count_steps(e, num_steps);
     return TPL_OK;
 }

@@ -141,28 +141,59 @@ __device__ __forceinline__ void load_image(uint4* s_image, const uint4* image) {
     __syncthreads();                                            // (its fence waits for the transfers)
 }
 
-__device__ __forceinline__ bf16x8 a_frag(const uint8_t* lds, int w_off, int q, int lane) {
-    return *(const bf16x8*)(lds + w_off + (q * 64 + lane) * 16);
+// Where a lane reads the image from.  A ds_read carries a 16-bit byte offset, the image is 158 KB: read as
+// `lds + constant + 16 lane` every fragment past the first 64 KB gets an address register of its own -- ninety-six of them,
+// all loop-invariant, all live across the whole kernel (that, not the arithmetic, was what filled the register file and put
+// two values in scratch).  So the lane keeps THREE bases, 64 KB apart, made opaque so that they are not folded back into
+// one, and every read is base[offset >> 16] + (offset & 0xFFFF) with the low part in the instruction.
+// (The bases are 32-bit LDS addresses and stay typed as such: through a generic pointer the reads would become flat loads.)
+typedef __attribute__((address_space(3))) const uint8_t lds_byte;
+typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
+typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
+struct LdsBases {
+    lds_byte* frag[3];          // image + 16 lane + 65536 i: A fragments
+    lds_byte* bias;             // image + 131072 + 16 (lane >> 4): the f32 biases sit in the third segment
+};
+__device__ __forceinline__ LdsBases lds_bases(const uint8_t* lds, int lane) {
+    LdsBases b;
+    lds_byte* image = (lds_byte*)lds;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        b.frag[i] = image + 65536 * i + 16 * lane;
+        asm volatile("" : "+v"(b.frag[i]));
+    }
+    b.bias = image + 131072 + 16 * (lane >> 4);
+    asm volatile("" : "+v"(b.bias));
+    return b;
+}
+__device__ __forceinline__ bf16x8 a_frag(const LdsBases& at, int w_off, int q) {
+    const int off = w_off + q * 1024;                           // a compile-time constant wherever this is called
+    return *(lds_bf16x8*)(at.frag[off >> 16] + (off & 0xFFFF));
+}
+// bias[k .. k + 3], k = 4 (lane >> 4) + first: `first` floats into the bias block
+__device__ __forceinline__ float4 bias4(const LdsBases& at, int first) {
+    const f32x4 v = *(lds_f32x4*)(at.bias + (kOffB - 131072) + 4 * first);
+    return make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // One layer with 16*kTiles outputs on two N tiles of 16 boards.  Output tile m outermost; the A fragments stream
 // through a four-deep register window (the read of fragment q+4 is issued right behind the MFMAs that consume
 // fragment q); tile m's epilogue sits behind the MFMAs of tile m+1.  xout[t][s] collects tiles 2s and 2s+1.
 template <int kTiles, int kKs, bool kRelu>
-__device__ __forceinline__ void dense(const uint8_t* lds, int w_off, const float* bias, int lane, int g,
+__device__ __forceinline__ void dense(const LdsBases& at, int w_off, int bias_first,
                                       const uint4 (&xin)[2][kKs], uint4 (&xout)[2][kTiles / 2 > 0 ? kTiles / 2 : 1],
                                       f32x4 (&last)[2]) {
     f32x4 acc[2][2];
     bf16x8 aq[4];
 #pragma unroll
-    for (int q = 0; q < 4 && q < kTiles * kKs; ++q) aq[q] = a_frag(lds, w_off, q, lane);
+    for (int q = 0; q < 4 && q < kTiles * kKs; ++q) aq[q] = a_frag(at, w_off, q);
     // the bias of tile m+1 is read while tile m is being multiplied: read just in time, the accumulator's initial
     // value would stall the first MFMA of every tile for one LDS latency
-    float4 bnext = *(const float4*)(bias + 4 * g);
+    float4 bnext = bias4(at, bias_first);
 #pragma unroll
     for (int m = 0; m < kTiles; ++m) {
         const float4 b = bnext;
-        if (m + 1 < kTiles) bnext = *(const float4*)(bias + 16 * (m + 1) + 4 * g);
+        if (m + 1 < kTiles) bnext = bias4(at, bias_first + 16 * (m + 1));
 #pragma unroll
         for (int t = 0; t < 2; ++t) { acc[m & 1][t][0] = b.x; acc[m & 1][t][1] = b.y; acc[m & 1][t][2] = b.z; acc[m & 1][t][3] = b.w; }
 #pragma unroll
@@ -171,7 +202,7 @@ __device__ __forceinline__ void dense(const uint8_t* lds, int w_off, const float
 #pragma unroll
             for (int t = 0; t < 2; ++t)
                 acc[m & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[q & 3], __builtin_bit_cast(bf16x8, xin[t][s]), acc[m & 1][t], 0, 0, 0);
-            if (q + 4 < kTiles * kKs) aq[q & 3] = a_frag(lds, w_off, q + 4, lane);
+            if (q + 4 < kTiles * kKs) aq[q & 3] = a_frag(at, w_off, q + 4);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (kRelu && m > 0) {
@@ -203,9 +234,7 @@ __device__ __forceinline__ void dense(const uint8_t* lds, int w_off, const float
 
 // five layers for the wave's two N tiles; fb[t] = features of board (t, c).  Returns the logits tile: lane (c, g)
 // holds outputs 4g + reg of board (t, c) in logits[t][reg].
-__device__ __forceinline__ void policy_logits(const uint8_t* lds, int lane, int g, const uint32_t (&fb)[2][8],
-                                              f32x4 (&logits)[2]) {
-    const float* bias = (const float*)(lds + kOffB);
+__device__ __forceinline__ void policy_logits(const LdsBases& at, int g, const uint32_t (&fb)[2][8], f32x4 (&logits)[2]) {
     // layer-1 B fragments straight from the feature bits: register i of lane group g holds bits 4g + i and
     // 16 + 4g + i of word s as the bf16 pattern 0x4000 (= 2.0; the packer halves the weights) -- one shift, one mask
     uint4 x0[2][kKs1];
@@ -227,12 +256,12 @@ __device__ __forceinline__ void policy_logits(const uint8_t* lds, int lane, int 
         }
     uint4 xa[2][kKsH], xb[2][kKsH];
     f32x4 unused[2];
-    dense<kMt, kKs1, true>(lds, kOffW1, bias, lane, g, x0, xa, unused);
-    dense<kMt, kKsH, true>(lds, kOffW2, bias + 1 * kHidden, lane, g, xa, xb, unused);
-    dense<kMt, kKsH, true>(lds, kOffW3, bias + 2 * kHidden, lane, g, xb, xa, unused);
-    dense<kMt, kKsH, true>(lds, kOffW4, bias + 3 * kHidden, lane, g, xa, xb, unused);
+    dense<kMt, kKs1, true>(at, kOffW1, 0, x0, xa, unused);
+    dense<kMt, kKsH, true>(at, kOffW2, 1 * kHidden, xa, xb, unused);
+    dense<kMt, kKsH, true>(at, kOffW3, 2 * kHidden, xb, xa, unused);
+    dense<kMt, kKsH, true>(at, kOffW4, 3 * kHidden, xa, xb, unused);
     uint4 none[2][1];
-    dense<1, kKsH, false>(lds, kOffW5, bias + 4 * kHidden, lane, g, xb, none, logits);
+    dense<1, kKsH, false>(at, kOffW5, 4 * kHidden, xb, none, logits);
 }
 
 struct PolicyArgs {
@@ -255,6 +284,7 @@ __global__ __launch_bounds__(64 * kPolicyWaves) void policy_kernel(const PolicyA
     const uint8_t* lds = (const uint8_t*)s_image;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
+    const LdsBases at = lds_bases(lds, lane);
     const int64_t tiles = (p.n + 31) / 32;
     const int64_t tile0 = (int64_t)blockIdx.x * kPolicyWaves + wave, tile_step = (int64_t)gridDim.x * kPolicyWaves;
     // the first tile's boards are requested ahead of the weights and arrive under their transfer
@@ -287,7 +317,7 @@ __global__ __launch_bounds__(64 * kPolicyWaves) void policy_kernel(const PolicyA
         board_features(s, p.L, p.M, own);
         both_features(own, g, fb);
         f32x4 lg[2];
-        policy_logits(lds, lane, g, fb, lg);
+        policy_logits(at, g, fb, lg);
         const uint32_t act0 = pick_action(lg[0], g, lane), act1 = pick_action(lg[1], g, lane);
         const uint32_t action = (g >> 1) ? act1 : act0;
         const f32x4 mine = (g >> 1) ? lg[1] : lg[0];     // the tile of this lane's own board (t = g >> 1)
@@ -324,18 +354,6 @@ __global__ __launch_bounds__(kBlock) void explore_kernel(uint8_t* action, int64_
     if (i < n) action[i] = (uint8_t)explore(action[i], seed, (uint64_t)(global_offset + i), step, eps_q24);
 }
 
-struct ActorArgs {
-    StepArgs s;
-    const uint4* image;
-    uint32_t T, step0, eps_q24;
-    uint64_t explore_seed;
-    uint8_t* actions;
-    float* rewards;
-    uint8_t* dones;
-    uint4* states_a;
-    uint4* states_b;
-};
-
 // T iterations of (policy -> epsilon-greedy -> step) in ONE launch: weights stay in LDS, boards stay in
 // registers, nothing but the trajectory leaves the chip.  Exactly T x (tpl_policy_act, tpl_explore_actions,
 // tpl_step).  Lanes g and g ^ 1 advance identical copies of board (g >> 1, c); the even one writes.
@@ -351,6 +369,7 @@ __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q
     const uint8_t* lds = (const uint8_t*)s_image;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
+    const LdsBases at = lds_bases(lds, lane);
     const bool writer = (g & 1) == 0;
     const int64_t tiles = (p.n + 31) / 32;
     Tally tally;
@@ -382,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q
             board_features(s, (int)p.L, (int)p.M, own);
             both_features(own, g, fb);
             f32x4 lg[2];
-            policy_logits(lds, lane, g, fb, lg);
+            policy_logits(at, g, fb, lg);
             const uint32_t act0 = pick_action(lg[0], g, lane), act1 = pick_action(lg[1], g, lane);
             uint32_t action = (g >> 1) ? act1 : act0;
             action = explore(action, q.explore_seed, (uint64_t)(p.global_offset + b), q.step0 + t, q.eps_q24);

@@ -5,9 +5,24 @@
 #pragma once
 
 #include "tpl_internal.h"
+#include "tpl_step.h"
 
 namespace tpl {
 namespace p16 {
+
+// arguments of the actor kernels (policy -> epsilon-greedy -> step, T times in one launch), bf16 and float32 alike
+struct ActorArgs {
+    StepArgs s;
+    const uint4* image;
+    uint32_t T, step0, eps_q24;
+    uint64_t explore_seed;
+    uint8_t* actions;
+    float* rewards;
+    uint8_t* dones;
+    uint4* states_a;
+    uint4* states_b;
+};
+
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;

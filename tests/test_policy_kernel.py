@@ -355,3 +355,59 @@ def test_f32_actor_drives_the_environment(T, oracle):
     for k, v in cpu.get_state().items():
         assert np.array_equal(got[k].view(np.uint16) if k == "rows" else got[k], v), k
     env.terminate()
+
+
+@pytest.mark.parametrize("auto,eps,n,steps", [(True, 0.0, 3000, 21), (True, 0.15, 70001, 7), (False, 0.3, 3000, 21)])
+def test_f32_actor_rollout_megakernel_equals_the_step_by_step_loop(T, oracle, auto, eps, n, steps):
+    """tpl_actor_rollout_f32 (T iterations of float32 policy -> epsilon-greedy -> step in ONE launch, the reference's
+    nn.Linear width as a multi-step loop) == T x (tpl_policy_act_f32, tpl_explore_actions, tpl_step) on a twin handle:
+    same actions, rewards, dones, recorded states, final boards and statistics -- the float32 products are the same
+    instructions in the same order, so the logits, and with them the decisions, are identical -- and the environment side
+    equals the oracle fed with the recorded actions.  70,001 boards: more than one pass per wave, a ragged last tile."""
+    import torch
+    L, M, seed = 10, 40, 29
+    torch.manual_seed(4)
+    model = T.PolicyMLP()
+    with torch.no_grad():
+        for prm in model.parameters():
+            prm.normal_(0.0, 0.35)
+    envs = []
+    for _ in range(2):
+        env = T.BatchedTetris(L, M, n, seed=seed, auto_reset=auto, global_offset=77, reward=(1.0, 2.0, -1.0))
+        rows, pieces = env.synthetic_configs(700)
+        env.load_configs(rows, pieces)
+        env.reset()
+        envs.append(env)
+    mega, ref = envs
+    image = T.actor.policy_image(model, mega.device, f32=True)
+    k1 = steps // 3                                            # two launches: the second resumes from stored state
+    out1 = mega.actor_rollout(image, k1, epsilon=eps, seed=5, step0=100, record_states=True)
+    out2 = mega.actor_rollout(image, steps - k1, epsilon=eps, seed=5, step0=100 + k1, record_states=True)
+    out = {k: torch.cat([out1[k], out2[k]]) for k in out1}
+    cpu = oracle.Env(n, L, M, 77, seed)
+    cpu.set_pool(rows.cpu().numpy().view(np.uint16), pieces.cpu().numpy())
+    cpu.set_options(auto_reset=auto, assign_mode=0, per_line=1.0, win=2.0, lose=-1.0)
+    cpu.reset()
+    explored = 0
+    for t in range(steps):
+        a_planes, b_planes = ref.raw_planes()
+        assert torch.equal(out["states_a"][t], a_planes) and torch.equal(out["states_b"][t], b_planes), t
+        greedy = ref.policy_act(image).clone()
+        action = ref.explore_actions(greedy.clone(), eps, seed=5, step=100 + t)
+        explored += int((action != greedy).sum())
+        _, r, d, _ = ref.step(action, observe=False)
+        assert torch.equal(out["actions"][t], action), t
+        assert torch.equal(out["rewards"][t], r) and torch.equal(out["dones"][t], d), t
+        r_c, d_c = cpu.step(action.cpu().numpy())
+        assert np.array_equal(r.cpu().numpy(), r_c) and np.array_equal(d.cpu().numpy(), d_c), t
+    if eps > 0:
+        assert 0.5 * eps < explored / (steps * n) < 1.5 * eps
+    else:
+        assert explored == 0
+    got = {k: v.cpu().numpy() for k, v in mega.packed_state().items()}
+    want = cpu.get_state()
+    for k, v in want.items():
+        assert np.array_equal(got[k].view(np.uint16) if k == "rows" else got[k], v), k
+    assert mega.stats() == ref.stats() == cpu.stats()
+    for e in envs:
+        e.terminate()
