@@ -176,92 +176,139 @@ __device__ __forceinline__ float4 bias4(const LdsBases& at, int first) {
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
-// One layer with 16*kTiles outputs on two N tiles of 16 boards.  Output tile m outermost; the A fragments stream
-// through a four-deep register window (the read of fragment q+4 is issued right behind the MFMAs that consume
-// fragment q); tile m's epilogue sits behind the MFMAs of tile m+1.  xout[t][s] collects tiles 2s and 2s+1.
+constexpr int kNt = 4;          // N tiles of 16 boards per wave: 64 boards, one per lane
+
+// One layer with 16*kTiles outputs on the wave's four N tiles.  Output tile m outermost; the A fragments stream through a
+// four-deep register window (the read of fragment q+4 is issued right behind the four MFMAs that consume fragment q);
+// tile m's epilogue sits behind the MFMAs of tile m+1.  xout[t][s] collects tiles 2s and 2s+1.
 template <int kTiles, int kKs, bool kRelu>
-__device__ __forceinline__ void dense(const LdsBases& at, int w_off, int bias_first,
-                                      const uint4 (&xin)[2][kKs], uint4 (&xout)[2][kTiles / 2 > 0 ? kTiles / 2 : 1],
-                                      f32x4 (&last)[2]) {
-    f32x4 acc[2][2];
+__device__ __forceinline__ void dense(const LdsBases& at, int w_off, int bias_first, const uint4 (&xin)[kNt][kKs],
+                                      uint4 (&xout)[kNt][kTiles / 2 > 0 ? kTiles / 2 : 1], f32x4 (&last)[kNt]) {
+    f32x4 acc[2][kNt];
     bf16x8 aq[4];
 #pragma unroll
     for (int q = 0; q < 4 && q < kTiles * kKs; ++q) aq[q] = a_frag(at, w_off, q);
     // the bias of tile m+1 is read while tile m is being multiplied: read just in time, the accumulator's initial
     // value would stall the first MFMA of every tile for one LDS latency
     float4 bnext = bias4(at, bias_first);
+    const auto hand_off = [&](int pm) {          // f32 accumulators of output tile pm -> ReLU -> the next layer's bf16 B values
 #pragma unroll
-    for (int m = 0; m < kTiles; ++m) {
-        const float4 b = bnext;
-        if (m + 1 < kTiles) bnext = bias4(at, bias_first + 16 * (m + 1));
-#pragma unroll
-        for (int t = 0; t < 2; ++t) { acc[m & 1][t][0] = b.x; acc[m & 1][t][1] = b.y; acc[m & 1][t][2] = b.z; acc[m & 1][t][3] = b.w; }
-#pragma unroll
-        for (int s = 0; s < kKs; ++s) {
-            const int q = m * kKs + s;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-                acc[m & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[q & 3], __builtin_bit_cast(bf16x8, xin[t][s]), acc[m & 1][t], 0, 0, 0);
-            if (q + 4 < kTiles * kKs) aq[q & 3] = a_frag(at, w_off, q + 4);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (kRelu && m > 0) {
-            const int pm = m - 1;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const uint32_t lo = relu_bf16x2(pack_bf16(acc[pm & 1][t][0], acc[pm & 1][t][1]));
-                const uint32_t hi = relu_bf16x2(pack_bf16(acc[pm & 1][t][2], acc[pm & 1][t][3]));
-                if (pm & 1) { xout[t][pm >> 1].z = lo; xout[t][pm >> 1].w = hi; }
-                else { xout[t][pm >> 1].x = lo; xout[t][pm >> 1].y = hi; }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if (kRelu) {
-        const int pm = kTiles - 1;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < kNt; ++t) {
             const uint32_t lo = relu_bf16x2(pack_bf16(acc[pm & 1][t][0], acc[pm & 1][t][1]));
             const uint32_t hi = relu_bf16x2(pack_bf16(acc[pm & 1][t][2], acc[pm & 1][t][3]));
             if (pm & 1) { xout[t][pm >> 1].z = lo; xout[t][pm >> 1].w = hi; }
             else { xout[t][pm >> 1].x = lo; xout[t][pm >> 1].y = hi; }
         }
-    } else {
+    };
 #pragma unroll
-        for (int t = 0; t < 2; ++t) last[t] = acc[(kTiles - 1) & 1][t];
+    for (int m = 0; m < kTiles; ++m) {
+        const float4 b = bnext;
+        if (m + 1 < kTiles) bnext = bias4(at, bias_first + 16 * (m + 1));
+#pragma unroll
+        for (int t = 0; t < kNt; ++t) { acc[m & 1][t][0] = b.x; acc[m & 1][t][1] = b.y; acc[m & 1][t][2] = b.z; acc[m & 1][t][3] = b.w; }
+#pragma unroll
+        for (int s = 0; s < kKs; ++s) {
+            const int q = m * kKs + s;
+#pragma unroll
+            for (int t = 0; t < kNt; ++t)
+                acc[m & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[q & 3], __builtin_bit_cast(bf16x8, xin[t][s]), acc[m & 1][t], 0, 0, 0);
+            if (q + 4 < kTiles * kKs) aq[q & 3] = a_frag(at, w_off, q + 4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kRelu && m > 0) {
+            hand_off(m - 1);
+            // (tried: sched_group_barrier patterns that issue four hand-off instructions and a fragment read behind every
+            // k-step's four MFMAs -- the schedule came out as asked and the kernel 3 % slower: profiles/NOTES.md, round 4)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (kRelu) hand_off(kTiles - 1);
+    else {
+#pragma unroll
+        for (int t = 0; t < kNt; ++t) last[t] = acc[(kTiles - 1) & 1][t];
     }
 }
 
-// five layers for the wave's two N tiles; fb[t] = features of board (t, c).  Returns the logits tile: lane (c, g)
-// holds outputs 4g + reg of board (t, c) in logits[t][reg].
-__device__ __forceinline__ void policy_logits(const LdsBases& at, int g, const uint32_t (&fb)[2][8], f32x4 (&logits)[2]) {
-    // layer-1 B fragments straight from the feature bits: register i of lane group g holds bits 4g + i and
-    // 16 + 4g + i of word s as the bf16 pattern 0x4000 (= 2.0; the packer halves the weights) -- one shift, one mask
-    uint4 x0[2][kKs1];
+// Layer 1: its B fragments are made from the boards' feature bits, sixteen registers per k-step for the four tiles -- all
+// seven k-steps at once would be 112 -- so here the K-STEPS run outermost and the accumulators of all eight output tiles stay
+// live (128 registers), each B fragment made once and used by eight MFMAs.  Register i of lane group g holds bits 4g + i and
+// 16 + 4g + i of feature word s as the bf16 pattern 0x4000 (= 2.0; the packer halves the weights): one shift, one mask.
+__device__ __forceinline__ void dense_first(const LdsBases& at, int g, const uint32_t (&fb)[kNt][8], uint4 (&xout)[kNt][kMt / 2]) {
+    f32x4 acc[kMt][kNt];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int m = 0; m < kMt; ++m) {
+        const float4 b = bias4(at, 16 * m);
 #pragma unroll
-        for (int s = 0; s < kKs1; ++s) {
+        for (int t = 0; t < kNt; ++t) { acc[m][t][0] = b.x; acc[m][t][1] = b.y; acc[m][t][2] = b.z; acc[m][t][3] = b.w; }
+    }
+    bf16x8 aq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) aq[q] = a_frag(at, kOffW1, (q % kMt) * kKs1 + q / kMt);          // order of use: (s, m), m fastest
+#pragma unroll
+    for (int s = 0; s < kKs1; ++s) {
+        uint4 x[kNt];
+#pragma unroll
+        for (int t = 0; t < kNt; ++t) {
             const uint32_t u = fb[t][s] >> (4 * g);
-            uint4 q;
-            q.x = (u << 14) & 0x40004000u;
-            q.y = (u << 13) & 0x40004000u;
-            q.z = (u << 12) & 0x40004000u;
-            q.w = (u << 11) & 0x40004000u;
+            x[t].x = (u << 14) & 0x40004000u;
+            x[t].y = (u << 13) & 0x40004000u;
+            x[t].z = (u << 12) & 0x40004000u;
+            x[t].w = (u << 11) & 0x40004000u;
             if (s == 6 && g == 1) {                      // bits 22, 23 of word 6 = features 214, 215: L_rem, M_rem
-                q.z |= fb[t][7] << 16;
-                q.w |= fb[t][7] & 0xFFFF0000u;
+                x[t].z |= fb[t][7] << 16;
+                x[t].w |= fb[t][7] & 0xFFFF0000u;
             }
-            x0[t][s] = q;
         }
-    uint4 xa[2][kKsH], xb[2][kKsH];
-    f32x4 unused[2];
-    dense<kMt, kKs1, true>(at, kOffW1, 0, x0, xa, unused);
+#pragma unroll
+        for (int m = 0; m < kMt; ++m) {
+            const int q = s * kMt + m;                   // position in the order of use
+#pragma unroll
+            for (int t = 0; t < kNt; ++t)
+                acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[q & 3], __builtin_bit_cast(bf16x8, x[t]), acc[m][t], 0, 0, 0);
+            if (q + 4 < kKs1 * kMt) aq[q & 3] = a_frag(at, kOffW1, ((q + 4) % kMt) * kKs1 + (q + 4) / kMt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < kMt; ++m)
+#pragma unroll
+        for (int t = 0; t < kNt; ++t) {
+            const uint32_t lo = relu_bf16x2(pack_bf16(acc[m][t][0], acc[m][t][1]));
+            const uint32_t hi = relu_bf16x2(pack_bf16(acc[m][t][2], acc[m][t][3]));
+            if (m & 1) { xout[t][m >> 1].z = lo; xout[t][m >> 1].w = hi; }
+            else { xout[t][m >> 1].x = lo; xout[t][m >> 1].y = hi; }
+        }
+}
+
+// five layers for the wave's four N tiles; fb[t] = features of board (t, c).  Returns the logits tiles: lane (c, g)
+// holds outputs 4g + reg of board (t, c) in logits[t][reg].
+__device__ __forceinline__ void policy_logits(const LdsBases& at, int g, const uint32_t (&fb)[kNt][8], f32x4 (&logits)[kNt]) {
+    uint4 xa[kNt][kKsH], xb[kNt][kKsH];
+    f32x4 unused[kNt];
+    dense_first(at, g, fb, xa);
     dense<kMt, kKsH, true>(at, kOffW2, 1 * kHidden, xa, xb, unused);
     dense<kMt, kKsH, true>(at, kOffW3, 2 * kHidden, xb, xa, unused);
     dense<kMt, kKsH, true>(at, kOffW4, 3 * kHidden, xa, xb, unused);
-    uint4 none[2][1];
+    uint4 none[kNt][1];
     dense<1, kKsH, false>(at, kOffW5, 4 * kHidden, xb, none, logits);
+}
+
+// the features of all four boards of the lane's column c (board (t, c) lives on lane 16 t + c), and the lane's own action
+// out of the four tiles' logits
+__device__ __forceinline__ void column_features(const uint32_t (&own)[8], int c, uint32_t (&fb)[kNt][8]) {
+#pragma unroll
+    for (int t = 0; t < kNt; ++t)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) fb[t][k] = __shfl(own[k], 16 * t + c);
+}
+__device__ __forceinline__ uint32_t own_action(const f32x4 (&lg)[kNt], int g, int lane) {
+    uint32_t action = 0;
+#pragma unroll
+    for (int t = 0; t < kNt; ++t) {
+        const uint32_t a = pick_action(lg[t], g, lane);          // on all four lanes of column c: the action of board (t, c)
+        action = g == t ? a : action;
+    }
+    return action;
 }
 
 struct PolicyArgs {
@@ -285,12 +332,15 @@ __global__ __launch_bounds__(64 * kPolicyWaves) void policy_kernel(const PolicyA
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const LdsBases at = lds_bases(lds, lane);
-    const int64_t tiles = (p.n + 31) / 32;
+#ifdef TPL_DIAG_CLOCK
+    const unsigned long long r_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int64_t tiles = (p.n + 63) / 64;
     const int64_t tile0 = (int64_t)blockIdx.x * kPolicyWaves + wave, tile_step = (int64_t)gridDim.x * kPolicyWaves;
     // the first tile's boards are requested ahead of the weights and arrive under their transfer
-    uint4 A, B;                                                   // the boards of the tile about to be computed
+    uint4 A, B;                                                   // the board of the tile about to be computed
     {
-        const int64_t b0 = tile0 * 32 + (g >> 1) * 16 + c;
+        const int64_t b0 = tile0 * 64 + lane;
         const int64_t j = b0 < p.n ? b0 : p.n - 1;                // a lane past the end holds the last real board
         A = p.plane_a[j];
         B = p.plane_b[j];
@@ -301,33 +351,32 @@ __global__ __launch_bounds__(64 * kPolicyWaves) void policy_kernel(const PolicyA
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     for (int64_t tile = tile0; tile < tiles; tile += tile_step) {
-        const int64_t b = tile * 32 + (g >> 1) * 16 + c;
+        const int64_t b = tile * 64 + lane;
         const bool valid = b < p.n;
-        Board s;
-        unpack_board(A, B, s);
+        uint32_t fb[kNt][8];
+        {
+            Board s;
+            unpack_board(A, B, s);
+            uint32_t own[8];
+            board_features(s, p.L, p.M, own);
+            column_features(own, c, fb);
+        }
         // the next tile's boards are requested now and used a whole tile of matrix work later (no per-lane branch:
         // the loads land in the registers the loop carries)
         if (tile + tile_step < tiles) {
-            const int64_t bn = b + tile_step * 32;
+            const int64_t bn = b + tile_step * 64;
             const int64_t jn = bn < p.n ? bn : p.n - 1;
             A = p.plane_a[jn];
             B = p.plane_b[jn];
         }
-        uint32_t own[8], fb[2][8];
-        board_features(s, p.L, p.M, own);
-        both_features(own, g, fb);
-        f32x4 lg[2];
+        f32x4 lg[kNt];
         policy_logits(at, g, fb, lg);
-        const uint32_t act0 = pick_action(lg[0], g, lane), act1 = pick_action(lg[1], g, lane);
-        const uint32_t action = (g >> 1) ? act1 : act0;
-        const f32x4 mine = (g >> 1) ? lg[1] : lg[0];     // the tile of this lane's own board (t = g >> 1)
-        // rows 4g + reg of board (t, c) live on lane (c, g) for BOTH t; a lane writes the rows of its own board's
-        // tile and fetches nothing: lanes (c, 0..3) of tile t are four different lanes, two of which own board t
+        const uint32_t action = own_action(lg, g, lane);
         if (p.logits) {
-            // every (t, c, g) triple must be written once: lane (c, g) holds lg[t] for both t
+            // rows 4g + reg of board (t, c) live on lane (c, g), for every t
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int64_t bt = tile * 32 + t * 16 + c;
+            for (int t = 0; t < kNt; ++t) {
+                const int64_t bt = tile * 64 + t * 16 + c;
                 if (bt < p.n) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
@@ -335,15 +384,16 @@ __global__ __launch_bounds__(64 * kPolicyWaves) void policy_kernel(const PolicyA
                 }
             }
         }
-        (void)mine;
-        if (valid && (g & 1) == 0) p.action[b] = (uint8_t)action;
+        if (valid) p.action[b] = (uint8_t)action;
     }
 #ifdef TPL_DIAG_CLOCK
     if (lane == 0 && p.diag) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long* d = p.diag + 2 * ((size_t)blockIdx.x * kPolicyWaves + wave);
+        unsigned long long* d = p.diag + 4 * ((size_t)blockIdx.x * kPolicyWaves + wave);
         d[0] = t1 - t0;
         d[1] = r1 - r0;
+        d[2] = r0 - r_entry;                                      // entry -> weights in LDS
+        d[3] = r_entry;                                           // when this wave started (100 MHz, free running)
     }
 #endif
 }
@@ -356,7 +406,7 @@ __global__ __launch_bounds__(kBlock) void explore_kernel(uint8_t* action, int64_
 
 // T iterations of (policy -> epsilon-greedy -> step) in ONE launch: weights stay in LDS, boards stay in
 // registers, nothing but the trajectory leaves the chip.  Exactly T x (tpl_policy_act, tpl_explore_actions,
-// tpl_step).  Lanes g and g ^ 1 advance identical copies of board (g >> 1, c); the even one writes.
+// tpl_step).  A wave holds 64 boards, one per lane (a tile spans two of the 32-board clock groups).
 template <bool kAutoReset>
 __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q) {
     const StepArgs& p = q.s;
@@ -370,63 +420,76 @@ __global__ __launch_bounds__(512, 2) void actor_rollout_kernel(const ActorArgs q
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const LdsBases at = lds_bases(lds, lane);
-    const bool writer = (g & 1) == 0;
-    const int64_t tiles = (p.n + 31) / 32;
-    Tally tally;
+    const int64_t tiles = (p.n + 63) / 64;
     for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < tiles; tile += (int64_t)gridDim.x * 8) {
-        const int64_t b = tile * 32 + (g >> 1) * 16 + c;
+        const int64_t b = tile * 64 + lane;
         const bool valid = b < p.n;
-        Board s;
+        // Through the matrix part a board lives as its two packed state words (8 registers instead of 16), its pool entry is
+        // worked out again at every step (one hash) and finished episodes go straight to the block's counters in LDS: the
+        // four tiles' activations need the registers.
+        uint4 A, B;
+        unsigned long long clock = 0;
         if (valid) {
-            unpack_board(p.plane_a[b], p.plane_b[b], s);
+            A = p.plane_a[b];
+            B = p.plane_b[b];
+            clock = p.clock[b >> kClockShift];
         } else {
+            Board filler;                                         // frozen: never moves, never resets
 #pragma unroll
-            for (int k = 0; k < kCols; ++k) s.c[k] = 0;
-            s.window = 0xFFFFFFFFu; s.window_hi = 0xFu; s.state = ST_LOST_LIMIT; s.lines = 0; s.moves = 0; s.slot = 0;   // frozen filler
+            for (int k = 0; k < kCols; ++k) filler.c[k] = 0;
+            filler.window = 0xFFFFFFFFu; filler.window_hi = 0xFu; filler.state = ST_LOST_LIMIT; filler.lines = 0; filler.moves = 0; filler.slot = 0;
+            pack_board(filler, A, B);
         }
-        // the tile's 32 boards are one clock group
-        // (wave-uniform: kept in scalar registers)
-        unsigned long long clock = p.clock[tile];
-        clock = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(clock >> 32)) << 32) |
-                (uint32_t)__builtin_amdgcn_readfirstlane((int)clock);
-        uint32_t cfg = current_config(s, p, (uint32_t)b, clock);
         for (uint32_t t = 0; t < q.T; ++t) {
-            if (q.states_a && valid && writer) {
-                uint4 A, B;
-                pack_board(s, A, B);
+            if (q.states_a && valid) {
                 q.states_a[(size_t)t * p.n + b] = A;
                 q.states_b[(size_t)t * p.n + b] = B;
             }
-            uint32_t own[8], fb[2][8];
-            board_features(s, (int)p.L, (int)p.M, own);
-            both_features(own, g, fb);
-            f32x4 lg[2];
-            policy_logits(at, g, fb, lg);
-            const uint32_t act0 = pick_action(lg[0], g, lane), act1 = pick_action(lg[1], g, lane);
-            uint32_t action = (g >> 1) ? act1 : act0;
+            f32x4 lg[kNt];
+            {
+                uint32_t own[8], fb[kNt][8];
+                {
+                    Board s;
+                    unpack_board(A, B, s);
+                    board_features(s, (int)p.L, (int)p.M, own);
+                }
+                column_features(own, c, fb);
+                policy_logits(at, g, fb, lg);
+            }
+            uint32_t action = own_action(lg, g, lane);
             action = explore(action, q.explore_seed, (uint64_t)(p.global_offset + b), q.step0 + t, q.eps_q24);
             uint32_t rot, loc;
             split_small_action(action, rot, loc);
             float reward;
             Tally mine;
+            Board s;
+            unpack_board(A, B, s);
+            uint32_t cfg = current_config(s, p, (uint32_t)b, clock + t);
             const bool done = advance_board<kAutoReset>(s, cfg, rot, loc, p, (uint32_t)b, clock + t, s_shape, reward, mine);
-            if (valid && writer) {
-                tally.episodes += mine.episodes; tally.lines += mine.lines;
-                tally.wins += mine.wins; tally.topouts += mine.topouts;
+            pack_board(s, A, B);
+            if (valid) {
+                if (mine.episodes) {
+                    atomicAdd(&s_stat[0], mine.episodes);
+                    if (mine.lines) atomicAdd(&s_stat[1], mine.lines);
+                    if (mine.wins) atomicAdd(&s_stat[2], mine.wins);
+                    if (mine.topouts) atomicAdd(&s_stat[3], mine.topouts);
+                }
                 if (q.actions) q.actions[(size_t)t * p.n + b] = (uint8_t)action;
                 if (q.rewards) q.rewards[(size_t)t * p.n + b] = reward;
                 if (q.dones) q.dones[(size_t)t * p.n + b] = done ? 1 : 0;
             }
         }
-        if (valid && writer) {
-            uint4 A, B;
-            pack_board(s, A, B);
+        if (valid) {
             p.plane_a[b] = A;
             p.plane_b[b] = B;
             if ((b & (kClockGroup - 1)) == 0) p.clock[b >> kClockShift] = clock + q.T;
         }
     }
-    flush_tally(tally, s_stat, p.stats);
+    __syncthreads();
+    if (threadIdx.x < 4) {                                        // as flush_tally: one sharded 64-bit atomic per counter
+        const uint32_t v = s_stat[threadIdx.x];
+        if (v) atomicAdd(&p.stats[(size_t)(blockIdx.x % kStatShards) * kStatStride + threadIdx.x], (unsigned long long)v);
+    }
 }
 
 }  // namespace p16
@@ -444,8 +507,8 @@ extern "C" int tpl_policy_act(tpl_env* e, const void* image, uint8_t* action, fl
     p.diag = (unsigned long long*)logits;    // the diagnostic build writes its stamps where the logits would go
     p.logits = nullptr;
 #endif
-    // one resident workgroup per CU (the weights fill its LDS), eight waves of 32 boards, looping over board tiles
-    const int64_t groups = ((e->n + 31) / 32 + kPolicyWaves - 1) / kPolicyWaves;
+    // one resident workgroup per CU (the weights fill its LDS), eight waves of 64 boards, looping over board tiles
+    const int64_t groups = ((e->n + 63) / 64 + kPolicyWaves - 1) / kPolicyWaves;
     hipLaunchKernelGGL(policy_kernel, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(64 * kPolicyWaves), 0, (hipStream_t)stream, p);
     TPL_HIP(hipGetLastError());
     return TPL_OK;
@@ -479,7 +542,7 @@ extern "C" int tpl_actor_rollout(tpl_env* e, const void* image, int32_t num_step
     q.image = (const uint4*)image; q.T = (uint32_t)num_steps; q.step0 = step0;
     q.eps_q24 = (uint32_t)(epsilon * 16777216.0f); q.explore_seed = seed;
     q.actions = actions; q.rewards = rewards; q.dones = dones; q.states_a = (uint4*)states_a; q.states_b = (uint4*)states_b;
-    const int64_t groups = ((e->n + 31) / 32 + 7) / 8;
+    const int64_t groups = ((e->n + 63) / 64 + 7) / 8;
     const dim3 grid((unsigned)(groups < 256 ? groups : 256)), block(512);
     if (e->auto_reset) hipLaunchKernelGGL(actor_rollout_kernel<true>, grid, block, 0, (hipStream_t)stream, q);
     else hipLaunchKernelGGL(actor_rollout_kernel<false>, grid, block, 0, (hipStream_t)stream, q);

@@ -25,8 +25,22 @@ for _ in range(200):                                                      # let 
     env.policy_act(image, out=out, logits=stamps)
 torch.cuda.synchronize()
 waves = 256 * 8
-d = stamps.view(torch.int64).flatten()[: 2 * waves].view(waves, 2).cpu()
-clk = [100e6 * float(a) / float(b) / 1e9 for a, b in d.tolist() if b > 0]
-dur = [float(b) / 100.0 for a, b in d.tolist() if b > 0]
+d = stamps.view(torch.int64).flatten()[: 4 * waves].view(waves, 4).cpu()
+rows = [r for r in d.tolist() if r[1] > 0]
+clk = [100e6 * float(a) / float(b) / 1e9 for a, b, _, _ in rows]
+dur = [float(b) / 100.0 for _, b, _, _ in rows]
+pro = [float(c) / 100.0 for _, _, c, _ in rows]
+first = min(e for _, _, _, e in rows)
+start = [(e - first) / 100.0 for _, _, _, e in rows]
+end = [(e - first + c + b) / 100.0 for _, b, c, e in rows]
 print(f"waves {len(clk)}: in-kernel clock median {statistics.median(clk):.3f} GHz (min {min(clk):.3f}, max {max(clk):.3f}); "
-      f"tile loop median {statistics.median(dur):.1f} us")
+      f"tile loop median {statistics.median(dur):.1f} us (min {min(dur):.1f}, max {max(dur):.1f}); entry -> weights in LDS median "
+      f"{statistics.median(pro):.1f} us (max {max(pro):.1f}); waves start within {max(start):.1f} us of the first; last wave out "
+      f"{max(end):.1f} us after the first wave started")
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(100):
+    env.policy_act(image, out=out, logits=stamps)
+e1.record()
+torch.cuda.synchronize()
+print(f"launch period {e0.elapsed_time(e1) * 10:.1f} us")
