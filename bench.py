@@ -360,14 +360,18 @@ def measure_actor_loop(torch, T, dev, L, M, boards, seed):
            "arithmetic": {"value": "bf16 operands, f32 accumulation (megakernel)", "fused_mfma_kernel": "bf16 operands, f32 accumulation",
                           "fused_f32_kernel": "float32 operands and accumulation: the reference's nn.Linear width (model/model.py:9-20)",
                           "f32_megakernel": "float32 operands and accumulation (v_mfma_f32_16x16x4_f32), T steps per launch",
+                          "fused_split_kernel": "float32 accuracy on the bf16 pipe: every weight and activation as three bf16 pieces, "
+                                                "six v_mfma_f32_16x16x32_bf16 per product, float32 accumulation (within the float32 "
+                                                "kernel's tolerance of a float64 evaluation; not bit-identical to a float32 FMA chain)",
                           "megakernel": "bf16 operands, f32 accumulation, T steps per launch",
                           "torch_linear_layers": "torch bf16 Linear layers (hipBLASLt)",
                           "torch_linear_layers_f32": "torch float32 Linear layers (hipBLASLt)"}}
     for name, use_fused, dtype in (("fused_mfma_kernel", True, torch.bfloat16), ("fused_f32_kernel", True, torch.float32),
+                                   ("fused_split_kernel", True, torch.float32),
                                    ("torch_linear_layers", False, torch.bfloat16), ("torch_linear_layers_f32", False, torch.float32)):
         torch.manual_seed(0)
         # two launches per iteration when fused: a graph replay costs more than it saves there
-        actor = T.Actor(env, T.PolicyMLP(), dtype=dtype, use_graph=not use_fused, fused=use_fused)
+        actor = T.Actor(env, T.PolicyMLP(), dtype=dtype, use_graph=not use_fused, fused=use_fused, split=name == "fused_split_kernel")
         actor.run(20)
         torch.cuda.synchronize(dev)
         ms = timed(torch, dev, actor.step, 300 if dtype is torch.bfloat16 else 60)
@@ -406,6 +410,16 @@ def measure_actor_loop(torch, T, dev, L, M, boards, seed):
     tflops = 2.0 * (224 * 128 + 3 * 128 * 128 + 128 * 16) * boards / (ms * 1e-3) / 1e12
     out["policy_kernel_f32"] = {"ms": ms, "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS,
                                                        "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS}}
+    image_split = T.actor.policy_image(T.PolicyMLP(), dev, f32="split")
+    for _ in range(3):
+        env.policy_act(image_split, out=act)
+    ms_s = timed(torch, dev, lambda: env.policy_act(image_split, out=act), 20)
+    # six bf16 MFMAs per product in the hidden layers and the head, three in layer 1: the FLOPs it ISSUES against the bf16 peak
+    issued = 2.0 * (3 * 224 * 128 + 6 * 3 * 128 * 128 + 6 * 128 * 16) * boards / (ms_s * 1e-3) / 1e12
+    out["policy_kernel_split"] = {"ms": ms_s, "speedup_over_policy_kernel_f32": ms / ms_s,
+                                  "roofline": {"bound": "mfma", "achieved": issued, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                               "frac": issued / MFMA_BF16_PEAK_TFLOPS,
+                                               "note": "bf16 FLOPs issued (3-6 per float32-grade product), not model FLOPs"}}
     env.terminate()
     return out
 

@@ -227,6 +227,16 @@ size_t tpl_policy_image_bytes_f32(void);
 int tpl_policy_pack_f32(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                         const float* b3, const float* w4, const float* b4, const float* w5, const float* b5, void* image);
 int tpl_policy_act_f32(tpl_env* env, const void* image, uint8_t* action, float* logits, void* stream);
+/* The same policy at FLOAT32 ACCURACY on the bf16 matrix pipe (csrc/policy_split.hip): every float32 weight and
+ * activation is the sum of three bf16 numbers (8 + 8 + 8 significand bits), a product is six
+ * v_mfma_f32_16x16x32_bf16 (three in layer 1, whose inputs are exact in bf16) accumulated in float32 -- 2.7 x less
+ * matrix time than eight v_mfma_f32_16x16x4_f32, measured 2.1 x on the kernel.  Within the float32 kernel's tolerance of
+ * a float64 evaluation of model/model.py:9-20 (2e-5 (1 + max|logit|)); not bit-identical to a float32 FMA chain.  The
+ * image (tpl_policy_pack_split, same arguments as tpl_policy_pack) is tpl_policy_image_bytes_split() bytes. */
+size_t tpl_policy_image_bytes_split(void);
+int tpl_policy_pack_split(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                          const float* b3, const float* w4, const float* b4, const float* w5, const float* b5, void* image);
+int tpl_policy_act_split(tpl_env* env, const void* image, uint8_t* action, float* logits, void* stream);
 /* Epsilon-greedy exploration on an action array: with probability epsilon action[i] is replaced by a uniform
  * action in [0, 40), a function of (seed, global board index, step) alone: steps 2j and 2j + 1 of a board share one 32-bit
  * hash word of (seed, index, j) and take sixteen bits of it each, (bits * 40) >> 16 -- every action within 40 / 65536 of 1/40;

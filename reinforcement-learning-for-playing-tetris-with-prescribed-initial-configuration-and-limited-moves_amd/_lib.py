@@ -27,7 +27,7 @@ _LIBDIR = os.path.join(_ROOT, "lib")
 LIB_PATH = os.path.join(_LIBDIR, "libtetris_piclim_diag.so" if _DIAG else
                         f"libtetris_piclim_{_EXTRA}.so" if _EXTRA else "libtetris_piclim.so")
 _UNITS = [os.path.join(_CSRC, f) for f in ("tetris_piclim.hip", "carve_generator.hip", "carve_device.hip",
-                                           "forward_generator.hip", "policy_mlp.hip", "policy_f32.hip", "observe.hip")]
+                                           "forward_generator.hip", "policy_mlp.hip", "policy_f32.hip", "policy_split.hip", "observe.hip")]
 _SOURCES = _UNITS + [os.path.join(_CSRC, "tpl_device.h"), os.path.join(_CSRC, "tpl_internal.h"),
                      os.path.join(_CSRC, "tpl_step.h"), os.path.join(_CSRC, "tpl_observe.h"), os.path.join(_CSRC, "tpl_policy.h"), os.path.join(_CSRC, "py_random.h"),
                      os.path.join(_ROOT, "include", "tetris_piclim.h")]
@@ -41,6 +41,7 @@ SYMBOLS = [
     "tpl_generate_configs_device_work_bytes", "tpl_generate_configs_device", "tpl_generate_configs_device_waves",
     "tpl_policy_image_bytes", "tpl_policy_pack", "tpl_policy_act",
     "tpl_policy_image_bytes_f32", "tpl_policy_pack_f32", "tpl_policy_act_f32",
+    "tpl_policy_image_bytes_split", "tpl_policy_pack_split", "tpl_policy_act_split",
     "tpl_explore_actions", "tpl_actor_rollout", "tpl_actor_rollout_f32", "tpl_pool_info", "tpl_pool_set_hold", "tpl_note_steps", "tpl_clock_ptr", "tpl_stream_create", "tpl_stream_destroy",
 ]
 
@@ -151,6 +152,10 @@ def lib() -> C.CDLL:
     L.tpl_policy_image_bytes.argtypes = []
     L.tpl_policy_pack.argtypes = [vp] * 11
     L.tpl_policy_act.argtypes = [vp, vp, vp, vp, vp]
+    L.tpl_policy_image_bytes_split.restype = sz
+    L.tpl_policy_image_bytes_split.argtypes = []
+    L.tpl_policy_pack_split.argtypes = [vp] * 11
+    L.tpl_policy_act_split.argtypes = [vp, vp, vp, vp, vp]
     L.tpl_policy_image_bytes_f32.restype = sz
     L.tpl_policy_image_bytes_f32.argtypes = []
     L.tpl_policy_pack_f32.argtypes = [vp] * 11
@@ -262,9 +267,10 @@ def forward_generate(L: int, M: int, seeds, initial_height_max: int = 4, max_att
     return out
 
 
-def pack_policy(params, f32: bool = False):
+def pack_policy(params, f32=False):
     """Five (weight, bias) pairs of Model(217, 14) (float32 numpy, torch layout) -> packed image (numpy uint8): for the
-    bf16 kernel (weights rounded to bf16) or, f32=True, for the float32 kernel (weights as they are)."""
+    bf16 kernel (weights rounded to bf16), f32=True for the float32 kernel (weights as they are), or f32="split" for the
+    kernel that reaches float32 accuracy on the bf16 matrix pipe (every weight as three bf16 pieces)."""
     import numpy as np
     flat = []
     for w, b in params:
@@ -273,7 +279,12 @@ def pack_policy(params, f32: bool = False):
     want = [(128, 217), (128,), (128, 128), (128,), (128, 128), (128,), (128, 128), (128,), (14, 128), (14,)]
     if shapes != want:
         raise ValueError(f"policy parameters must have shapes {want}, got {shapes}")
-    size, pack = (lib().tpl_policy_image_bytes_f32(), lib().tpl_policy_pack_f32) if f32 else (lib().tpl_policy_image_bytes(), lib().tpl_policy_pack)
+    if f32 == "split":
+        size, pack = lib().tpl_policy_image_bytes_split(), lib().tpl_policy_pack_split
+    elif f32:
+        size, pack = lib().tpl_policy_image_bytes_f32(), lib().tpl_policy_pack_f32
+    else:
+        size, pack = lib().tpl_policy_image_bytes(), lib().tpl_policy_pack
     image = np.empty(size, np.uint8)
     check(pack(*[a.ctypes.data_as(C.c_void_p) for a in flat], image.ctypes.data_as(C.c_void_p)))
     return image

@@ -33,9 +33,10 @@ class PolicyMLP(nn.Module):
         return self.layer5(x)
 
 
-def policy_image(model: nn.Module, device, f32: bool = False) -> torch.Tensor:
-    """The packed image of a PolicyMLP for the fused kernels, on `device`: weights rounded to bf16, or (f32=True)
-    float32 as they are -- the reference's arithmetic width (model/model.py:9-20)."""
+def policy_image(model: nn.Module, device, f32=False) -> torch.Tensor:
+    """The packed image of a PolicyMLP for the fused kernels, on `device`: weights rounded to bf16, (f32=True)
+    float32 as they are -- the reference's arithmetic width (model/model.py:9-20) -- or (f32="split") every weight as
+    three bf16 pieces: float32 accuracy on the bf16 matrix pipe."""
     from ._lib import pack_policy
     layers = [model.layer1, model.layer2, model.layer3, model.layer4, model.layer5]
     params = [(l.weight.detach().float().cpu().numpy(), l.bias.detach().float().cpu().numpy()) for l in layers]
@@ -47,12 +48,15 @@ class Actor:
 
     fused=False: observation kernel -> torch Linear layers -> decode kernel -> step kernel.
     fused=True:  one MFMA kernel from the 32-B board state to the action -> step kernel; with dtype=torch.float32 the
-                 float32 kernel (csrc/policy_f32.hip), otherwise the bf16 one (csrc/policy_mlp.hip)."""
+                 float32 kernel (csrc/policy_f32.hip) or, split=True, the kernel that reaches float32 accuracy with three
+                 bf16 pieces per number (csrc/policy_split.hip, twice as fast); otherwise the bf16 one (csrc/policy_mlp.hip)."""
 
     def __init__(self, env: BatchedTetris, model: nn.Module, dtype=torch.bfloat16, use_graph: bool = True,
-                 fused: bool = False):
+                 fused: bool = False, split: bool = False):
         self.env, self.dtype, self.fused = env, dtype, fused
-        self.image = policy_image(model, env.device, f32=dtype is torch.float32) if fused else None
+        if split and not (fused and dtype is torch.float32):
+            raise ValueError("split=True goes with fused=True and dtype=torch.float32")
+        self.image = policy_image(model, env.device, f32=("split" if split else dtype is torch.float32)) if fused else None
         self.model = model.to(device=env.device, dtype=dtype).eval()
         n, d = env.num_envs, env.device
         self.obs = torch.empty((n, OBS_DIM), dtype=dtype, device=d)

@@ -105,7 +105,7 @@ __device__ __forceinline__ void start_chunk(uint4* dst, const uint4* src, int by
     typedef __attribute__((address_space(1))) const void global_ptr;
     typedef __attribute__((address_space(3))) void lds_ptr;
     const int pieces = bytes / 16;
-    const int wave = (int)threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);      // uniform: the chunk offsets stay scalar
     // The lane's byte offset is made opaque HERE, at every call: the source addresses of a chunk are loop-invariant 64-bit
     // values per lane, and left alone the compiler computes all of them (eight per chunk, six chunks) ahead of the pass loop
     // and keeps them -- twenty-one registers' worth went to scratch in a kernel that has none to spare.
@@ -241,7 +241,7 @@ constexpr int kWaves = 8;
 __global__ __launch_bounds__(64 * kWaves) void policy_f32_kernel(const PolicyF32Args p) {
     __shared__ uint4 s_buf[2][kBufBytes / 16];
     __shared__ float s_bias[4 * kHidden + 16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // (a scalar)
     const int c = lane & 15, g = lane >> 4;
     const int64_t tiles = (p.n + 31) / 32;
     const int64_t tile_step = (int64_t)gridDim.x * kWaves;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64 * kWaves) void actor_rollout_f32_kernel(const Ac
     __shared__ float s_bias[4 * kHidden + 16];
     __shared__ ShapeWord s_shape[32];
     __shared__ uint32_t s_stat[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // (a scalar)
     const int c = lane & 15, g = lane >> 4;
     const bool writer = (g & 1) == 0;
     const int64_t tiles = (p.n + 31) / 32;

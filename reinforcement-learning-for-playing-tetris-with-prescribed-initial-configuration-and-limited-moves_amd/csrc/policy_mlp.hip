@@ -55,19 +55,6 @@ constexpr int kOffB = kOffW5 + kKsH * 1024;                    // 159744
 constexpr int kImageBytes = kOffB + (4 * kHidden + 16) * 4;    // 161856
 static_assert(kImageBytes <= 160 * 1024 - 512, "policy image + shape table must fit the CU's LDS");
 
-static inline uint16_t bf16_rne(float f) {
-    uint32_t u;
-    std::memcpy(&u, &f, 4);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
-    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
-
-// k of element j of lane group g in k-step s.  Hidden layers: dictated by the accumulator hand-off.
-static inline int frag_k(int s, int g, int j) { return 32 * s + 16 * (j >> 2) + 4 * g + (j & 3); }
-// Layer 1 is free to choose, because its B fragments are made from bits: the two elements of register i come from
-// bits 4g + i and 16 + 4g + i of feature word s, so that one shift and one mask turn the word into the register.
-static inline int frag_k1(int s, int g, int j) { return 32 * s + 4 * g + (j >> 1) + 16 * (j & 1); }
-
 }  // namespace p16
 }  // namespace tpl
 

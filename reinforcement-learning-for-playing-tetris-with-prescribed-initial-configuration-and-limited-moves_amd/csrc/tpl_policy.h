@@ -5,6 +5,8 @@
 #pragma once
 
 #include "tpl_internal.h"
+
+#include <cstring>
 #include "tpl_step.h"
 
 namespace tpl {
@@ -36,6 +38,20 @@ static inline int std_feature(int k) {
     if (k < 200) return (k % 20) * 10 + (k / 20);
     return k < kObs ? k : -1;
 }
+
+// host side of the packers: float -> bf16, round to nearest even
+static inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+// k of element j of lane group g in k-step s.  Hidden layers: dictated by the accumulator hand-off.
+static inline int frag_k(int s, int g, int j) { return 32 * s + 16 * (j >> 2) + 4 * g + (j & 3); }
+// Layer 1 is free to choose, because its B fragments are made from bits: the two elements of register i come from
+// bits 4g + i and 16 + 4g + i of feature word s, so that one shift and one mask turn the word into the register.
+static inline int frag_k1(int s, int g, int j) { return 32 * s + 4 * g + (j >> 1) + 16 * (j & 1); }
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     f32x2 v = {a, b};

@@ -459,15 +459,19 @@ class BatchedTetris:
         if out is None:
             out = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
         self._own(out, torch.uint8, "out")
-        f32 = self._image(image, either=True)
+        kind = self._image(image, either=True, split=True)
         if logits is not None:
             self._own(logits, torch.float32, "logits", (self.num_envs, 14))
-        act = self._lib.tpl_policy_act_f32 if f32 else self._lib.tpl_policy_act
+        act = {"split": self._lib.tpl_policy_act_split, True: self._lib.tpl_policy_act_f32, False: self._lib.tpl_policy_act}[kind]
         check(act(self._h, _ptr(image), _ptr(out), _ptr(logits), self._stream()))
         return out
 
-    def _image(self, image: torch.Tensor, either: bool = False) -> bool:
-        """Checks a policy image; returns True for the float32 kind (accepted only where `either`)."""
+    def _image(self, image: torch.Tensor, either: bool = False, split: bool = False):
+        """Checks a policy image; returns False for the bf16 kind, True for the float32 kind (accepted only where `either`),
+        "split" for the three-piece kind (only where `split`)."""
+        if split and isinstance(image, torch.Tensor) and image.numel() == self._lib.tpl_policy_image_bytes_split():
+            self._own(image, torch.uint8, "image (the device copy of pack_policy(..., f32='split'))", (image.numel(),))
+            return "split"
         if either and isinstance(image, torch.Tensor) and image.numel() == self._lib.tpl_policy_image_bytes_f32():
             self._own(image, torch.uint8, "image (the device copy of pack_policy(..., f32=True))", (image.numel(),))
             return True
