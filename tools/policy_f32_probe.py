@@ -25,5 +25,5 @@ for _ in range(20):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
-tf = 2.0 * (224 * 128 + 3 * 128 * 128 + 128 * 16) * n / (ms * 1e-3) / 1e12
+tf = 2.0 * (217 * 128 + 3 * 128 * 128 + 128 * 14) * n / (ms * 1e-3) / 1e12
 print(f"policy_f32 {n} boards: {ms * 1e3:.1f} us = {tf:.1f} TFLOP/s = {tf / 157.3:.3f} of the f32 MFMA peak")

@@ -106,7 +106,7 @@ def main():
     stop.set()
     th.join()
     us = e0.elapsed_time(e1) * 1e3 / launches
-    tf = 2.0 * (224 * 128 + 3 * 128 * 128 + 128 * 16) * n / (us * 1e-6) / 1e12
+    tf = 2.0 * (217 * 128 + 3 * 128 * 128 + 128 * 14) * n / (us * 1e-6) / 1e12
     print(json.dumps({"kernel": "tpl::p16::policy_kernel", "boards": n, "launches": launches, "us_per_launch_incl_sync_gaps": us,
                       "tflops": tf, "frac_of_2500": tf / 2500}))
 

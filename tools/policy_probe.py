@@ -26,5 +26,5 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
-tf = 2.0 * (224 * 128 + 3 * 128 * 128 + 128 * 16) * n / (ms * 1e-3) / 1e12
+tf = 2.0 * (217 * 128 + 3 * 128 * 128 + 128 * 14) * n / (ms * 1e-3) / 1e12
 print(f"policy_bf16 {n} boards: {ms * 1e3:.2f} us = {tf:.0f} TFLOP/s = {tf / 2500:.3f} of the bf16 MFMA peak")
