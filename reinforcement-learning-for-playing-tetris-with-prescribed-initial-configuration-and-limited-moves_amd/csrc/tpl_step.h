@@ -228,8 +228,9 @@ __device__ __forceinline__ bool advance_board_lds(Board& s, uint32_t* cols, cons
     // window is down to its last two entries and the next piece word replaces it
     until_refill -= 1u;
     const bool refill = until_refill == 0u && (p.n_cfg[0] | p.n_cfg[1]) != 0u;
-    // (read only where `refill` is set: any value will do elsewhere -- initialising it costs two instructions a step)
-    uint64_t word;
+    // (read only where `refill` is set: any value will do elsewhere -- initialising it costs two instructions a step.  "Any
+    // value" is said to the compiler in so many words: an unspecified but valid value, not an uninitialised read)
+    uint64_t word = __builtin_nondeterministic_value(word);
     if (refill) {
         word = *(const uint64_t*)next_word;
         next_word += 8;
