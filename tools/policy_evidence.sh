@@ -14,8 +14,10 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k
 timeout -k 10 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc -- $B > $OUT/pmc.log 2>&1 || echo "pmc failed"
 python3 - $OUT <<'PY'
 import csv, glob, json, os, sys
+sys.path.insert(0, "tools")
+from profile_stamp import stamp
 d = sys.argv[1]
-out = {}
+out = {"stamp": stamp()}
 for f in glob.glob(os.path.join(d, "kt", "*", "*_kernel_stats.csv")):
     for row in csv.DictReader(open(f)):
         if "policy_kernel" in row["Name"]:

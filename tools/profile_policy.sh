@@ -14,8 +14,10 @@ for P in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
 done
 python3 - "$OUT" <<'PY'
 import collections, csv, glob, json, os, sys
+sys.path.insert(0, "tools")
+from profile_stamp import stamp
 d = sys.argv[1]
-out = {}
+out = {"stamp": stamp()}
 for f in sorted(glob.glob(os.path.join(d, "pmc_*", "*", "*_counter_collection.csv"))):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for row in csv.DictReader(open(f)):
