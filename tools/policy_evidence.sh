@@ -38,3 +38,5 @@ json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
 head -c 400 $OUT/power_trace.jsonl; echo; cat $OUT/in_kernel_clock.log | tail -2
+# the raw per-dispatch tables are large (gpurun brings back 64 MiB at most): the summary holds what is kept
+find $OUT -name "*_counter_collection.csv" -delete; find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "*.db" -delete

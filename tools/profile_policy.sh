@@ -34,3 +34,5 @@ for f in glob.glob(os.path.join(d, "kt", "*", "*_kernel_stats.csv")):
 json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
+# the raw per-dispatch tables are large (gpurun brings back 64 MiB at most): the summary holds what is kept
+find $OUT -name "*_counter_collection.csv" -delete; find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "*.db" -delete
