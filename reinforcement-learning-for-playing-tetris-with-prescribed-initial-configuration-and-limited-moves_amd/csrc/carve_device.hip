@@ -274,6 +274,10 @@ template <typename T> __device__ __forceinline__ void lds_store(T* p, T v) {
 // persistent wave keeps its place for the whole launch (trips of 1.2 to 2.7 us side by side, profiles/r04_carve/NOTES).
 constexpr int kWavesPerBlock = 4;
 constexpr int kQueueChunk = 16;            // configurations a wave takes from the queue per atomic
+// trips of the search between two looks at the queue, the helpers and the state words: 32 where a search takes hundreds of
+// trips or more (L >= 8: median 400 and up), 8 below (measured at L = 10, 2^20 configurations: 4 -> 50 M/s, 8 -> 55, 16 -> 56,
+// 32 -> 57; at L = 5 a search is 190 trips and a lane whose attempt ends sits out the rest of its burst)
+__device__ __forceinline__ int burst_shift(int L) { return L >= 8 ? 5 : 3; }
 
 // waves_per_eu(4, 4): the register count is reported high enough that a SIMD holds no more than four of these waves --
 // with the LDS padding at the launch (four blocks to a CU) the only placement left is four waves on every SIMD
@@ -315,7 +319,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     int32_t k = 0;                         // what this lane is running: configuration,
     int attempt = 0, home = lane;          // attempt, and the lane that took the configuration from the queue
     int64_t limit = 0;                     // iterations this attempt may use
-    uint32_t trip = 0;
+    uint32_t trip = 0;                     // bursts so far
+    const int shift = burst_shift(p.L);    // log2 of a burst's trips
     // the wave's share of the queue: configurations [res_lo, res_hi) are its own to hand to its lanes (wave-uniform values)
     int64_t res_lo = 0, res_hi = 0;
     bool exhausted = false;                // the queue had nothing left when this wave last asked
@@ -337,9 +342,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         // A SIMD issues for its OLDEST wave first: of the four waves a SIMD holds, the one of the first quarter of the grid ran a
         // trip in 1.2 us and the one of the last quarter in 2.5 (profiles/r04_carve/NOTES), which the queue evens out while it
         // has work and nothing does afterwards -- the launch then waits for the youngest waves.  So the issue priority goes
-        // round: every 256 trips a wave takes the next of the four levels, a quarter of the grid on each at any time.
-        if ((trip & 255u) == 0u) {
-            switch (((uint32_t)blockIdx.x / (gridDim.x / 4u + 1u) + (trip >> 8)) & 3u) {
+        // round: every 256 trips (32 bursts) a wave takes the next of the four levels, a quarter of the grid on each at any time.
+        if ((trip & ((256u >> shift) - 1u)) == 0u) {
+            switch (((uint32_t)blockIdx.x / (gridDim.x / 4u + 1u) + (trip >> (8 - shift))) & 3u) {
                 case 0: __builtin_amdgcn_s_setprio(0); break;
                 case 1: __builtin_amdgcn_s_setprio(1); break;
                 case 2: __builtin_amdgcn_s_setprio(2); break;
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         const unsigned long long open = __ballot(owns);
 #ifdef TPL_CARVE_DIAG
         if (w_dry == 0 && __ballot(dry) != 0ULL) w_dry = wall_clock64();
-        if (w_dry != 0) ++w_tail_trips;
+        if (w_dry != 0) w_tail_trips += 1u << shift;
 #endif
         if (open == 0ULL && __ballot(!dry) == 0ULL) break;                   // wave-uniform: nothing left here, nothing to take
         // (2) lanes with nothing to do (the queue is dry) run a further attempt of a configuration of this wave that has no
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         bool won = false;                  // this lane's attempt is the answer: it has finished and every lower one has failed
         // (3) has a lower attempt of my configuration finished (mine cannot be the answer then), or -- holding a finished
         // attempt -- have all lower ones failed?
-        if (mode != kIdle && (trip & 3u) == 0u) {
+        if (mode != kIdle) {
             const unsigned long long st = lds_load(&s_state[home]);
             const uint32_t below = (1u << attempt) - 1u;
             if (finished_of(st) & below) {
@@ -433,15 +438,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
 #endif
             } else if (mode == kHold && (failed_of(st) & below) == below) won = true;
         }
-        // (4) one trip of the search, or the end of the attempt
+        // (4) a burst of the search -- the bookkeeping above is some forty instructions, a trip of the search two hundred: it is
+        // paid once per burst (a lane whose attempt ends inside a burst sits out the rest of it: sixteen trips in 2,500) --
+        // then, if the attempt is over, its end
         if (mode == kRun) {
-            const bool done = solved(g), out = !done && g.iters >= limit;
-            if (!done && !out) {
+#pragma unroll 1
+            for (int r = 0; r < (1 << shift); ++r) {
+                if (solved(g) || g.iters >= limit) break;
                 ++g.iters;
 #ifdef TPL_CARVE_DIAG
                 ++d_iters;
 #endif
                 search_iteration(g, w, p);
+            }
+            const bool done = solved(g), out = !done && g.iters >= limit;
+            if (!done && !out) {
+                // the attempt goes on
             } else if (done) {
                 const unsigned long long bit = 1ULL << (kCarveAttempts + attempt);
                 const unsigned long long st = atomicOr(&s_state[home], bit) | bit;

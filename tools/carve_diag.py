@@ -59,7 +59,7 @@ def main():
         q = lambda a: " ".join(f"{v:.2f}" for v in np.percentile(a, [0, 10, 50, 90, 99, 100]))
         print(f"    per wave (min p10 p50 p90 p99 max): out of the loop {q((wd[:, 1] - t0) / 100e3)} ms after the start; {q(tail_ms)} ms after "
               f"its first lane found the queue dry; trips after that {q(wd[:, 3])}; us per trip after that {q(tail_ms * 1e3 / np.maximum(wd[:, 3], 1))}; "
-              f"us per trip before {q((wd[:, 0] - t0) / 100.0 / np.maximum(wd[:, 2] - wd[:, 3], 1))}", flush=True)
+              f"us per trip before {q((wd[:, 0] - t0) / 100.0 / np.maximum((32 if args.L >= 8 else 8) * wd[:, 2] - wd[:, 3], 1))}", flush=True)
 
 
 if __name__ == "__main__":
