@@ -112,18 +112,24 @@ __device__ __forceinline__ bool carve(uint32_t* col, uint32_t& bottom, const DSh
     uint32_t revtopo;
     int drop = drop_of(d, s, revtopo);
     drop += (int)revtopo + 1;                                               // :298-301
-    const int tries = allow_partial ? (int)s.h : 1;                         // :304
-    for (int t = 0; t < tries; ++t, --drop) {
-        if (try_carve(d, drop, s, allow_partial, after)) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                under[k * kColStride] = after[k];
-                bottom -= ((d[k] ^ after[k]) >> (kRows - 1)) & 1u;
-            }
-            return true;
+    // :304 -- the first piece of a configuration may stick out of the stack and is tried at h depths; every other carve has
+    // ONE try, and that is the path every trip takes: it is written without the loop (whose bookkeeping -- a dozen scalar
+    // instructions and two branches -- would be paid by every carve of every trip)
+    bool ok = try_carve(d, drop, s, allow_partial, after);
+    if (!ok && allow_partial) {
+        for (int t = 1; t < (int)s.h && !ok; ++t) {
+            --drop;
+            ok = try_carve(d, drop, s, true, after);
         }
     }
-    return false;
+    if (ok) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            under[k * kColStride] = after[k];
+            bottom -= ((d[k] ^ after[k]) >> (kRows - 1)) & 1u;
+        }
+    }
+    return ok;
 }
 
 constexpr uint32_t kFullBag = 0u | 1u << 3 | 2u << 6 | 3u << 9 | 4u << 12 | 5u << 15 | 6u << 18;
