@@ -446,7 +446,7 @@ typedef struct {
     int n_pieces;
 } carve_checkpoint;
 
-int64_t to_generate_config(int L, int M, to_randint_fn randint, void* ctx, int64_t max_iters,
+int64_t to_generate_config(int L, int M, to_randint_fn randint, void* ctx, to_phase_fn search_over, int64_t max_iters,
                            uint16_t* rows, uint8_t* pieces_out, uint8_t* solution, int32_t* sol_len) {
     /* game state: board, pieces (front = first to fall), solution (parallel to the carved prefix of pieces) */
     uint8_t pieces[256];
@@ -524,6 +524,7 @@ int64_t to_generate_config(int L, int M, to_randint_fn randint, void* ctx, int64
         }
     }
     free(cps);
+    if (search_over) search_over(ctx);               /* the source of decisions is told that the loop of :234 has ended */
     if (sol_len) *sol_len = n_pieces;
     if (solution) memcpy(solution, sol, (size_t)n_pieces * 2);
     /* :281-284  pad with get_random_sequence(M - len + 1) (:95-102): the leftover bag is shuffled first */
@@ -556,7 +557,7 @@ static int32_t tape_randint(void* vctx, int32_t lo, int32_t hi) {
 int64_t to_generate_config_tape(int L, int M, const int32_t* tape, int64_t n, int64_t* consumed,
                                 uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* sol_len) {
     tape_ctx t = {tape, n, 0, 0};
-    int64_t it = to_generate_config(L, M, tape_randint, &t, 0, rows, pieces, solution, sol_len);
+    int64_t it = to_generate_config(L, M, tape_randint, &t, NULL, 0, rows, pieces, solution, sol_len);
     if (consumed) *consumed = t.pos;
     return t.bad ? -2 : it;
 }
@@ -564,22 +565,36 @@ int64_t to_generate_config_tape(int L, int M, const int32_t* tape, int64_t n, in
 /* The counter-driven decision stream and the restart rule (the build's own definitions; the carving
  * logic above is the reference's).
  *
- * Stream: attempt `a` of configuration `index` owns the word  w = to_rng(seed, 4, index, a);  its decision k is the 32-bit
- * murmur3 finaliser of  low32(w) + k * (high32(w) | 1);  the top 24 bits are reduced to [lo, hi] as
- * lo + ((top24 * (hi - lo + 1)) >> 24).
+ * Stream: attempt `a` of configuration `index` owns the word  w = to_rng(seed, 4, index, a);  its k-th stream word is the
+ * 32-bit murmur3 finaliser of  low32(w) + k * (high32(w) | 1).  While the search loop (:234) runs, ONE stream word serves the
+ * three decisions of a trip, asked for in the reference's order: bag index (:85) = (bits 31-20 * n) >> 12, rotations (:250) =
+ * bits 19-18, location (:253) = (bits 17-0 * n) >> 18, n = hi - lo + 1.  After the loop (the shuffles of :93) every decision
+ * takes a stream word of its own, its top 24 bits reduced to [lo, hi] as lo + ((top24 * (hi - lo + 1)) >> 24).
  *
  * Restart rule: the configuration is what the FIRST attempt a = 0, 1, ... 23 builds whose search loop (:234) ends within
  * limit(a) = base << (a / 6) trips, base = `cutoff` if positive, else the table below (about twice the median search length
  * at that L).  Every attempt starts from the full stack with its own stream.  If all 24 attempts run into their limit the
  * configuration is capped: all-zero rows and pieces, no solution, return value -1. */
-typedef struct { uint32_t key, stride, counter; } seeded_ctx;
+typedef struct { uint32_t key, stride, counter, word; int asked, searching; } seeded_ctx;
 
 static int32_t seeded_randint(void* vctx, int32_t lo, int32_t hi) {
     seeded_ctx* c = (seeded_ctx*)vctx;
-    uint32_t top24 = fmix32(c->key + c->counter * c->stride) >> 8;
-    c->counter += 1;
-    return lo + (int32_t)(((uint64_t)top24 * (uint64_t)(hi - lo + 1)) >> 24);
+    uint32_t n = (uint32_t)(hi - lo + 1);
+    if (!c->searching) {
+        uint32_t top24 = fmix32(c->key + c->counter * c->stride) >> 8;
+        c->counter += 1;
+        return lo + (int32_t)(((uint64_t)top24 * n) >> 24);
+    }
+    int which = c->asked++ % 3;                      /* the loop asks three times a trip, always in this order */
+    if (which == 0) {
+        c->word = fmix32(c->key + c->counter * c->stride);
+        c->counter += 1;
+        return lo + (int32_t)(((c->word >> 20) * n) >> 12);
+    }
+    if (which == 1) return lo + (int32_t)((c->word >> 18) & 3u);          /* asked as randint(0, 3) */
+    return lo + (int32_t)(((c->word & 0x3FFFFu) * n) >> 18);
 }
+static void seeded_search_over(void* vctx) { ((seeded_ctx*)vctx)->searching = 0; }
 
 #define TO_CARVE_ATTEMPTS 24
 static const int64_t carve_base_limit[17] = {0, 64, 64, 64, 128, 256, 384, 512, 768, 1792, 3328, 5376, 9216, 17408, 36000,
@@ -595,9 +610,9 @@ int64_t to_generate_config_seeded(int L, int M, uint64_t seed, uint64_t index, i
     int64_t total = 0;
     for (int a = 0; a < TO_CARVE_ATTEMPTS; ++a) {
         uint64_t w = to_rng(seed, 4, index, (uint64_t)a);
-        seeded_ctx c = {(uint32_t)w, (uint32_t)(w >> 32) | 1u, 0};
+        seeded_ctx c = {(uint32_t)w, (uint32_t)(w >> 32) | 1u, 0, 0, 0, 1};
         int64_t limit = to_carve_attempt_limit(L, cutoff, a);
-        int64_t it = to_generate_config(L, M, seeded_randint, &c, limit, rows, pieces, solution, sol_len);
+        int64_t it = to_generate_config(L, M, seeded_randint, &c, seeded_search_over, limit, rows, pieces, solution, sol_len);
         if (it >= 0) {
             if (attempt_out) *attempt_out = a;
             return total + it;                       /* iterations spent on this configuration, failed attempts included */

@@ -116,14 +116,16 @@ void to_synth_actions(uint64_t seed, int64_t first, int64_t count, uint64_t step
  * the reference itself made (tests/golden/carving_*.npz -- pins the generator logic bit-exactly) or (b) by the
  * counter-based generator that the product uses.  randint(ctx, lo, hi) returns a value in [lo, hi]. */
 typedef int32_t (*to_randint_fn)(void* ctx, int32_t lo, int32_t hi);
+typedef void (*to_phase_fn)(void* ctx);
 
 /* Tetris.carve(piece, rotations, location, allow_partial) (game/tetris.py:286-311) on rows[20]; returns 1/0. */
 int to_carve(uint16_t* rows, int piece, int rotations, int location, int allow_partial);
 
 /* Tetris._generate_initial_config (game/tetris.py:226-284) for one game.  rows[20], pieces[M+1],
  * solution[M][2] (rotations, location) and *sol_len are outputs.  Returns the number of loop iterations, or -1
- * if max_iters was hit (the reference has no bound). */
-int64_t to_generate_config(int L, int M, to_randint_fn randint, void* ctx, int64_t max_iters,
+ * if max_iters was hit (the reference has no bound).  `search_over` (may be NULL) is called once, when the loop of :234 has
+ * ended and before the padding draws. */
+int64_t to_generate_config(int L, int M, to_randint_fn randint, void* ctx, to_phase_fn search_over, int64_t max_iters,
                            uint16_t* rows, uint8_t* pieces, uint8_t* solution, int32_t* sol_len);
 
 /* (a) tape-driven: tape = [n][3] int32 (lo, hi, value); returns iterations, -2 on a tape mismatch/underrun;

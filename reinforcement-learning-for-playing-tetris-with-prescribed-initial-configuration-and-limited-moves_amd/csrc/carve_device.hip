@@ -167,7 +167,8 @@ __device__ __forceinline__ void search_iteration(Search& g, const Slice& w, cons
     const int max_cps = p.M / 7 + 3;
     bool fresh = false;                                                     // _regenerate (:71-81)
     if (g.n_bag == 0) { g.bag = kFullBag; g.n_bag = 7; fresh = true; }
-    const int idx = g.randint(0, g.n_bag - 1);                              // :85
+    const uint32_t word = decision_word(g.rnd);                             // this trip's three decisions (tpl_device.h)
+    const int idx = word_bag_index(word, g.n_bag);                          // :85
     const uint32_t piece = (g.bag >> (3 * idx)) & 7u;
     if (fresh && g.n_cp < max_cps) {                                        // :239-247
         uint32_t* e = w.cps + g.n_cp * 11;
@@ -182,9 +183,9 @@ __device__ __forceinline__ void search_iteration(Search& g, const Slice& w, cons
         g.top[kCols * kColStride] = tail;
         ++g.n_cp;
     }
-    const int rotations = g.randint(0, 3);                                  // :250
+    const int rotations = word_rotations(word);                             // :250
     const DShape s = shape_of(g.shapes, piece, (uint32_t)rotations);
-    const int loc = g.randint(0, kCols - (int)s.w);                         // :253
+    const int loc = word_location(word, kCols - (int)s.w + 1);              // :253
     if (g.n < p.M && carve(g.col, g.bottom, s, (uint32_t)loc, g.n == 0)) {  // :257
         w.pieces_rev[g.n] = (uint8_t)piece;                                 // insert(0, ...) (:258-260), reversed
         w.sol_rev[2 * g.n] = (uint8_t)rotations;

@@ -21,10 +21,29 @@ namespace tpl {
 
 namespace {
 
-struct Decisions {
+// The two sources of decisions.  A trip of the search asks for a piece and its rotations, then -- the piece's width known --
+// for a location; the padding asks for single numbers.
+struct Decisions {                                       // the build's counter-based stream: one word per trip (tpl_device.h)
     DecisionStream s;
+    uint32_t word = 0;
     Decisions(uint64_t seed, uint64_t index, uint32_t attempt) : s(decision_stream(seed, index, attempt)) {}
+    void piece_and_rotations(int n_bag, int& idx, int& rotations) {
+        word = decision_word(s);
+        idx = word_bag_index(word, n_bag);
+        rotations = word_rotations(word);
+    }
+    int location(int places) { return word_location(word, places); }
     int randint(int lo, int hi) { return decision(s, lo, hi); }
+};
+struct PyDecisions {                                     // CPython's stream, drawn from in the reference's order (:85, :250, :253)
+    PyRandom r;
+    explicit PyDecisions(uint64_t seed) : r(seed) {}
+    void piece_and_rotations(int n_bag, int& idx, int& rotations) {
+        idx = r.randint(0, n_bag - 1);
+        rotations = r.randint(0, 3);
+    }
+    int location(int places) { return r.randint(0, places - 1); }
+    int randint(int lo, int hi) { return r.randint(lo, hi); }
 };
 
 struct Shape {
@@ -117,12 +136,12 @@ bool generate_one(int L, int M, Random& rnd, int64_t max_iters, uint16_t* rows_o
         if (max_iters > 0 && iters++ >= max_iters) return false;
         bool fresh_bag = false;                                             // _regenerate (:71-81)
         if (n_bag == 0) { for (int k = 0; k < 7; ++k) bag[k] = (uint8_t)k; n_bag = 7; fresh_bag = true; }
-        const int idx = rnd.randint(0, n_bag - 1);                          // :85
+        int idx, rotations;
+        rnd.piece_and_rotations(n_bag, idx, rotations);                     // :85, :250
         const int piece = bag[idx];
         if (fresh_bag && n_cp < kMaxCheckpoints) checkpoints[n_cp++] = g;   // :239-247
-        const int rotations = rnd.randint(0, 3);                            // :250
         const int width = shape_of(piece, rotations).w;
-        const int loc = rnd.randint(0, kCols - width);                      // :253
+        const int loc = rnd.location(kCols - width + 1);                    // :253
         if (g.n < M && carve(g.col, piece, rotations, loc, g.n == 0)) {     // :257
             std::memmove(g.pieces + 1, g.pieces, (size_t)g.n);              // insert(0, ...) (:258-260)
             std::memmove(g.sol + 1, g.sol, (size_t)g.n * 2);
@@ -222,7 +241,7 @@ extern "C" int tpl_generate_configs_pyseed(int32_t L, int32_t M, const uint64_t*
     if (!seeds) return fail_msg(TPL_ERR_ARG, "seeds is null");
     // CPython's stream is the reference's own: one search, no restarts (max_iters > 0 only bounds it)
     return run_generator(L, M, count, threads, rows, pieces, [=](int64_t k) {
-        PyRandom rnd(seeds[k]);
+        PyDecisions rnd(seeds[k]);
         return generate_one(L, M, rnd, max_iters, rows + k * kRows, pieces + k * (M + 1),
                             solution ? solution + k * (int64_t)M * 2 : nullptr, solution_len ? solution_len + k : nullptr);
     });

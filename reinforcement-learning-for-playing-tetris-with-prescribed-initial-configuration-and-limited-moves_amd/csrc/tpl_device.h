@@ -432,8 +432,9 @@ __host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
 // rule below); attempt `a` of configuration `index` owns the 64-bit word  w = rng(seed, 4, index, a)  and its decision k is
 // fmix32(key_k),  key_k = low32(w) + k * stride  (a running add),  stride = high32(w) | 1  -- both halves of the word are
 // used, so two configurations (or two attempts) share a stream only if their 63 bits agree; a stream's period is 2^32
-// decisions.  A decision is reduced to [lo, hi] as  lo + (((d >> 8) * (hi - lo + 1)) >> 24)  -- a 24-bit multiply; the
-// ranges drawn from have at most ten values (a bias below 10 / 2^24), and at most 255 fit.
+// words.  A word serves one trip of the search loop (decision_word below) or one other decision, reduced to [lo, hi] as
+// lo + (((d >> 8) * (hi - lo + 1)) >> 24)  -- a 24-bit multiply; the ranges drawn from have at most ten values (a bias below
+// 10 / 2^24), and at most 255 fit.
 // (Through round 2 every decision was a 64-bit splitmix round and a 64-bit multiply-high: some seven quarter-rate
 // multiplies each, three decisions per iteration of the search; in round 3 the stride was one constant for every stream,
 // so all streams walked one 2^32-cycle from different offsets.)
@@ -442,6 +443,20 @@ __host__ __device__ __forceinline__ DecisionStream decision_stream(uint64_t seed
     const uint64_t w = rng(seed, 4, index, attempt);
     return DecisionStream{(uint32_t)w, (uint32_t)(w >> 32) | 1u};
 }
+// One trip of the search loop (:234-279) makes three decisions -- which piece of the bag (:85), how many rotations (:250), where
+// (:253) -- and takes ONE word of the stream for them: bits 31-20 -> the bag index, (field * n_bag) >> 12; bits 19-18 -> the
+// rotations; bits 17-0 -> the location, (field * places) >> 18 (biases below 7 / 4096 and 10 / 2^18).  Three hashes a trip
+// were a fifth of what a trip cost on the device (two quarter-rate multiplies each).  Every other decision (the shuffles
+// of the padding, :93) takes a word of its own through decision().
+__host__ __device__ __forceinline__ uint32_t decision_word(DecisionStream& s) {
+    const uint32_t w = fmix32(s.key);
+    s.key += s.stride;
+    return w;
+}
+__host__ __device__ __forceinline__ int word_bag_index(uint32_t w, int n_bag) { return (int)(((w >> 20) * (uint32_t)n_bag) >> 12); }
+__host__ __device__ __forceinline__ int word_rotations(uint32_t w) { return (int)((w >> 18) & 3u); }
+__host__ __device__ __forceinline__ int word_location(uint32_t w, int places) { return (int)(((w & 0x3FFFFu) * (uint32_t)places) >> 18); }
+
 __host__ __device__ __forceinline__ int decision(DecisionStream& s, int lo, int hi) {
     const uint32_t d = fmix32(s.key) >> 8;
     s.key += s.stride;
