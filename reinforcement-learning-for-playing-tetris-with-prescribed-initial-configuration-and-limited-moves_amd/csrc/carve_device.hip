@@ -142,7 +142,7 @@ struct Search {
     uint32_t bottom;            // filled cells of the bottom row (the search ends at eight, :234)
     uint32_t bag;               // the 7-bag as 3-bit fields
     int n_bag, n, n_cp, attempts, uses;
-    int64_t iters;
+    uint32_t iters;             // trips of this attempt (a cut-off is at most 132,000 << 3)
     DecisionStream rnd;         // this attempt's decision stream (tpl_device.h)
     __device__ __forceinline__ int randint(int lo, int hi) { return decision(rnd, lo, hi); }
 };
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     int32_t own_k = 0;                     // ... this one (its state word and ticket counter are s_state[lane], s_ticket[lane])
     int32_t k = 0;                         // what this lane is running: configuration,
     int attempt = 0, home = lane;          // attempt, and the lane that took the configuration from the queue
-    int64_t limit = 0;                     // iterations this attempt may use
+    uint32_t limit = 0;                    // iterations this attempt may use
     uint32_t trip = 0;                     // bursts so far
     const int shift = burst_shift(p.L);    // log2 of a burst's trips
     // the wave's share of the queue: configurations [res_lo, res_hi) are its own to hand to its lanes (wave-uniform values)
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
 #endif
 
     auto begin_attempt = [&](int32_t cfg, int a, int at) {
-        k = cfg; attempt = a; home = at; limit = carve_cutoff(p.L, p.cutoff, a);
+        k = cfg; attempt = a; home = at; limit = (uint32_t)carve_cutoff(p.L, p.cutoff, a);
         begin_search(g, p, cfg, a);
         mode = kRun;
     };
@@ -541,7 +541,7 @@ extern "C" int tpl_generate_configs_device_waves(int32_t L, int32_t M, uint64_t 
     if (M < 1 || M > 254) return fail_msg(TPL_ERR_ARG, "M=%d out of range [1, 254]", M);
     if (count < 1 || count > 0x7FFFFFFF || first < 0 || !rows || !pieces)
         return fail_msg(TPL_ERR_ARG, "bad count / first / output pointers");
-    if (waves < 0 || cutoff < 0) return fail_msg(TPL_ERR_ARG, "waves / cutoff is negative");
+    if (waves < 0 || cutoff < 0 || cutoff > ((int64_t)1 << 28)) return fail_msg(TPL_ERR_ARG, "waves is negative / cutoff outside [0, 2^28]");
     const size_t need = tpl_generate_configs_device_work_bytes(M, count);
     if (!work || work_bytes < need) return fail_msg(TPL_ERR_ARG, "work has %zu bytes, need %zu", work_bytes, need);
     if (((uintptr_t)work & 7u) != 0) return fail_msg(TPL_ERR_ARG, "work must be 8-byte aligned");

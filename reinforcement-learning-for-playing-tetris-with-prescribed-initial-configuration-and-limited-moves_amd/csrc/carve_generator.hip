@@ -219,7 +219,7 @@ extern "C" int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t
                                     int32_t* solution_len) {
     using namespace tpl;
     if (first < 0) return fail_msg(TPL_ERR_ARG, "first is negative");
-    if (cutoff < 0) return fail_msg(TPL_ERR_ARG, "cutoff is negative");
+    if (cutoff < 0 || cutoff > ((int64_t)1 << 28)) return fail_msg(TPL_ERR_ARG, "cutoff outside [0, 2^28]");
     return run_generator(L, M, count, threads, rows, pieces, [=](int64_t k) {
         uint8_t* sol = solution ? solution + k * (int64_t)M * 2 : nullptr;
         int32_t* len = solution_len ? solution_len + k : nullptr;
