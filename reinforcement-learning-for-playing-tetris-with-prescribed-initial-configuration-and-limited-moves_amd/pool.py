@@ -113,7 +113,7 @@ class PoolRefresher:
     """
 
     def __init__(self, env, count: int, seed: int = 0, first: int = 0, waves: int = 0, reserved_cus: int = 0,
-                 low_priority: bool = False):
+                 low_priority: bool = False, cutoff: int = 0):
         """waves: how many persistent 64-lane waves share the generator's queue (0 = count / 256): its footprint beside
         the stepping environment.  What a footprint costs and supplies is in bench.py's `live_supply_run`
         (`by_generator_footprint`; profiles/NOTES.md has the history).  (The step kernel raises its waves'
@@ -123,6 +123,7 @@ class PoolRefresher:
         options because the review of round 2 asked for the comparison, not because they help."""
         import torch
         self.env, self.count, self.seed, self.next_first = env, int(count), int(seed), int(first)
+        self.cutoff = int(cutoff)     # the restart rule's iteration cut-off (0 = by L), as generate_configs / carved_configs take it
         self.waves = int(waves) or max(1, self.count // 256)       # beside a stepping environment: a quarter of the lanes a lone generator takes
         self._masked = bool(reserved_cus or low_priority)
         self.side = side_stream(env, reserved_cus, low_priority) if self._masked else concurrent_stream(env)
@@ -146,7 +147,7 @@ class PoolRefresher:
             status = torch.empty(n, dtype=torch.int32, device=d)
             nbytes = env._lib.tpl_generate_configs_device_work_bytes(env.M, n)
             work = torch.empty(nbytes, dtype=torch.uint8, device=d)
-            check(env._lib.tpl_generate_configs_device_waves(env.L, env.M, self.seed, self.next_first, n, 0, self.waves,
+            check(env._lib.tpl_generate_configs_device_waves(env.L, env.M, self.seed, self.next_first, n, self.cutoff, self.waves,
                                                              C.c_void_p(rows.data_ptr()), C.c_void_p(pieces.data_ptr()), None, None,
                                                              C.c_void_p(status.data_ptr()), C.c_void_p(work.data_ptr()), nbytes,
                                                              self.side.cuda_stream))

@@ -528,3 +528,34 @@ def test_randomised_mix_of_steps_rollouts_resets_and_pool_swaps(T, oracle):
             assert gpu.step_clock() == cpu.clock == t, (tag, op)
         assert gpu.stats() == cpu.stats(), tag
         gpu.terminate()
+
+
+@pytest.mark.gpu
+def test_pool_refresher_drops_a_batch_that_cannot_be_carved_and_the_run_goes_on(T):
+    """An (L, M) that cannot be carved (the search ends when two cells of the bottom row are gone: two shafts through sixteen
+    rows take eight pieces, there are six): every attempt of every configuration runs into its cut-off, the generator reports
+    it, and poll() -- which used to raise and end the run -- drops the batch, says so once, keeps the pool as it is and starts
+    the next batch; stepping is unaffected."""
+    import warnings
+    import torch
+    L, M, n = 16, 6, 2048
+    env = T.BatchedTetris(L, M, n, seed=1, auto_reset=True)
+    rows, pieces = env.synthetic_configs(256)
+    env.load_configs(rows, pieces)
+    env.reset()
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        feeder = T.PoolRefresher(env, 128, seed=1, cutoff=8)
+        swapped = 0
+        for t in range(400):
+            env.step(env.synthetic_actions(t), observe=False)
+            swapped += bool(feeder.poll())
+            if feeder.capped_batches >= 2:
+                break
+        torch.cuda.synchronize()
+    assert swapped == 0 and feeder.swaps == 0 and feeder.capped_batches >= 2
+    said = [w for w in caught if "could not be carved" in str(w.message)]
+    assert len(said) == 1
+    assert env.pool_info()["n_configs"] == 256                    # the pool the run started with
+    feeder.close()
+    env.terminate()
