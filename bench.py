@@ -385,7 +385,10 @@ def measure_actor_loop(torch, T, dev, L, M, boards, seed):
     torch.cuda.synchronize(dev)
     ms = timed(torch, dev, lambda: env.actor_rollout(image, iters), 6) / iters
     out["megakernel"] = {"value": boards / (ms * 1e-3), "ms_per_step": ms, "steps_per_launch": iters,
-                         "outputs": "per-step action u8 + reward f32 + done u8 written"}
+                         "outputs": "per-step action u8 + reward f32 + done u8 written",
+                         # the model's FLOPs over the WHOLE iteration (policy, exploration draw, move, trajectory stores): what
+                         # the matrix pipe delivers when the per-launch costs (weights into LDS, launch gap) are paid once per T
+                         "model_flops_over_whole_step_frac_of_bf16_peak": MODEL_FLOPS_PER_BOARD * boards / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
     out["value"] = out["megakernel"]["value"]
     # the same loop at the reference's arithmetic width: float32 operands and accumulation, T iterations per launch
     image32m = T.actor.policy_image(T.PolicyMLP(), dev, f32=True)
