@@ -361,6 +361,7 @@ def measure_actor_loop(torch, T, dev, L, M, boards, seed):
            "arithmetic": {"value": "bf16 operands, f32 accumulation (megakernel)", "fused_mfma_kernel": "bf16 operands, f32 accumulation",
                           "fused_f32_kernel": "float32 operands and accumulation: the reference's nn.Linear width (model/model.py:9-20)",
                           "f32_megakernel": "float32 operands and accumulation (v_mfma_f32_16x16x4_f32), T steps per launch",
+                          "split_megakernel": "as fused_split_kernel, T steps per launch",
                           "fused_split_kernel": "float32 accuracy on the bf16 pipe: every weight and activation as three bf16 pieces, "
                                                 "six v_mfma_f32_16x16x32_bf16 per product, float32 accumulation (within the float32 "
                                                 "kernel's tolerance of a float64 evaluation; not bit-identical to a float32 FMA chain)",
@@ -398,6 +399,12 @@ def measure_actor_loop(torch, T, dev, L, M, boards, seed):
     ms = timed(torch, dev, lambda: env.actor_rollout(image32m, iters32), 3) / iters32
     out["f32_megakernel"] = {"value": boards / (ms * 1e-3), "ms_per_step": ms, "steps_per_launch": iters32,
                              "outputs": "per-step action u8 + reward f32 + done u8 written"}
+    image_sm = T.actor.policy_image(T.PolicyMLP(), dev, f32="split")
+    env.actor_rollout(image_sm, iters32)
+    torch.cuda.synchronize(dev)
+    ms = timed(torch, dev, lambda: env.actor_rollout(image_sm, iters32), 3) / iters32
+    out["split_megakernel"] = {"value": boards / (ms * 1e-3), "ms_per_step": ms, "steps_per_launch": iters32,
+                               "outputs": "per-step action u8 + reward f32 + done u8 written"}
     # the policy kernel alone against the dense bf16 MFMA peak: USEFUL FLOPs per board -- 2 x (217 x 128 + 3 x 128 x 128 +
     # 128 x 14) = 157,440, the model's own (the kernel issues 159,744: K padded to 224, the head as a 16-row tile)
     # -- over its own duration

@@ -254,6 +254,10 @@ int tpl_actor_rollout(tpl_env* env, const void* image, int32_t num_steps, float 
  * through it once per step.  Same outputs, same results as the step-by-step calls. */
 int tpl_actor_rollout_f32(tpl_env* env, const void* image, int32_t num_steps, float epsilon, uint64_t seed, uint32_t step0,
                           uint8_t* actions, float* rewards, uint8_t* dones, void* states_a, void* states_b, void* stream);
+/* ... and for a split image (tpl_policy_pack_split): float32-grade decisions as a multi-step loop, at twice the float32
+ * megakernel's rate.  num_steps iterations of (tpl_policy_act_split, tpl_explore_actions(step0 + t), tpl_step). */
+int tpl_actor_rollout_split(tpl_env* env, const void* image, int32_t num_steps, float epsilon, uint64_t seed, uint32_t step0,
+                            uint8_t* actions, float* rewards, uint8_t* dones, void* states_a, void* states_b, void* stream);
 
 /* Statistics over episodes finished since the last full reset, reduced on the device into
  * out[4] (device pointer, uint64): {episodes, sum of lines_cleared at finish, wins, top-outs}. */

@@ -42,7 +42,7 @@ SYMBOLS = [
     "tpl_policy_image_bytes", "tpl_policy_pack", "tpl_policy_act",
     "tpl_policy_image_bytes_f32", "tpl_policy_pack_f32", "tpl_policy_act_f32",
     "tpl_policy_image_bytes_split", "tpl_policy_pack_split", "tpl_policy_act_split",
-    "tpl_explore_actions", "tpl_actor_rollout", "tpl_actor_rollout_f32", "tpl_pool_info", "tpl_pool_set_hold", "tpl_note_steps", "tpl_clock_ptr", "tpl_stream_create", "tpl_stream_destroy",
+    "tpl_explore_actions", "tpl_actor_rollout", "tpl_actor_rollout_f32", "tpl_actor_rollout_split", "tpl_pool_info", "tpl_pool_set_hold", "tpl_note_steps", "tpl_clock_ptr", "tpl_stream_create", "tpl_stream_destroy",
 ]
 
 TPL_U8, TPL_I32, TPL_I64 = 0, 1, 2
@@ -163,6 +163,7 @@ def lib() -> C.CDLL:
     L.tpl_explore_actions.argtypes = [vp, vp, f32, u64, C.c_uint32, vp]
     L.tpl_actor_rollout.argtypes = [vp, vp, i32, f32, u64, C.c_uint32, vp, vp, vp, vp, vp, vp]
     L.tpl_actor_rollout_f32.argtypes = [vp, vp, i32, f32, u64, C.c_uint32, vp, vp, vp, vp, vp, vp]
+    L.tpl_actor_rollout_split.argtypes = [vp, vp, i32, f32, u64, C.c_uint32, vp, vp, vp, vp, vp, vp]
     L.tpl_get_stats.argtypes = [vp, vp, vp]
     L.tpl_shape_info.argtypes = [i32, i32, C.POINTER(i32), C.POINTER(i32), vp, vp]
     L.tpl_state_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]

@@ -118,14 +118,29 @@ __device__ __forceinline__ void start_chunk(uint4* dst, const uint4* src, int by
     }
 }
 
+// Where a lane reads a chunk's fragments from: the buffer's LDS address + 16 lane as a typed 32-bit LDS pointer, made opaque
+// (which buffer a chunk sits in is known at compile time, and a constant address above 64 KB does not fit a ds_read's offset
+// field: policy_split.hip).
+typedef __attribute__((address_space(3))) const uint8_t lds_byte;
+typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
+__device__ __forceinline__ lds_byte* chunk_base(const uint4* buffer, int lane) {
+    lds_byte* w = (lds_byte*)buffer + 16 * lane;
+    asm volatile("" : "+v"(w));
+    return w;
+}
+__device__ __forceinline__ float4 frag4(lds_byte* w, int piece) {           // piece = index of the 1-KB fragment row in the chunk
+    const f32x4 v = *(lds_f32x4*)(w + piece * 1024);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // kTiles output tiles of one layer from the chunk at `w`: acc = bias; acc += W[tile rows][k-step] x xin[k-step].
 // xin[t][q4] holds the four B values of k-steps 4 q4 .. 4 q4 + 3 for N tile t (for a hidden layer: the previous layer's
 // output tile q4 as it left the matrix core).
 template <int kTiles, int kKs4, bool kRelu>
-__device__ __forceinline__ void dense(const uint8_t* w, const float* bias, int lane, int g, const f32x4 (&xin)[2][kKs4],
+__device__ __forceinline__ void dense(lds_byte* w, const float* bias, int lane, int g, const f32x4 (&xin)[2][kKs4],
                                       f32x4* xout0, f32x4* xout1) {
     // the A fragments run one step ahead of the multiplies that use them (2.5 % on the kernel, same box)
-    float4 a_next = *(const float4*)(w + (size_t)lane * 16);
+    float4 a_next = frag4(w, 0);
 #pragma unroll
     for (int m = 0; m < kTiles; ++m) {
         const float4 b = *(const float4*)(bias + 16 * m + 4 * g);
@@ -136,7 +151,7 @@ __device__ __forceinline__ void dense(const uint8_t* w, const float* bias, int l
         for (int q4 = 0; q4 < kKs4; ++q4) {
             const float4 a = a_next;
             if (m * kKs4 + q4 + 1 < kTiles * kKs4)
-                a_next = *(const float4*)(w + (size_t)((m * kKs4 + q4 + 1) * 64 + lane) * 16);     // one ds_read_b128
+                a_next = frag4(w, m * kKs4 + q4 + 1);     // one ds_read_b128
             const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -161,7 +176,7 @@ __device__ __forceinline__ void dense(const uint8_t* w, const float* bias, int l
 // needed (k-step q of lane group g = bit 4 (q & 7) + g of feature word q >> 3; the two counters -- features 214, 215 =
 // k-step 53, groups 2 and 3 -- enter as numbers), so the k-steps run outermost and the tiles' accumulators stay live.
 template <int kTiles>
-__device__ __forceinline__ void dense_first(const uint8_t* w, const float* bias, int lane, int g, const uint32_t (&fb)[2][8],
+__device__ __forceinline__ void dense_first(lds_byte* w, const float* bias, int lane, int g, const uint32_t (&fb)[2][8],
                                             f32x4* xout0, f32x4* xout1) {
     f32x4 acc[2][kTiles];
 #pragma unroll
@@ -175,7 +190,7 @@ __device__ __forceinline__ void dense_first(const uint8_t* w, const float* bias,
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int k = 0; k < 7; ++k) u[t][k] = fb[t][k] >> g;
-    float4 a_next = *(const float4*)(w + (size_t)lane * 16);          // fragments run one step ahead of their multiplies
+    float4 a_next = frag4(w, 0);          // fragments run one step ahead of their multiplies
 #pragma unroll
     for (int q4 = 0; q4 < kKs1 / 4; ++q4) {
         float x[2][4];
@@ -196,7 +211,7 @@ __device__ __forceinline__ void dense_first(const uint8_t* w, const float* bias,
             const float4 a = a_next;
             {
                 const int mn = m + 1 < kTiles ? m + 1 : 0, qn = m + 1 < kTiles ? q4 : q4 + 1;
-                if (qn < kKs1 / 4) a_next = *(const float4*)(w + (size_t)((mn * (kKs1 / 4) + qn) * 64 + lane) * 16);
+                if (qn < kKs1 / 4) a_next = frag4(w, mn * (kKs1 / 4) + qn);
             }
             const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
@@ -268,27 +283,27 @@ __global__ __launch_bounds__(64 * kWaves) void policy_f32_kernel(const PolicyF32
         f32x4 xa[2][kMt], xb[2][kMt];
         // chunk 0: layer 1, tiles 0-3
         start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[1]), kChunkBytes[1]);
-        dense_first<4>((const uint8_t*)s_buf[buf], s_bias, lane, g, fb, &xa[0][0], &xa[1][0]);
+        dense_first<4>(chunk_base(s_buf[buf], lane), s_bias, lane, g, fb, &xa[0][0], &xa[1][0]);
         __syncthreads(); buf ^= 1;
         forget_derived(fb);
         // chunk 1: layer 1, tiles 4-7
         start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[2]), kChunkBytes[2]);
-        dense_first<4>((const uint8_t*)s_buf[buf], s_bias + 64, lane, g, fb, &xa[0][4], &xa[1][4]);
+        dense_first<4>(chunk_base(s_buf[buf], lane), s_bias + 64, lane, g, fb, &xa[0][4], &xa[1][4]);
         __syncthreads(); buf ^= 1;
         // chunks 2-4: the hidden layers
         start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[3]), kChunkBytes[3]);
-        dense<kMt, kMt, true>((const uint8_t*)s_buf[buf], s_bias + 1 * kHidden, lane, g, xa, &xb[0][0], &xb[1][0]);
+        dense<kMt, kMt, true>(chunk_base(s_buf[buf], lane), s_bias + 1 * kHidden, lane, g, xa, &xb[0][0], &xb[1][0]);
         __syncthreads(); buf ^= 1;
         start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[4]), kChunkBytes[4]);
-        dense<kMt, kMt, true>((const uint8_t*)s_buf[buf], s_bias + 2 * kHidden, lane, g, xb, &xa[0][0], &xa[1][0]);
+        dense<kMt, kMt, true>(chunk_base(s_buf[buf], lane), s_bias + 2 * kHidden, lane, g, xb, &xa[0][0], &xa[1][0]);
         __syncthreads(); buf ^= 1;
         start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[5]), kChunkBytes[5]);
-        dense<kMt, kMt, true>((const uint8_t*)s_buf[buf], s_bias + 3 * kHidden, lane, g, xa, &xb[0][0], &xb[1][0]);
+        dense<kMt, kMt, true>(chunk_base(s_buf[buf], lane), s_bias + 3 * kHidden, lane, g, xa, &xb[0][0], &xb[1][0]);
         __syncthreads(); buf ^= 1;
         // chunk 5: the head; the next pass's first chunk arrives under it
         if (pass + 1 < passes) start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[0]), kChunkBytes[0]);
         f32x4 lg[2];
-        dense<1, kMt, false>((const uint8_t*)s_buf[buf], s_bias + 4 * kHidden, lane, g, xb, &lg[0], &lg[1]);
+        dense<1, kMt, false>(chunk_base(s_buf[buf], lane), s_bias + 4 * kHidden, lane, g, xb, &lg[0], &lg[1]);
         __syncthreads(); buf ^= 1;
 
         const uint32_t act0 = pick_action(lg[0], g, lane), act1 = pick_action(lg[1], g, lane);
@@ -373,25 +388,25 @@ __global__ __launch_bounds__(64 * kWaves) void actor_rollout_f32_kernel(const Ac
                 both_features(own, g, fb);
                 f32x4 xa[2][kMt], xb[2][kMt];
                 start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[1]), kChunkBytes[1]);
-                dense_first<4>((const uint8_t*)s_buf[buf], s_bias, lane, g, fb, &xa[0][0], &xa[1][0]);
+                dense_first<4>(chunk_base(s_buf[buf], lane), s_bias, lane, g, fb, &xa[0][0], &xa[1][0]);
                 __syncthreads(); buf ^= 1;
                 forget_derived(fb);
                 start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[2]), kChunkBytes[2]);
-                dense_first<4>((const uint8_t*)s_buf[buf], s_bias + 64, lane, g, fb, &xa[0][4], &xa[1][4]);
+                dense_first<4>(chunk_base(s_buf[buf], lane), s_bias + 64, lane, g, fb, &xa[0][4], &xa[1][4]);
                 __syncthreads(); buf ^= 1;
                 start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[3]), kChunkBytes[3]);
-                dense<kMt, kMt, true>((const uint8_t*)s_buf[buf], s_bias + 1 * kHidden, lane, g, xa, &xb[0][0], &xb[1][0]);
+                dense<kMt, kMt, true>(chunk_base(s_buf[buf], lane), s_bias + 1 * kHidden, lane, g, xa, &xb[0][0], &xb[1][0]);
                 __syncthreads(); buf ^= 1;
                 start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[4]), kChunkBytes[4]);
-                dense<kMt, kMt, true>((const uint8_t*)s_buf[buf], s_bias + 2 * kHidden, lane, g, xb, &xa[0][0], &xa[1][0]);
+                dense<kMt, kMt, true>(chunk_base(s_buf[buf], lane), s_bias + 2 * kHidden, lane, g, xb, &xa[0][0], &xa[1][0]);
                 __syncthreads(); buf ^= 1;
                 start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[5]), kChunkBytes[5]);
-                dense<kMt, kMt, true>((const uint8_t*)s_buf[buf], s_bias + 3 * kHidden, lane, g, xa, &xb[0][0], &xb[1][0]);
+                dense<kMt, kMt, true>(chunk_base(s_buf[buf], lane), s_bias + 3 * kHidden, lane, g, xa, &xb[0][0], &xb[1][0]);
                 __syncthreads(); buf ^= 1;
                 // the head; the next step's (or pass's) first chunk arrives under it
                 if (t + 1 < q.T || pass + 1 < passes)
                     start_chunk<64 * kWaves>(s_buf[buf ^ 1], (const uint4*)(image + kChunkOff[0]), kChunkBytes[0]);
-                dense<1, kMt, false>((const uint8_t*)s_buf[buf], s_bias + 4 * kHidden, lane, g, xb, &lg[0], &lg[1]);
+                dense<1, kMt, false>(chunk_base(s_buf[buf], lane), s_bias + 4 * kHidden, lane, g, xb, &lg[0], &lg[1]);
                 __syncthreads(); buf ^= 1;
             }
             const uint32_t act0 = pick_action(lg[0], g, lane), act1 = pick_action(lg[1], g, lane);

@@ -21,6 +21,7 @@
 // The three weight planes are 474 KB and stream through two 64-KB LDS buffers in ten chunks per pass, as in policy_f32.hip.
 #include "tpl_internal.h"
 #include "tpl_policy.h"
+#include "tpl_step.h"
 
 #include <cstring>
 #include <vector>
@@ -131,9 +132,19 @@ __device__ __forceinline__ void start_chunk(uint4* dst, const uint8_t* src, int 
     }
 }
 
-__device__ __forceinline__ bf16x8 frag(const uint8_t* w, int plane_off, int q, int lane) {
-    return *(const bf16x8*)(w + plane_off + (q * 64 + lane) * 16);
+// Where a lane reads a chunk's fragments from: the buffer's LDS address + 16 lane, as a typed 32-bit LDS pointer made OPAQUE.
+// Which of the two buffers a chunk sits in is known at compile time (ten chunks a pass, the buffers alternate), so left
+// alone every fragment address is a constant + 16 lane -- and for the second buffer a constant above 64 KB, which does not fit a
+// ds_read's 16-bit offset: a register per fragment, dozens of them, in scratch.  From an opaque base every fragment of a
+// chunk is base + (an offset below 64 KB) in the instruction.
+typedef __attribute__((address_space(3))) const uint8_t lds_byte;
+typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
+__device__ __forceinline__ lds_byte* chunk_base(const uint4* buffer, int lane) {
+    lds_byte* w = (lds_byte*)buffer + 16 * lane;
+    asm volatile("" : "+v"(w));
+    return w;
 }
+__device__ __forceinline__ bf16x8 frag(lds_byte* w, int plane_off, int q) { return *(lds_bf16x8*)(w + plane_off + q * 1024); }
 __device__ __forceinline__ f32x4 mfma(bf16x8 a, const uint4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -205,52 +216,26 @@ __device__ __forceinline__ void relu(f32x4 (&acc)[kMt][2]) {
             for (int r = 0; r < 4; ++r) acc[m][t][r] = fmaxf(acc[m][t][r], 0.0f);
 }
 
-__global__ __launch_bounds__(64 * kWaves) void policy_split_kernel(const PolicySplitArgs p) {
-    __shared__ uint4 s_buf[2][kBufBytes / 16];
-    __shared__ float s_bias[4 * kHidden + 16];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // (a scalar)
-    const int c = lane & 15, g = lane >> 4;
-    const int64_t tiles = (p.n + 31) / 32;
-    const int64_t tile_step = (int64_t)gridDim.x * kWaves;
-    // every wave of the workgroup makes the same number of passes (the chunk barriers need all of them)
-    const int64_t passes = (tiles - (int64_t)blockIdx.x * kWaves + tile_step - 1) / tile_step;
-    const uint8_t* image = p.image;
-
-    for (int k = threadIdx.x; k < 4 * kHidden + 16; k += 64 * kWaves) s_bias[k] = ((const float*)(image + kOffB))[k];
-    start_chunk<64 * kWaves>(s_buf[0], image + kChunkOff[0], kChunkBytes[0]);
-    __syncthreads();                                             // (its fence waits for the transfers)
-
-    int buf = 0;
-    // chunk j is in s_buf[buf]; the transfer of chunk `next` into the other buffer starts now and is complete at the barrier
-    // that ends the work on chunk j
+// The five layers for the wave's two N tiles of boards whose feature words are fb.  On entry chunk 0 is in s_buf[buf] (every
+// wave of the workgroup calls this together: the chunk barriers are inside); on exit `buf` names the buffer chunk 0 is arriving
+// in -- if `more`, i.e. if there is another call to come.
+__device__ __forceinline__ void split_logits(uint4 (&s_buf)[2][kBufBytes / 16], const float* s_bias, const uint8_t* image, int& buf,
+                                             bool more, int lane, int g, const uint32_t (&fb)[2][8], f32x4 (&lg)[2]) {
 #define TPL_NEXT_CHUNK(next) start_chunk<64 * kWaves>(s_buf[buf ^ 1], image + kChunkOff[next], kChunkBytes[next])
 #define TPL_CHUNK_DONE() do { __syncthreads(); buf ^= 1; } while (0)
-    for (int64_t pass = 0; pass < passes; ++pass) {
-        const int64_t tile = (int64_t)blockIdx.x * kWaves + wave + pass * tile_step;
-        const int64_t b = tile * 32 + (g >> 1) * 16 + c;
-        const bool valid = b < p.n;
-        const int64_t j = valid ? b : p.n - 1;                    // a lane past the end holds the last real board
-        uint32_t fb[2][8];
-        {
-            Board s;
-            unpack_board(p.plane_a[j], p.plane_b[j], s);
-            uint32_t own[8];
-            board_features(s, p.L, p.M, own);
-            both_features(own, g, fb);
-        }
         f32x4 acc[kMt][2], x[kMt][2];
         // ---- layer 1: three planes, the inputs exact
         set_bias(acc, s_bias, g);
 #pragma unroll
         for (int plane = 0; plane < 3; ++plane) {
             TPL_NEXT_CHUNK(plane + 1);
-            const uint8_t* w = (const uint8_t*)s_buf[buf];
+            lds_byte* w = chunk_base(s_buf[buf], lane);
 #pragma unroll
             for (int s = 0; s < kKs1; ++s) {
                 const uint4 x0 = first_fragment(fb[0], s, g), x1 = first_fragment(fb[1], s, g);
 #pragma unroll
                 for (int m = 0; m < kMt; ++m) {
-                    const bf16x8 a = frag(w, 0, m * kKs1 + s, lane);
+                    const bf16x8 a = frag(w, 0, m * kKs1 + s);
                     acc[m][0] = mfma(a, x0, acc[m][0]);
                     acc[m][1] = mfma(a, x1, acc[m][1]);
                 }
@@ -268,7 +253,7 @@ __global__ __launch_bounds__(64 * kWaves) void policy_split_kernel(const PolicyS
             // chunk 3 + 2 layer: the high and low planes -- five of the six products
             TPL_NEXT_CHUNK(4 + 2 * layer);
             {
-                const uint8_t* w = (const uint8_t*)s_buf[buf];
+                lds_byte* w = chunk_base(s_buf[buf], lane);
 #pragma unroll
                 for (int s = 0; s < kKsH; ++s) {
                     uint4 xh[2], xl[2], xll[2];
@@ -281,8 +266,8 @@ __global__ __launch_bounds__(64 * kWaves) void policy_split_kernel(const PolicyS
                         bf16x8 ah[2], al[2];
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
-                            ah[i] = frag(w, 0, (m + i) * kKsH + s, lane);
-                            al[i] = frag(w, kPlaneH, (m + i) * kKsH + s, lane);
+                            ah[i] = frag(w, 0, (m + i) * kKsH + s);
+                            al[i] = frag(w, kPlaneH, (m + i) * kKsH + s);
                         }
                         // smallest terms first
 #pragma unroll
@@ -314,13 +299,13 @@ __global__ __launch_bounds__(64 * kWaves) void policy_split_kernel(const PolicyS
             // chunk 4 + 2 layer: the low-low plane against the high pieces
             TPL_NEXT_CHUNK(5 + 2 * layer);
             {
-                const uint8_t* w = (const uint8_t*)s_buf[buf];
+                lds_byte* w = chunk_base(s_buf[buf], lane);
 #pragma unroll
                 for (int s = 0; s < kKsH; ++s) {
                     const uint4 xh0 = high_fragment(x[2 * s][0], x[2 * s + 1][0]), xh1 = high_fragment(x[2 * s][1], x[2 * s + 1][1]);
 #pragma unroll
                     for (int m = 0; m < kMt; ++m) {
-                        const bf16x8 all = frag(w, 0, m * kKsH + s, lane);
+                        const bf16x8 all = frag(w, 0, m * kKsH + s);
                         acc[m][0] = mfma(all, xh0, acc[m][0]);
                         acc[m][1] = mfma(all, xh1, acc[m][1]);
                     }
@@ -331,16 +316,15 @@ __global__ __launch_bounds__(64 * kWaves) void policy_split_kernel(const PolicyS
         }
         // ---- the head: one output tile, all three planes in one chunk; the next pass's first chunk arrives under it
         relu(acc);
-        f32x4 lg[2];
         {
-            if (pass + 1 < passes) TPL_NEXT_CHUNK(0);
-            const uint8_t* w = (const uint8_t*)s_buf[buf];
+            if (more) TPL_NEXT_CHUNK(0);
+            lds_byte* w = chunk_base(s_buf[buf], lane);
             const float4 bb = *(const float4*)(s_bias + 4 * kHidden + 4 * g);
 #pragma unroll
             for (int t = 0; t < 2; ++t) { lg[t][0] = bb.x; lg[t][1] = bb.y; lg[t][2] = bb.z; lg[t][3] = bb.w; }
 #pragma unroll
             for (int s = 0; s < kKsH; ++s) {
-                const bf16x8 ah = frag(w, 0, s, lane), al = frag(w, kPlane5, s, lane), all = frag(w, 2 * kPlane5, s, lane);
+                const bf16x8 ah = frag(w, 0, s), al = frag(w, kPlane5, s), all = frag(w, 2 * kPlane5, s);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     uint4 xh, xl, xll;
@@ -355,6 +339,41 @@ __global__ __launch_bounds__(64 * kWaves) void policy_split_kernel(const PolicyS
             }
             TPL_CHUNK_DONE();
         }
+#undef TPL_NEXT_CHUNK
+#undef TPL_CHUNK_DONE
+}
+
+__global__ __launch_bounds__(64 * kWaves) void policy_split_kernel(const PolicySplitArgs p) {
+    __shared__ uint4 s_buf[2][kBufBytes / 16];
+    __shared__ float s_bias[4 * kHidden + 16];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // (a scalar)
+    const int c = lane & 15, g = lane >> 4;
+    const int64_t tiles = (p.n + 31) / 32;
+    const int64_t tile_step = (int64_t)gridDim.x * kWaves;
+    // every wave of the workgroup makes the same number of passes (the chunk barriers need all of them)
+    const int64_t passes = (tiles - (int64_t)blockIdx.x * kWaves + tile_step - 1) / tile_step;
+    const uint8_t* image = p.image;
+
+    for (int k = threadIdx.x; k < 4 * kHidden + 16; k += 64 * kWaves) s_bias[k] = ((const float*)(image + kOffB))[k];
+    start_chunk<64 * kWaves>(s_buf[0], image + kChunkOff[0], kChunkBytes[0]);
+    __syncthreads();                                             // (its fence waits for the transfers)
+
+    int buf = 0;
+    for (int64_t pass = 0; pass < passes; ++pass) {
+        const int64_t tile = (int64_t)blockIdx.x * kWaves + wave + pass * tile_step;
+        const int64_t b = tile * 32 + (g >> 1) * 16 + c;
+        const bool valid = b < p.n;
+        const int64_t j = valid ? b : p.n - 1;                    // a lane past the end holds the last real board
+        uint32_t fb[2][8];
+        {
+            Board s;
+            unpack_board(p.plane_a[j], p.plane_b[j], s);
+            uint32_t own[8];
+            board_features(s, p.L, p.M, own);
+            both_features(own, g, fb);
+        }
+        f32x4 lg[2];
+        split_logits(s_buf, s_bias, image, buf, pass + 1 < passes, lane, g, fb, lg);
         const uint32_t act0 = pick_action(lg[0], g, lane), act1 = pick_action(lg[1], g, lane);
         const uint32_t action = (g >> 1) ? act1 : act0;
         if (p.logits) {
@@ -372,8 +391,104 @@ __global__ __launch_bounds__(64 * kWaves) void policy_split_kernel(const PolicyS
         }
         if (valid && (g & 1) == 0) p.action[b] = (uint8_t)action;
     }
-#undef TPL_NEXT_CHUNK
-#undef TPL_CHUNK_DONE
+}
+
+// T iterations of (split policy -> epsilon-greedy -> step) in ONE launch: float32-grade decisions as a multi-step loop at
+// twice the float32 megakernel's rate.  Exactly T x (tpl_policy_act_split, tpl_explore_actions, tpl_step); structure as
+// actor_rollout_f32_kernel (policy_f32.hip): boards packed between the moves, the pool entry worked out again at every
+// step, episodes tallied in LDS, the weight planes streamed through LDS once per step.
+template <bool kAutoReset>
+__global__ __launch_bounds__(64 * kWaves) void actor_rollout_split_kernel(const ActorArgs q) {
+    const StepArgs& p = q.s;
+    __shared__ uint4 s_buf[2][kBufBytes / 16];
+    __shared__ float s_bias[4 * kHidden + 16];
+    __shared__ ShapeWord s_shape[32];
+    __shared__ uint32_t s_stat[4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // (a scalar)
+    const int c = lane & 15, g = lane >> 4;
+    const bool writer = (g & 1) == 0;
+    const int64_t tiles = (p.n + 31) / 32;
+    const int64_t tile_step = (int64_t)gridDim.x * kWaves;
+    const int64_t passes = (tiles - (int64_t)blockIdx.x * kWaves + tile_step - 1) / tile_step;
+    const uint8_t* image = (const uint8_t*)q.image;
+
+    if (threadIdx.x < 32) s_shape[threadIdx.x] = kShapeTable[threadIdx.x];
+    if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
+    for (int k = threadIdx.x; k < 4 * kHidden + 16; k += 64 * kWaves) s_bias[k] = ((const float*)(image + kOffB))[k];
+    start_chunk<64 * kWaves>(s_buf[0], image + kChunkOff[0], kChunkBytes[0]);
+    __syncthreads();
+
+    int buf = 0;
+    for (int64_t pass = 0; pass < passes; ++pass) {
+        const int64_t tile = (int64_t)blockIdx.x * kWaves + wave + pass * tile_step;
+        const int64_t b = tile * 32 + (g >> 1) * 16 + c;
+        const bool valid = b < p.n;
+        uint4 A, B;                                               // the board between the steps' moves, packed
+        if (valid) {
+            A = p.plane_a[b];
+            B = p.plane_b[b];
+        } else {
+            Board filler;                                         // frozen: never moves, never resets
+#pragma unroll
+            for (int k = 0; k < kCols; ++k) filler.c[k] = 0;
+            filler.window = 0xFFFFFFFFu; filler.window_hi = 0xFu; filler.state = ST_LOST_LIMIT; filler.lines = 0; filler.moves = 0; filler.slot = 0;
+            pack_board(filler, A, B);
+        }
+        unsigned long long clock = tile < tiles ? p.clock[tile] : 0ULL;
+        clock = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(clock >> 32)) << 32) |
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)clock);
+        for (uint32_t t = 0; t < q.T; ++t) {
+            if (q.states_a && valid && writer) {
+                q.states_a[(size_t)t * p.n + b] = A;
+                q.states_b[(size_t)t * p.n + b] = B;
+            }
+            f32x4 lg[2];
+            {
+                uint32_t fb[2][8];
+                {
+                    Board s;
+                    unpack_board(A, B, s);
+                    uint32_t own[8];
+                    board_features(s, (int)p.L, (int)p.M, own);
+                    both_features(own, g, fb);
+                }
+                split_logits(s_buf, s_bias, image, buf, t + 1 < q.T || pass + 1 < passes, lane, g, fb, lg);
+            }
+            const uint32_t act0 = pick_action(lg[0], g, lane), act1 = pick_action(lg[1], g, lane);
+            uint32_t action = (g >> 1) ? act1 : act0;
+            action = explore(action, q.explore_seed, (uint64_t)(p.global_offset + b), q.step0 + t, q.eps_q24);
+            uint32_t rot, loc;
+            split_small_action(action, rot, loc);
+            float reward;
+            Tally mine;
+            Board s;
+            unpack_board(A, B, s);
+            uint32_t cfg = current_config(s, p, (uint32_t)b, clock + t);
+            const bool done = advance_board<kAutoReset>(s, cfg, rot, loc, p, (uint32_t)b, clock + t, s_shape, reward, mine);
+            pack_board(s, A, B);
+            if (valid && writer) {
+                if (mine.episodes) {
+                    atomicAdd(&s_stat[0], mine.episodes);
+                    if (mine.lines) atomicAdd(&s_stat[1], mine.lines);
+                    if (mine.wins) atomicAdd(&s_stat[2], mine.wins);
+                    if (mine.topouts) atomicAdd(&s_stat[3], mine.topouts);
+                }
+                if (q.actions) q.actions[(size_t)t * p.n + b] = (uint8_t)action;
+                if (q.rewards) q.rewards[(size_t)t * p.n + b] = reward;
+                if (q.dones) q.dones[(size_t)t * p.n + b] = done ? 1 : 0;
+            }
+        }
+        if (valid && writer) {
+            p.plane_a[b] = A;
+            p.plane_b[b] = B;
+            if ((b & (kClockGroup - 1)) == 0) p.clock[b >> kClockShift] = clock + q.T;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {                                        // as flush_tally: one sharded 64-bit atomic per counter
+        const uint32_t v = s_stat[threadIdx.x];
+        if (v) atomicAdd(&p.stats[(size_t)(blockIdx.x % kStatShards) * kStatStride + threadIdx.x], (unsigned long long)v);
+    }
 }
 
 }  // namespace psp
@@ -391,5 +506,30 @@ extern "C" int tpl_policy_act_split(tpl_env* e, const void* image, uint8_t* acti
     const int64_t groups = ((e->n + 31) / 32 + kWaves - 1) / kWaves;
     hipLaunchKernelGGL(policy_split_kernel, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(64 * kWaves), 0, (hipStream_t)stream, p);
     TPL_HIP(hipGetLastError());
+    return TPL_OK;
+}
+
+extern "C" int tpl_actor_rollout_split(tpl_env* e, const void* image, int32_t num_steps, float epsilon, uint64_t seed, uint32_t step0,
+                                       uint8_t* actions, float* rewards, uint8_t* dones, void* states_a, void* states_b,
+                                       void* stream) {
+    if (!e) return fail_msg(TPL_ERR_ARG, "env is null");
+    if (!image) return fail_msg(TPL_ERR_ARG, "image is null");
+    if (((uintptr_t)image & 15u) != 0) return fail_msg(TPL_ERR_ARG, "image must be 16-byte aligned");
+    if (num_steps < 1) return fail_msg(TPL_ERR_ARG, "num_steps must be >= 1");
+    if (!(epsilon >= 0.0f && epsilon <= 1.0f)) return fail_msg(TPL_ERR_ARG, "epsilon must be in [0, 1]");
+    if ((states_a == nullptr) != (states_b == nullptr)) return fail_msg(TPL_ERR_ARG, "states_a and states_b go together");
+    if (int rc = check_can_advance(e)) return rc;
+    DeviceGuard guard(e->device);
+    ActorArgs q{};
+    q.s = make_args(e);
+    q.image = (const uint4*)image; q.T = (uint32_t)num_steps; q.step0 = step0;
+    q.eps_q24 = (uint32_t)(epsilon * 16777216.0f); q.explore_seed = seed;
+    q.actions = actions; q.rewards = rewards; q.dones = dones; q.states_a = (uint4*)states_a; q.states_b = (uint4*)states_b;
+    const int64_t groups = ((e->n + 31) / 32 + kWaves - 1) / kWaves;
+    const dim3 grid((unsigned)(groups < 256 ? groups : 256)), block(64 * kWaves);
+    if (e->auto_reset) hipLaunchKernelGGL(actor_rollout_split_kernel<true>, grid, block, 0, (hipStream_t)stream, q);
+    else hipLaunchKernelGGL(actor_rollout_split_kernel<false>, grid, block, 0, (hipStream_t)stream, q);
+    TPL_HIP(hipGetLastError());
+    count_steps(e, num_steps);
     return TPL_OK;
 }

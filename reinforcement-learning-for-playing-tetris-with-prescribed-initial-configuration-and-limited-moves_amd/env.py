@@ -487,12 +487,12 @@ class BatchedTetris:
     def actor_rollout(self, image: torch.Tensor, steps: int, epsilon: float = 0.0, seed: int = 0, step0: int = 0,
                       record: bool = True, record_states: bool = False) -> dict:
         """`steps` iterations of policy -> epsilon-greedy -> step in one kernel launch (weights in LDS, boards in
-        registers).  `image`: the bf16 image or the float32 one (pack_policy(..., f32=True): the reference's arithmetic
-        width, the weights stream through LDS once per step) -- told apart by size.  Returns the trajectory:
+        registers).  `image`: the bf16 image, the float32 one (pack_policy(..., f32=True): the reference's arithmetic
+        width, the weights stream through LDS once per step) or the split one (f32="split") -- told apart by size.  Returns the trajectory:
         actions/rewards/dones [steps, N] and, if asked, the 32-byte state of every board before each step as two int32
         [steps, N, 4] tensors."""
         n, d = self.num_envs, self.device
-        f32 = self._image(image, either=True)
+        kind = self._image(image, either=True, split=True)
         if steps < 1:
             raise ValueError("steps must be positive")
         out = {}
@@ -503,7 +503,7 @@ class BatchedTetris:
         if record_states:
             out["states_a"] = torch.empty((steps, n, 4), dtype=torch.int32, device=d)
             out["states_b"] = torch.empty((steps, n, 4), dtype=torch.int32, device=d)
-        launch = self._lib.tpl_actor_rollout_f32 if f32 else self._lib.tpl_actor_rollout
+        launch = {"split": self._lib.tpl_actor_rollout_split, True: self._lib.tpl_actor_rollout_f32, False: self._lib.tpl_actor_rollout}[kind]
         check(launch(self._h, _ptr(image), int(steps), float(epsilon), int(seed), int(step0),
                      _ptr(out.get("actions")), _ptr(out.get("rewards")), _ptr(out.get("dones")),
                      _ptr(out.get("states_a")), _ptr(out.get("states_b")), self._stream()))

@@ -357,13 +357,15 @@ def test_f32_actor_drives_the_environment(T, oracle):
     env.terminate()
 
 
+@pytest.mark.parametrize("kind", [True, "split"])
 @pytest.mark.parametrize("auto,eps,n,steps", [(True, 0.0, 3000, 21), (True, 0.15, 70001, 7), (False, 0.3, 3000, 21)])
-def test_f32_actor_rollout_megakernel_equals_the_step_by_step_loop(T, oracle, auto, eps, n, steps):
+def test_f32_actor_rollout_megakernel_equals_the_step_by_step_loop(T, oracle, auto, eps, n, steps, kind):
     """tpl_actor_rollout_f32 (T iterations of float32 policy -> epsilon-greedy -> step in ONE launch, the reference's
     nn.Linear width as a multi-step loop) == T x (tpl_policy_act_f32, tpl_explore_actions, tpl_step) on a twin handle:
     same actions, rewards, dones, recorded states, final boards and statistics -- the float32 products are the same
     instructions in the same order, so the logits, and with them the decisions, are identical -- and the environment side
-    equals the oracle fed with the recorded actions.  70,001 boards: more than one pass per wave, a ragged last tile."""
+    equals the oracle fed with the recorded actions.  70,001 boards: more than one pass per wave, a ragged last tile.
+    kind = "split": the same for tpl_actor_rollout_split against tpl_policy_act_split (three bf16 pieces per number)."""
     import torch
     L, M, seed = 10, 40, 29
     torch.manual_seed(4)
@@ -379,7 +381,7 @@ def test_f32_actor_rollout_megakernel_equals_the_step_by_step_loop(T, oracle, au
         env.reset()
         envs.append(env)
     mega, ref = envs
-    image = T.actor.policy_image(model, mega.device, f32=True)
+    image = T.actor.policy_image(model, mega.device, f32=kind)
     k1 = steps // 3                                            # two launches: the second resumes from stored state
     out1 = mega.actor_rollout(image, k1, epsilon=eps, seed=5, step0=100, record_states=True)
     out2 = mega.actor_rollout(image, steps - k1, epsilon=eps, seed=5, step0=100 + k1, record_states=True)

@@ -17,8 +17,8 @@ env.load_configs(rows, pieces)
 env.reset()
 torch.manual_seed(0)
 out = []
-for name, f32, k, reps in (("bf16", False, iters, 6), ("f32", True, max(1, iters // 5), 3)):
-    if f32 and not hasattr(env._lib, "tpl_actor_rollout_f32"):
+for name, f32, k, reps in (("bf16", False, iters, 6), ("f32", True, max(1, iters // 5), 3), ("split", "split", max(1, iters // 5), 3)):
+    if (f32 is True and not hasattr(env._lib, "tpl_actor_rollout_f32")) or (f32 == "split" and not hasattr(env._lib, "tpl_actor_rollout_split")):
         continue
     image = T.actor.policy_image(T.PolicyMLP(), env.device, f32=f32)
     try:
