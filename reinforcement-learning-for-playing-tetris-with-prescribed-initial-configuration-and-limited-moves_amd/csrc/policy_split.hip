@@ -37,10 +37,10 @@ constexpr int kKs1 = 7, kKsH = 4, kMt = 8;
 constexpr int kPlane1 = kMt * kKs1 * 1024;     // 57,344: one bf16 plane of layer 1's A fragments
 constexpr int kPlaneH = kMt * kKsH * 1024;     // 32,768: of a hidden layer
 constexpr int kPlane5 = kKsH * 1024;           //  4,096: of the head (one 16-row tile)
-// chunks in the order of use: layer 1 plane by plane; a hidden layer as (high + low planes), then its low-low plane; the head
+// chunks in the order of use: layer 1 plane by plane; a hidden layer as its high plane, then (low + low-low planes); the head
 constexpr int kChunks = 10;
-constexpr int kChunkBytes[kChunks] = {kPlane1, kPlane1, kPlane1, 2 * kPlaneH, kPlaneH, 2 * kPlaneH, kPlaneH, 2 * kPlaneH, kPlaneH, 3 * kPlane5};
-constexpr int kChunkOff[kChunks] = {0, 57344, 114688, 172032, 237568, 270336, 335872, 368640, 434176, 466944};
+constexpr int kChunkBytes[kChunks] = {kPlane1, kPlane1, kPlane1, kPlaneH, 2 * kPlaneH, kPlaneH, 2 * kPlaneH, kPlaneH, 2 * kPlaneH, 3 * kPlane5};
+constexpr int kChunkOff[kChunks] = {0, 57344, 114688, 172032, 204800, 270336, 303104, 368640, 401408, 466944};
 constexpr int kOffB = 479232;
 constexpr int kImageBytes = kOffB + (4 * kHidden + 16) * 4;
 constexpr int kBufBytes = 65536;
@@ -96,7 +96,7 @@ extern "C" int tpl_policy_pack_split(const float* w1, const float* b1, const flo
     pack_layer(l1, w1, kHidden, kObs, kMt, kKs1, true);
     const float* wh[3] = {w2, w3, w4};
     for (int l = 0; l < 3; ++l) {
-        const int pl[3] = {kChunkOff[3 + 2 * l], kChunkOff[3 + 2 * l] + kPlaneH, kChunkOff[4 + 2 * l]};
+        const int pl[3] = {kChunkOff[3 + 2 * l], kChunkOff[4 + 2 * l], kChunkOff[4 + 2 * l] + kPlaneH};
         pack_layer(pl, wh[l], kHidden, kHidden, kMt, kKsH, false);
     }
     const int l5[3] = {kChunkOff[9], kChunkOff[9] + kPlane5, kChunkOff[9] + 2 * kPlane5};
@@ -126,6 +126,9 @@ __device__ __forceinline__ void start_chunk(uint4* dst, const uint8_t* src, int 
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);      // uniform: the chunk offsets stay scalar
     uint32_t lane_bytes = ((uint32_t)threadIdx.x & 63u) * 16u;
     asm volatile("" : "+v"(lane_bytes));
+#ifdef TPL_X_SPLIT_NO_STREAM
+    if (src != nullptr) return;        /* TIMING EXPERIMENT: no transfers at all (results are garbage) */
+#endif
     for (int chunk = wave; chunk * 64 < pieces; chunk += kThreads / 64) {
         if (chunk * 64 + (int)(lane_bytes >> 4) < pieces)
             __builtin_amdgcn_global_load_lds((global_ptr*)(src + (size_t)chunk * 1024 + lane_bytes), (lds_ptr*)(dst + chunk * 64), 16, 0, 0);
@@ -250,7 +253,11 @@ __device__ __forceinline__ void split_logits(uint4 (&s_buf)[2][kBufBytes / 16], 
 #pragma unroll
             for (int m = 0; m < kMt; ++m) { x[m][0] = acc[m][0]; x[m][1] = acc[m][1]; }
             set_bias(acc, s_bias + (layer + 1) * kHidden, g);
-            // chunk 3 + 2 layer: the high and low planes -- five of the six products
+            // Two chunks of THREE products each, so that neither is short against the transfer that runs under it.  (As five and
+            // one -- high + low planes, then the low-low plane -- the second chunk was 64 multiplies per wave under a 64-KB
+            // transfer.  With no transfers at all the kernel runs 13 % faster, a timing experiment said; evening the chunks
+            // out recovered none of it -- 163 us either way -- so it is the stream's average rate, not its bursts.)
+            // chunk 3 + 2 layer: the HIGH plane against all three pieces of the activations
             TPL_NEXT_CHUNK(4 + 2 * layer);
             {
                 lds_byte* w = chunk_base(s_buf[buf], lane);
@@ -260,28 +267,16 @@ __device__ __forceinline__ void split_logits(uint4 (&s_buf)[2][kBufBytes / 16], 
 #pragma unroll
                     for (int t = 0; t < 2; ++t) split_fragment(x[2 * s][t], x[2 * s + 1][t], xh[t], xl[t], xll[t]);
                     // two output tiles at a time, term by term: four independent accumulators between two multiplies into
-                    // the same one (five in a row into one accumulator wait for each other)
+                    // the same one (several in a row into one accumulator wait for each other); smallest terms first
 #pragma unroll
                     for (int m = 0; m < kMt; m += 2) {
-                        bf16x8 ah[2], al[2];
+                        bf16x8 ah[2];
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            ah[i] = frag(w, 0, (m + i) * kKsH + s);
-                            al[i] = frag(w, kPlaneH, (m + i) * kKsH + s);
-                        }
-                        // smallest terms first
+                        for (int i = 0; i < 2; ++i) ah[i] = frag(w, 0, (m + i) * kKsH + s);
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
                             for (int t = 0; t < 2; ++t) acc[m + i][t] = mfma(ah[i], xll[t], acc[m + i][t]);
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int t = 0; t < 2; ++t) acc[m + i][t] = mfma(al[i], xl[t], acc[m + i][t]);
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int t = 0; t < 2; ++t) acc[m + i][t] = mfma(al[i], xh[t], acc[m + i][t]);
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -296,18 +291,36 @@ __device__ __forceinline__ void split_logits(uint4 (&s_buf)[2][kBufBytes / 16], 
                 }
             }
             TPL_CHUNK_DONE();
-            // chunk 4 + 2 layer: the low-low plane against the high pieces
+            // chunk 4 + 2 layer: the LOW plane against the high and low pieces, the LOW-LOW plane against the high pieces
             TPL_NEXT_CHUNK(5 + 2 * layer);
             {
                 lds_byte* w = chunk_base(s_buf[buf], lane);
 #pragma unroll
                 for (int s = 0; s < kKsH; ++s) {
-                    const uint4 xh0 = high_fragment(x[2 * s][0], x[2 * s + 1][0]), xh1 = high_fragment(x[2 * s][1], x[2 * s + 1][1]);
+                    uint4 xh[2], xl[2], unused[2];
 #pragma unroll
-                    for (int m = 0; m < kMt; ++m) {
-                        const bf16x8 all = frag(w, 0, m * kKsH + s);
-                        acc[m][0] = mfma(all, xh0, acc[m][0]);
-                        acc[m][1] = mfma(all, xh1, acc[m][1]);
+                    for (int t = 0; t < 2; ++t) split_fragment(x[2 * s][t], x[2 * s + 1][t], xh[t], xl[t], unused[t]);
+#pragma unroll
+                    for (int m = 0; m < kMt; m += 2) {
+                        bf16x8 al[2], all[2];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            al[i] = frag(w, 0, (m + i) * kKsH + s);
+                            all[i] = frag(w, kPlaneH, (m + i) * kKsH + s);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int t = 0; t < 2; ++t) acc[m + i][t] = mfma(all[i], xh[t], acc[m + i][t]);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int t = 0; t < 2; ++t) acc[m + i][t] = mfma(al[i], xl[t], acc[m + i][t]);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int t = 0; t < 2; ++t) acc[m + i][t] = mfma(al[i], xh[t], acc[m + i][t]);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
