@@ -288,7 +288,8 @@ int tpl_set_tuning(tpl_env* env, int32_t boards_per_lane, int32_t block_threads)
  * first+i draws decision k as a 32-bit hash of key + k * stride, (key, stride) = the halves of rng(seed, 4, first+i, a),
  * top 24 bits reduced to [lo, hi] by a multiply; (2) the restart rule -- the reference's search loop has no bound and an
  * exponentially distributed length, so configuration first+i is the outcome of the FIRST attempt a = 0, 1, ... 23 that ends
- * within its iteration cut-off: `cutoff` << (a / 6), or, with cutoff = 0, about twice the median search length at this L.
+ * within its iteration cut-off: `cutoff` for attempts 0-11, twice that for 12-17, four times for 18-23 -- with cutoff = 0,
+ * about twice the median search length at this L.
  * The output depends on (L, M, seed, first+i, cutoff) only -- not on `threads`, and it is the same on the device.  If all
  * 24 attempts run into their cut-off (an (L, M) that cannot be carved, e.g. M pieces too few for L rows) the
  * configuration's outputs are zeroed and the call returns TPL_ERR_STATE after finishing the others.  1 <= L <= 16. */

@@ -48,7 +48,7 @@ namespace tpl {
 namespace {
 
 constexpr uint32_t kAttemptMask = (1u << kCarveAttempts) - 1u;
-constexpr int kHelpersPerConfiguration = 8;      // attempts of one configuration in flight at a time, at most (roughly)
+constexpr int kHelpersPerConfiguration = 12;     // attempts of one configuration in flight at a time, at most: those at the base cut-off
 
 struct CarveArgs {
     int32_t L, M;
@@ -142,7 +142,7 @@ struct Search {
     uint32_t bottom;            // filled cells of the bottom row (the search ends at eight, :234)
     uint32_t bag;               // the 7-bag as 3-bit fields
     int n_bag, n, n_cp, attempts, uses;
-    uint32_t iters;             // trips of this attempt (a cut-off is at most 132,000 << 3)
+    uint32_t iters;             // trips of this attempt (a cut-off is at most 2^28 << 2)
     DecisionStream rnd;         // this attempt's decision stream (tpl_device.h)
     __device__ __forceinline__ int randint(int lo, int hi) { return decision(rnd, lo, hi); }
 };

@@ -476,8 +476,8 @@ __host__ __device__ __forceinline__ int decision(DecisionStream& s, int lo, int 
 // cut-off of about twice the median search costs 1-3 % more iterations in total (a memoryless search loses only its
 // warm-up when restarted) and bounds every attempt -- which is what lets the device generator run the attempts of one
 // straggling configuration on many lanes at once and still return exactly this configuration (carve_device.hip).  After
-// kCarveAttempts failed attempts the configuration is reported as capped (all-zero outputs); the cut-off doubles every six
-// attempts, so an (L, M) whose searches are long only pays a logarithmic number of restarts.
+// kCarveAttempts failed attempts the configuration is reported as capped (all-zero outputs); the cut-off doubles after twelve
+// attempts and again after eighteen, for an (L, M) whose searches are longer than the table's.
 constexpr int kCarveAttempts = 24;
 // iterations allowed to attempt `attempt`: `cutoff` if the caller gave one, else about twice the measured median search
 // length at this L (M = 40; M matters little unless it is close to the fewest pieces that can clear L rows)
@@ -492,7 +492,10 @@ __host__ __device__ __forceinline__ int64_t carve_cutoff(int L, int64_t cutoff, 
             default: c = 132000; break;
         }
     }
-    return c << (attempt / 6);
+    // twelve attempts at the base cut-off, six at twice, six at four times it.  (Doubling from the seventh attempt on, as this
+    // first was, made the unluckiest configuration of EVERY large batch -- one in 4,000 fails six times -- wait for an attempt
+    // of 2 c trips: the slowest wave of a launch ran 10,000 trips past the queue's end where the median ran 5,100.)
+    return c << (attempt < 12 ? 0 : (attempt - 12) / 6 + 1);
 }
 
 // which pool entry the episode of global board `g` = global_offset + i that begins at step `birth` starts from.

@@ -49,8 +49,8 @@ def concurrent_stream(env):
     key = (env._index, main.cuda_stream)                   # tested against THIS stepping stream
     if key in _CONCURRENT:
         return _CONCURRENT[key]
-    # The probe launch does not depend on the environment: L = 16 with an iteration cut-off of 128 -- no attempt of a
-    # 16-row stack ends that early, so every lane runs its 24 attempts to their cut-offs (6 x 128 x (1 + 2 + 4 + 8) = 11,520
+    # The probe launch does not depend on the environment: L = 16 with an iteration cut-off of 256 -- no attempt of a
+    # 16-row stack ends that early, so every lane runs its 24 attempts to their cut-offs (256 x (12 + 6 x 2 + 6 x 4) = 12,288
     # iterations) whatever the seed: about ten milliseconds on one wave, and its output is discarded.
     L, M, count = 16, 40, 64
     rows = torch.empty((count, 20), dtype=torch.int16, device=d)
@@ -64,7 +64,7 @@ def concurrent_stream(env):
     for attempt in range(12):
         cand = torch.cuda.Stream(d)
         busy, quick = torch.cuda.Event(), torch.cuda.Event()
-        check(env._lib.tpl_generate_configs_device_waves(L, M, 0x5EED, 0, count, 128, 1, C.c_void_p(rows.data_ptr()),
+        check(env._lib.tpl_generate_configs_device_waves(L, M, 0x5EED, 0, count, 256, 1, C.c_void_p(rows.data_ptr()),
                                                          C.c_void_p(pieces.data_ptr()), None, None, C.c_void_p(status.data_ptr()),
                                                          C.c_void_p(work.data_ptr()), nbytes, cand.cuda_stream))
         busy.record(cand)

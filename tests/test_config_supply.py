@@ -194,11 +194,11 @@ def test_restart_rule_host_generator_equals_the_oracle(oracle, L, M, n, cutoff):
             g.move(int(rot), int(loc))
         assert g.state == 1, k
     if cutoff:
-        assert (attempts > 0).mean() > 0.3 and attempts.max() >= 6        # restarts happened, some past the first doubling
+        assert (attempts > 0).mean() > 0.3 and attempts.max() >= 6        # restarts happened, many in a row for some
     else:
         assert (attempts > 0).mean() < 0.5                                # the default cut-off: most finish at once
-    assert oracle.carve_attempt_limit(L, cutoff, 0) * 2 == oracle.carve_attempt_limit(L, cutoff, 6)
-    assert oracle.carve_attempt_limit(10, 0, 0) == 3328 and oracle.carve_attempt_limit(10, 0, 23) == 3328 * 8
+    assert [oracle.carve_attempt_limit(10, 0, a) // 3328 for a in (0, 11, 12, 17, 18, 23)] == [1, 1, 2, 2, 4, 4]
+    assert oracle.carve_attempt_limit(L, cutoff, 12) == 2 * oracle.carve_attempt_limit(L, cutoff, 0)
 
 
 @pytest.mark.gpu
