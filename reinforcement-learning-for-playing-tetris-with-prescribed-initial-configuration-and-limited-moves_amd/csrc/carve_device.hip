@@ -349,13 +349,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         // A SIMD issues for its OLDEST wave first: of the four waves a SIMD holds, the one of the first quarter of the grid ran a
         // trip in 1.2 us and the one of the last quarter in 2.5 (profiles/r04_carve/NOTES), which the queue evens out while it
         // has work and nothing does afterwards -- the launch then waits for the youngest waves.  So the issue priority goes
-        // round: every 256 trips (32 bursts) a wave takes the next of the four levels, a quarter of the grid on each at any time.
+        // round: every 256 trips a wave moves on to the next of four phases (levels 0, 1, 2, 2), a quarter of the grid in each.
         if ((trip & ((256u >> shift) - 1u)) == 0u) {
             switch (((uint32_t)blockIdx.x / (gridDim.x / 4u + 1u) + (trip >> (8 - shift))) & 3u) {
                 case 0: __builtin_amdgcn_s_setprio(0); break;
                 case 1: __builtin_amdgcn_s_setprio(1); break;
                 case 2: __builtin_amdgcn_s_setprio(2); break;
-                default: __builtin_amdgcn_s_setprio(3); break;
+                default: __builtin_amdgcn_s_setprio(2); break;      // never 3: that level is the step kernel's (tetris_piclim.hip),
+                                                                   // which must win the issue against a generator beside it
             }
         }
         ++trip;
