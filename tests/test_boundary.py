@@ -73,6 +73,27 @@ def test_sizes_and_argument_errors_without_gpu():
     assert lib.tpl_destroy(None) == 0
 
 
+def test_round_4_entry_points_refuse_bad_arguments_without_a_gpu():
+    """The entry points added in round 4 -- compact trajectory, float32 / split megakernels, split policy -- check their
+    arguments before they touch the device: callable (and refusing) in a process that has no GPU."""
+    lib = T._lib.lib()
+    assert lib.tpl_rollout_trajectory(None, None, 0, 1, None, None, None) < 0 and b"null" in lib.tpl_last_error()
+    assert lib.tpl_rollout_random_trajectory(None, 0, 0, 1, None, None, None, None) < 0
+    assert lib.tpl_decode_trajectory(None, None, 1, None, None, None) < 0
+    assert lib.tpl_actor_rollout_f32(None, None, 1, 0.0, 0, 0, None, None, None, None, None, None) < 0
+    assert lib.tpl_actor_rollout_split(None, None, 1, 0.0, 0, 0, None, None, None, None, None, None) < 0
+    assert lib.tpl_policy_act_split(None, None, None, None, None) < 0
+    assert lib.tpl_policy_pack_split(*([None] * 11)) < 0 and b"null" in lib.tpl_last_error()
+    # three bf16 planes of the bf16 image's fragments + the float32 biases
+    assert lib.tpl_policy_image_bytes_split() == 3 * (lib.tpl_policy_image_bytes() - (4 * 128 + 16) * 4) + (4 * 128 + 16) * 4
+    # the generators: a cut-off beyond 2^28 (the device counts trips in 32 bits) and a negative one are refused
+    import numpy as np
+    rows, pieces = np.zeros((2, 20), np.uint16), np.zeros((2, 41), np.uint8)
+    for cutoff in (-1, (1 << 28) + 1):
+        rc = lib.tpl_generate_configs(10, 40, 0, 0, 2, 1, cutoff, rows.ctypes.data, pieces.ctypes.data, None, None)
+        assert rc < 0 and b"cutoff" in lib.tpl_last_error()
+
+
 def test_product_never_touches_the_oracle_or_a_cpu_fallback():
     for base, _, files in os.walk(PKG):
         for fn in files:
