@@ -88,19 +88,24 @@ __device__ __forceinline__ int drop_of(const uint32_t* d, const DShape& s, uint3
     return (int)best - 4;
 }
 
-// calculate_carve (:313-352) on the local copy d of the piece's four columns; `after` = the columns with the piece taken out
+// calculate_carve (:313-352) on the local copy d of the piece's four columns; `after` = the columns with the piece taken out.
+// Straight-line: its three tests (inside the board :317-318, every cell of the piece filled :321-329, the piece comes to rest
+// where it was carved :341-349) are all computed and combined.  Early exits here were nested divergent regions that a wave
+// of 64 searches entered on every trip anyway -- some lane passes each test -- at a dozen scalar instructions and two branches
+// a test.
 __device__ __forceinline__ bool try_carve(const uint32_t* d, int drop, const DShape& s, bool allow_partial, uint32_t* after) {
-    if (drop + (int)s.h > kRows || drop < 0) return false;                  // :317-318
+    const bool inside = drop + (int)s.h <= kRows && drop >= 0;              // :317-318
+    const uint32_t shift = (uint32_t)drop & 31u;                            // (a drop outside the board is refused below, whatever it shifts)
     uint32_t missing = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t m = ((s.pat16 >> (4 * k)) & 0xFu) << (uint32_t)drop;
+        const uint32_t m = ((s.pat16 >> (4 * k)) & 0xFu) << shift;
         missing |= m & ~d[k];
         after[k] = d[k] & ~m;                                               // :332-337
     }
-    if (!allow_partial && missing) return false;                            // :321-329
     uint32_t unused;
-    return drop_of(after, s, unused) == drop;                               // :341-349: the piece must come to rest there
+    const bool rests = drop_of(after, s, unused) == drop;                   // :341-349: the piece must come to rest there
+    return inside & (allow_partial | (missing == 0u)) & rests;              // :321-329
 }
 
 // carve (:286-311) on the lane's columns in LDS; `bottom` = filled cells of the bottom row, kept up to date
