@@ -1,5 +1,6 @@
-import numpy as np, heapq, sys
-its=np.load('/tmp/its_10_40.npy').astype(np.int64)
+import numpy as np, heapq, sys, os
+# search lengths of 20,000 configurations at L = 10, M = 40 without the restart rule (what iteration_histogram.json summarises)
+its=np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r04_carve', 'search_lengths_L10_M40.npz'))['iterations'].astype(np.int64)
 rng=np.random.default_rng(1)
 def sample(): return int(its[rng.integers(len(its))])
 def run_wave(C, T0, policy, H=8, theta=0.0, A=24):
