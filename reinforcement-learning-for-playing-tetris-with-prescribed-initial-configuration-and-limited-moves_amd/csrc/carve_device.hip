@@ -108,14 +108,17 @@ __device__ __forceinline__ bool try_carve(const uint32_t* d, int drop, const DSh
     return inside & (allow_partial | (missing == 0u)) & rests;              // :321-329
 }
 
-// carve (:286-311) on the lane's columns in LDS; `bottom` = filled cells of the bottom row, kept up to date
-__device__ __forceinline__ bool carve(uint32_t* col, uint32_t& bottom, const DShape& s, uint32_t loc, bool allow_partial) {
-    uint32_t* under = col + loc * kColStride;
-    uint32_t d[4], after[4];
+// carve (:286-311) on the lane's columns in LDS, as a TEST: `after` = the four columns under the piece with the piece taken
+// out, `drop` = where; the caller writes them back if the carve stands (take_out).  Every lane of a wave runs this whether its
+// list has room for another piece or not (the caller refuses the result if it has none): the columns are there to be read,
+// and a region under `n < M` -- true for all but a lane or two -- only cost its entry, exit and the copies around it.
+__device__ __forceinline__ bool carve(const uint32_t* col, const DShape& s, uint32_t loc, bool allow_partial, uint32_t* after, int& drop) {
+    const uint32_t* under = col + loc * kColStride;
+    uint32_t d[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) d[k] = under[k * kColStride];
     uint32_t revtopo;
-    int drop = drop_of(d, s, revtopo);
+    drop = drop_of(d, s, revtopo);
     drop += (int)revtopo + 1;                                               // :298-301
     // :304 -- the first piece of a configuration may stick out of the stack and is tried at h depths; every other carve has
     // ONE try, and that is the path every trip takes: it is written without the loop (whose bookkeeping -- a dozen scalar
@@ -127,14 +130,20 @@ __device__ __forceinline__ bool carve(uint32_t* col, uint32_t& bottom, const DSh
             ok = try_carve(d, drop, s, true, after);
         }
     }
-    if (ok) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            under[k * kColStride] = after[k];
-            bottom -= ((d[k] ^ after[k]) >> (kRows - 1)) & 1u;
-        }
-    }
     return ok;
+}
+
+// the carve stands: the columns go back, and `bottom` (filled cells of the bottom row) follows
+__device__ __forceinline__ void take_out(uint32_t* col, uint32_t& bottom, const DShape& s, uint32_t loc, const uint32_t* after, int drop) {
+    uint32_t* under = col + loc * kColStride;
+    {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) under[k * kColStride] = after[k];
+        // Cells taken out of the bottom row = cells of the piece that lie in it: bit 19 - drop of each column nibble (every cell
+        // of the piece was filled, or -- a configuration's first piece -- the board is the full stack, whose bottom row is full).
+        // Shifted left by drop - 16 (mod 32) that bit sits at the top of its nibble for drop 16..19 and past bit 15 for any other.
+        bottom -= (uint32_t)__builtin_popcount((s.pat16 << (((uint32_t)drop - 16u) & 31u)) & 0x8888u);
+    }
 }
 
 constexpr uint32_t kFullBag = 0u | 1u << 3 | 2u << 6 | 3u << 9 | 4u << 12 | 5u << 15 | 6u << 18;
@@ -153,8 +162,11 @@ struct Search {
 };
 
 // this lane's slice of the work memory: reversed piece list, reversed solution, checkpoints (entries of 11 words: ten
-// columns, then list length | bottom-row count << 16)
-struct Slice { uint8_t* pieces_rev; uint8_t* sol_rev; uint32_t* cps; };
+// columns, then list length | bottom-row count << 16).  Held as 32-bit byte offsets from CarveArgs::work (the work memory of
+// a full launch is 0.3-0.7 GB): an access is then the uniform base plus a 32-bit lane offset, with no 64-bit lane arithmetic
+struct Slice { uint32_t pieces_rev, sol_rev, cps; };
+__device__ __forceinline__ uint8_t* bytes_at(const CarveArgs& p, uint32_t offset) { return p.work + (size_t)offset; }
+__device__ __forceinline__ uint32_t* words_at(const CarveArgs& p, uint32_t offset) { return (uint32_t*)(p.work + (size_t)offset); }
 
 __device__ __forceinline__ void begin_search(Search& g, const CarveArgs& p, int64_t k, int attempt) {
     const uint32_t filled = p.L >= kRows ? kColMask : (((1u << p.L) - 1u) << (kRows - p.L));
@@ -176,7 +188,7 @@ __device__ __forceinline__ void search_iteration(Search& g, const Slice& w, cons
     const int idx = word_bag_index(word, g.n_bag);                          // :85
     const uint32_t piece = (g.bag >> (3 * idx)) & 7u;
     if (fresh && g.n_cp < max_cps) {                                        // :239-247
-        uint32_t* e = w.cps + g.n_cp * 11;
+        uint32_t* e = words_at(p, w.cps + (uint32_t)g.n_cp * 44u);
         const uint32_t tail = (uint32_t)g.n | (g.bottom << 16);
 #pragma unroll
         for (int x = 0; x < kCols; ++x) {
@@ -191,10 +203,15 @@ __device__ __forceinline__ void search_iteration(Search& g, const Slice& w, cons
     const int rotations = word_rotations(word);                             // :250
     const DShape s = shape_of(g.shapes, piece, (uint32_t)rotations);
     const int loc = word_location(word, kCols - (int)s.w + 1);              // :253
-    if (g.n < p.M && carve(g.col, g.bottom, s, (uint32_t)loc, g.n == 0)) {  // :257
-        w.pieces_rev[g.n] = (uint8_t)piece;                                 // insert(0, ...) (:258-260), reversed
-        w.sol_rev[2 * g.n] = (uint8_t)rotations;
-        w.sol_rev[2 * g.n + 1] = (uint8_t)loc;
+    uint32_t after[4];
+    int drop;
+    const bool stands = carve(g.col, s, (uint32_t)loc, g.n == 0, after, drop) & (g.n < p.M);       // :257
+    if (stands) {
+        take_out(g.col, g.bottom, s, (uint32_t)loc, after, drop);
+        *bytes_at(p, w.pieces_rev + (uint32_t)g.n) = (uint8_t)piece;        // insert(0, ...) (:258-260), reversed
+        uint8_t* sol = bytes_at(p, w.sol_rev + 2u * (uint32_t)g.n);
+        sol[0] = (uint8_t)rotations;
+        sol[1] = (uint8_t)loc;
         ++g.n;
         const uint32_t low = g.bag & ((1u << (3 * idx)) - 1u);              // delete_index (:262)
         g.bag = low | ((g.bag >> (3 * (idx + 1))) << (3 * idx));
@@ -203,7 +220,7 @@ __device__ __forceinline__ void search_iteration(Search& g, const Slice& w, cons
         g.attempts = 0;                                                     // load_checkpoint (:128-137)
         if (g.n_cp > 1 && g.uses > 10) {                                    // drop the top entry: the one below becomes the top
             --g.n_cp; g.uses = 0;
-            const uint32_t* e = w.cps + (g.n_cp - 1) * 11;
+            const uint32_t* e = words_at(p, w.cps + (uint32_t)(g.n_cp - 1) * 44u);
 #pragma unroll
             for (int x = 0; x <= kCols; ++x) g.top[x * kColStride] = e[x];
         } else ++g.uses;
@@ -298,9 +315,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block;
     const int64_t slot = wave * 64 + lane;
     Slice w;
-    w.pieces_rev = p.work + slot * p.work_stride;
-    w.sol_rev = w.pieces_rev + 256;
-    w.cps = (uint32_t*)(w.sol_rev + 512);
+    w.pieces_rev = (uint32_t)(slot * p.work_stride);
+    w.sol_rev = w.pieces_rev + 256u;
+    w.cps = w.sol_rev + 512u;
 
     // everything in LDS is per WAVE (no barrier anywhere: a wave runs in lockstep with itself)
     __shared__ uint32_t s_col_all[kWavesPerBlock][kCols + kPadCols][kColStride];
@@ -551,6 +568,8 @@ extern "C" int tpl_generate_configs_device_waves(int32_t L, int32_t M, uint64_t 
     const size_t need = tpl_generate_configs_device_work_bytes(M, count);
     if (!work || work_bytes < need) return fail_msg(TPL_ERR_ARG, "work has %zu bytes, need %zu", work_bytes, need);
     if (((uintptr_t)work & 7u) != 0) return fail_msg(TPL_ERR_ARG, "work must be 8-byte aligned");
+    if (work_stride_bytes(M) * work_slices(count) >= ((size_t)1 << 32))             // the kernel's slice offsets are 32-bit
+        return fail_msg(TPL_ERR_STATE, "work slices of %zu bytes outgrew 32-bit offsets", work_stride_bytes(M));
     // how many waves share the queue.  Automatic: as many as the chip runs at full rate (four per SIMD), or one lane per
     // configuration if that is fewer -- lanes without a configuration of their own run further attempts of their wave's.
     const int64_t most = (count + 63) / 64;
