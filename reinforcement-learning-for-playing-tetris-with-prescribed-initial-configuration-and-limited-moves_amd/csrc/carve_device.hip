@@ -64,38 +64,57 @@ struct CarveArgs {
     unsigned long long* next;   // the queue: index of the next configuration nobody has taken yet (zeroed before the launch)
 };
 
-struct DShape { uint32_t pat16, w, h; uint32_t bias; };   // column nibbles, width, height, per-column 3 - revtopo bytes
+// A shape as this kernel reads it (16 bytes of the wave's LDS table, made from kShapeTable at the kernel's start):
+//   x   = column nibbles (16 bits) | places the piece can stand, 10 - w + 1, << 16 | 20 - h << 20 | h << 25
+//   b01, b23 = per column k a 16-bit constant B_k = 128 bias_k + 32 k,  bias_k = 3 - reverse topography, or 64 past the width.
+// With c_k = the top of column k (v_ffbl: the columns carry a sentinel bit at row 20, so an empty one reads 20), the KEY
+// 129 c_k + B_k = 128 (c_k + bias_k) + 32 k + c_k orders the columns by c_k + bias_k, equal sums by k (c_k <= 20 < 32), and
+// carries c_k in its low five bits: the minimum of four keys is np.argmin's column (:298), its c_k and its sum in one go --
+// three instructions a column where compare / minimum / select on two values were six.
+struct CarveShape { uint32_t x, b01, b23, pad; };
+struct DShape { uint32_t pat16, places, room, x, b01, b23; };             // room = 20 - h: the deepest drop that stays inside
 
-__device__ __forceinline__ DShape shape_of(const ShapeWord* table, uint32_t piece, uint32_t rotations) {
-    const ShapeWord sw = table[piece * 4u + (rotations & 3u)];             // get_tetromino (:60-61); `table` = the wave's LDS copy
-    return DShape{sw.x & 0xFFFFu, (sw.x >> 16) & 7u, (sw.x >> 19) & 7u, sw.y};
+__device__ __forceinline__ CarveShape carve_shape(const ShapeWord sw) {
+    const uint32_t w = (sw.x >> 16) & 7u, h = (sw.x >> 19) & 7u;
+    uint32_t B[4];
+    for (int k = 0; k < 4; ++k) B[k] = ((sw.y >> (8 * k)) & 0xFFu) * 128u + 32u * (uint32_t)k;
+    return CarveShape{(sw.x & 0xFFFFu) | ((uint32_t)kCols - w + 1u) << 16 | ((uint32_t)kRows - h) << 20 | h << 25,
+                      B[0] | B[1] << 16, B[2] | B[3] << 16, 0u};
 }
 
-constexpr int kPadCols = 3;                // empty columns behind column 9, for pieces narrower than four at the right edge
+__device__ __forceinline__ DShape shape_of(const CarveShape* table, uint32_t piece, uint32_t rotations) {
+    const CarveShape e = table[piece * 4u + (rotations & 3u)];             // get_tetromino (:60-61); `table` = the wave's LDS copy
+    return DShape{e.x & 0xFFFFu, (e.x >> 16) & 15u, (e.x >> 20) & 31u, e.x, e.b01, e.b23};
+}
+
+constexpr int kPadCols = 3;                // columns behind column 9 (empty: the sentinel alone), for pieces narrower than four at the right edge
 constexpr int kColStride = 64;             // words between consecutive columns of a lane
+constexpr uint32_t kFloor = 1u << kRows;   // the sentinel every column word carries in LDS
 
-// calculate_drop_deltas + calculate_drop (:424-433) on the four columns under the piece (d = c[loc .. loc+3]): drop, and
-// reverse_topography of the first column that attains the minimum (np.argmin, :298)
-__device__ __forceinline__ int drop_of(const uint32_t* d, const DShape& s, uint32_t& revtopo_at_min) {
-    uint32_t best = 0xFFu, at_bias = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t bias = (s.bias >> (8 * k)) & 0xFFu;                 // 3 - revtopo, or 64 past the width
-        const uint32_t v = (uint32_t)__builtin_ctz(d[k] | (1u << kRows)) + bias;
-        if (v < best) { best = v; at_bias = bias; }
-    }
-    revtopo_at_min = 3u - at_bias;
-    return (int)best - 4;
+__device__ __forceinline__ uint32_t column_key(uint32_t column, const DShape& s, int k) {
+    const uint32_t B = k < 2 ? (s.b01 >> (16 * k)) & 0xFFFFu : (s.b23 >> (16 * (k - 2))) & 0xFFFFu;
+    return __umul24((uint32_t)__builtin_ctz(column), 129u) + B;
 }
+__device__ __forceinline__ uint32_t least_key(const uint32_t* d, const DShape& s) {
+    uint32_t best = column_key(d[0], s, 0);
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { const uint32_t v = column_key(d[k], s, k); best = v < best ? v : best; }
+    return best;
+}
+// calculate_drop_deltas + calculate_drop (:424-433) on the four columns under the piece (d = c[loc .. loc+3]), then :298-301:
+// drop + reverse_topography of the first column that attains the minimum (np.argmin) + 1 = (c + bias - 4) + (3 - bias) + 1 = c
+__device__ __forceinline__ int carve_depth(const uint32_t* d, const DShape& s) { return (int)(least_key(d, s) & 31u); }
+// where the piece comes to rest on the columns d
+__device__ __forceinline__ int rest_of(const uint32_t* d, const DShape& s) { return (int)(least_key(d, s) >> 7) - 4; }
 
 // calculate_carve (:313-352) on the local copy d of the piece's four columns; `after` = the columns with the piece taken out.
 // Straight-line: its three tests (inside the board :317-318, every cell of the piece filled :321-329, the piece comes to rest
 // where it was carved :341-349) are all computed and combined.  Early exits here were nested divergent regions that a wave
 // of 64 searches entered on every trip anyway -- some lane passes each test -- at a dozen scalar instructions and two branches
-// a test.
+// a test.  (A drop outside the board may shift the piece onto the sentinel; it is refused whatever the other tests say.)
 __device__ __forceinline__ bool try_carve(const uint32_t* d, int drop, const DShape& s, bool allow_partial, uint32_t* after) {
-    const bool inside = drop + (int)s.h <= kRows && drop >= 0;              // :317-318
-    const uint32_t shift = (uint32_t)drop & 31u;                            // (a drop outside the board is refused below, whatever it shifts)
+    const bool inside = (uint32_t)drop <= s.room;                           // :317-318: 0 <= drop and drop + h <= 20, as one comparison
+    const uint32_t shift = (uint32_t)drop & 31u;
     uint32_t missing = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -103,8 +122,7 @@ __device__ __forceinline__ bool try_carve(const uint32_t* d, int drop, const DSh
         missing |= m & ~d[k];
         after[k] = d[k] & ~m;                                               // :332-337
     }
-    uint32_t unused;
-    const bool rests = drop_of(after, s, unused) == drop;                   // :341-349: the piece must come to rest there
+    const bool rests = rest_of(after, s) == drop;                           // :341-349: the piece must come to rest there
     return inside & (allow_partial | (missing == 0u)) & rests;              // :321-329
 }
 
@@ -117,15 +135,14 @@ __device__ __forceinline__ bool carve(const uint32_t* col, const DShape& s, uint
     uint32_t d[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) d[k] = under[k * kColStride];
-    uint32_t revtopo;
-    drop = drop_of(d, s, revtopo);
-    drop += (int)revtopo + 1;                                               // :298-301
+    drop = carve_depth(d, s);                                               // :298-301
     // :304 -- the first piece of a configuration may stick out of the stack and is tried at h depths; every other carve has
     // ONE try, and that is the path every trip takes: it is written without the loop (whose bookkeeping -- a dozen scalar
     // instructions and two branches -- would be paid by every carve of every trip)
     bool ok = try_carve(d, drop, s, allow_partial, after);
     if (!ok && allow_partial) {
-        for (int t = 1; t < (int)s.h && !ok; ++t) {
+        const int h = (int)(s.x >> 25);
+        for (int t = 1; t < h && !ok; ++t) {
             --drop;
             ok = try_carve(d, drop, s, true, after);
         }
@@ -152,7 +169,7 @@ constexpr uint32_t kFullBag = 0u | 1u << 3 | 2u << 6 | 3u << 9 | 4u << 12 | 5u <
 struct Search {
     uint32_t* col;              // this lane's column 0 in LDS; column k at col[64 k]
     uint32_t* top;              // this lane's copy of the TOP checkpoint in LDS: ten columns, then length | bottom << 16
-    const ShapeWord* shapes;    // the shape table in LDS (a per-lane indexed read of constant memory is a vector memory load)
+    const CarveShape* shapes;   // the shape table in LDS (a per-lane indexed read of constant memory is a vector memory load)
     uint32_t bottom;            // filled cells of the bottom row (the search ends at eight, :234)
     uint32_t bag;               // the 7-bag as 3-bit fields
     int n_bag, n, n_cp, attempts, uses;
@@ -169,7 +186,7 @@ __device__ __forceinline__ uint8_t* bytes_at(const CarveArgs& p, uint32_t offset
 __device__ __forceinline__ uint32_t* words_at(const CarveArgs& p, uint32_t offset) { return (uint32_t*)(p.work + (size_t)offset); }
 
 __device__ __forceinline__ void begin_search(Search& g, const CarveArgs& p, int64_t k, int attempt) {
-    const uint32_t filled = p.L >= kRows ? kColMask : (((1u << p.L) - 1u) << (kRows - p.L));
+    const uint32_t filled = (p.L >= kRows ? kColMask : (((1u << p.L) - 1u) << (kRows - p.L))) | kFloor;
     g.rnd = decision_stream(p.seed, (uint64_t)(p.first + k), (uint32_t)attempt);
 #pragma unroll
     for (int x = 0; x < kCols; ++x) g.col[x * kColStride] = filled;         // :228
@@ -188,7 +205,7 @@ __device__ __forceinline__ void search_iteration(Search& g, const Slice& w, cons
     const int idx = word_bag_index(word, g.n_bag);                          // :85
     const uint32_t piece = (g.bag >> (3 * idx)) & 7u;
     if (fresh && g.n_cp < max_cps) {                                        // :239-247
-        uint32_t* e = words_at(p, w.cps + (uint32_t)g.n_cp * 44u);
+        uint32_t* e = words_at(p, w.cps + __umul24((uint32_t)g.n_cp, 44u));
         const uint32_t tail = (uint32_t)g.n | (g.bottom << 16);
 #pragma unroll
         for (int x = 0; x < kCols; ++x) {
@@ -202,7 +219,7 @@ __device__ __forceinline__ void search_iteration(Search& g, const Slice& w, cons
     }
     const int rotations = word_rotations(word);                             // :250
     const DShape s = shape_of(g.shapes, piece, (uint32_t)rotations);
-    const int loc = word_location(word, kCols - (int)s.w + 1);              // :253
+    const int loc = word_location(word, (int)s.places);                     // :253
     uint32_t after[4];
     int drop;
     const bool stands = carve(g.col, s, (uint32_t)loc, g.n == 0, after, drop) & (g.n < p.M);       // :257
@@ -220,7 +237,7 @@ __device__ __forceinline__ void search_iteration(Search& g, const Slice& w, cons
         g.attempts = 0;                                                     // load_checkpoint (:128-137)
         if (g.n_cp > 1 && g.uses > 10) {                                    // drop the top entry: the one below becomes the top
             --g.n_cp; g.uses = 0;
-            const uint32_t* e = words_at(p, w.cps + (uint32_t)(g.n_cp - 1) * 44u);
+            const uint32_t* e = words_at(p, w.cps + __umul24((uint32_t)(g.n_cp - 1), 44u));
 #pragma unroll
             for (int x = 0; x <= kCols; ++x) g.top[x * kColStride] = e[x];
         } else ++g.uses;
@@ -325,19 +342,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     // per configuration taken from the queue by lane i of this wave (indexed by i, its "home"): state word, tickets handed out
     __shared__ unsigned long long s_state_all[kWavesPerBlock][64];
     __shared__ uint32_t s_ticket_all[kWavesPerBlock][64];
-    __shared__ ShapeWord s_shape_all[kWavesPerBlock][32];
+    __shared__ CarveShape s_shape_all[kWavesPerBlock][32];
     uint32_t (*s_col)[kColStride] = s_col_all[wave_in_block];
     uint32_t (*s_top)[kColStride] = s_top_all[wave_in_block];
     unsigned long long* s_state = s_state_all[wave_in_block];
     uint32_t* s_ticket = s_ticket_all[wave_in_block];
-    ShapeWord* s_shape = s_shape_all[wave_in_block];
-    if (lane < 32) s_shape[lane] = kShapeTable[lane];
+    CarveShape* s_shape = s_shape_all[wave_in_block];
+    if (lane < 32) s_shape[lane] = carve_shape(kShapeTable[lane]);
     Search g;
     g.col = &s_col[0][lane];
     g.top = &s_top[0][lane];
     g.shapes = s_shape;
 #pragma unroll
-    for (int x = kCols; x < kCols + kPadCols; ++x) g.col[x * kColStride] = 0u;
+    for (int x = kCols; x < kCols + kPadCols; ++x) g.col[x * kColStride] = kFloor;
     begin_search(g, p, 0, 0);
 
     enum : int { kIdle = 0, kRun = 1, kHold = 2 };
@@ -472,16 +489,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         // paid once per burst (a lane whose attempt ends inside a burst sits out the rest of it: sixteen trips in 2,500) --
         // then, if the attempt is over, its end
         if (mode == kRun) {
+            // attempts begin between bursts, so within one every running lane is at trip `iters + r` of its attempt: the cut-off
+            // is a comparison of the burst's own (scalar) counter with what the lane has left, and `iters` moves once per burst
+            const uint32_t left = limit - g.iters;
 #pragma unroll 1
-            for (int r = 0; r < (1 << shift); ++r) {
-                if (solved(g) || g.iters >= limit) break;
-                ++g.iters;
+            for (uint32_t r = 0; r < (1u << shift); ++r) {
+                if (solved(g) || r >= left) break;
 #ifdef TPL_CARVE_DIAG
                 ++d_iters;
 #endif
                 search_iteration(g, w, p);
             }
-            const bool done = solved(g), out = !done && g.iters >= limit;
+            const bool done = solved(g), out = !done && left <= (1u << shift);
+            g.iters += 1u << shift;                                          // (only read again if the attempt goes on)
             if (!done && !out) {
                 // the attempt goes on
             } else if (done) {
@@ -585,7 +605,7 @@ extern "C" int tpl_generate_configs_device_waves(int32_t L, int32_t M, uint64_t 
     TPL_HIP(hipMemsetAsync(p.next, 0, 64, (hipStream_t)stream));
     // LDS per block padded to a quarter of a CU's 160 KB: no CU takes more than four blocks (one wave of each per SIMD), so a
     // full launch of 1024 blocks sits four to every CU instead of three here and five there
-    constexpr size_t kLdsPerBlock = 160 * 1024 / 4, kLdsStatic = 28672;
+    constexpr size_t kLdsPerBlock = 160 * 1024 / 4, kLdsStatic = 29696;
     static_assert(kLdsStatic <= kLdsPerBlock, "the kernel's LDS arrays outgrew the padding");
     hipLaunchKernelGGL(carve_kernel, dim3((unsigned)blocks), dim3(256), kLdsPerBlock - kLdsStatic, (hipStream_t)stream, p);
     TPL_HIP(hipGetLastError());

@@ -453,7 +453,13 @@ __host__ __device__ __forceinline__ uint32_t decision_word(DecisionStream& s) {
     s.key += s.stride;
     return w;
 }
-__host__ __device__ __forceinline__ int word_bag_index(uint32_t w, int n_bag) { return (int)(((w >> 20) * (uint32_t)n_bag) >> 12); }
+__host__ __device__ __forceinline__ int word_bag_index(uint32_t w, int n_bag) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return (int)(__umul24(w >> 20, (uint32_t)n_bag) >> 12);        // twelve bits by three: the full-rate 24-bit multiply
+#else
+    return (int)(((w >> 20) * (uint32_t)n_bag) >> 12);
+#endif
+}
 __host__ __device__ __forceinline__ int word_rotations(uint32_t w) { return (int)((w >> 18) & 3u); }
 __host__ __device__ __forceinline__ int word_location(uint32_t w, int places) { return (int)(((w & 0x3FFFFu) * (uint32_t)places) >> 18); }
 
