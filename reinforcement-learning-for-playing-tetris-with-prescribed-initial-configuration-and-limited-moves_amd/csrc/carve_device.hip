@@ -64,27 +64,31 @@ struct CarveArgs {
     unsigned long long* next;   // the queue: index of the next configuration nobody has taken yet (zeroed before the launch)
 };
 
-// A shape as this kernel reads it (16 bytes of the wave's LDS table, made from kShapeTable at the kernel's start):
-//   x   = column nibbles (16 bits) | places the piece can stand, 10 - w + 1, << 16 | 20 - h << 20 | h << 25
-//   b01, b23 = per column k a 16-bit constant B_k = 128 bias_k + 32 k,  bias_k = 3 - reverse topography, or 64 past the width.
+// A shape as this kernel reads it (32 bytes of the wave's LDS table, made from kShapeTable at the kernel's start):
+//   x   = column nibbles (16 bits) | places the piece can stand, 10 - w + 1, << 16 | 20 - h << 24 (a byte each)
+//   B[k] = per column k the constant 128 bias_k + 32 k,  bias_k = 3 - reverse topography, or 64 past the width (a word each:
+//          an operand as it is read).
 // With c_k = the top of column k (v_ffbl: the columns carry a sentinel bit at row 20, so an empty one reads 20), the KEY
 // 129 c_k + B_k = 128 (c_k + bias_k) + 32 k + c_k orders the columns by c_k + bias_k, equal sums by k (c_k <= 20 < 32), and
 // carries c_k in its low five bits: the minimum of four keys is np.argmin's column (:298), its c_k and its sum in one go --
 // three instructions a column where compare / minimum / select on two values were six.
-struct CarveShape { uint32_t x, b01, b23, pad; };
-struct DShape { uint32_t pat16, places, room, x, b01, b23; };             // room = 20 - h: the deepest drop that stays inside
+//   cols = the column nibbles again, a BYTE each: a byte of a register is an operand (SDWA), a nibble takes an extract
+struct alignas(16) CarveShape { uint32_t x, cols, spare0, spare1, B[4]; };
+struct DShape { uint32_t pat16, places, room, cols, B[4]; };              // room = 20 - h: the deepest drop that stays inside
 
 __device__ __forceinline__ CarveShape carve_shape(const ShapeWord sw) {
     const uint32_t w = (sw.x >> 16) & 7u, h = (sw.x >> 19) & 7u;
     uint32_t B[4];
     for (int k = 0; k < 4; ++k) B[k] = ((sw.y >> (8 * k)) & 0xFFu) * 128u + 32u * (uint32_t)k;
-    return CarveShape{(sw.x & 0xFFFFu) | ((uint32_t)kCols - w + 1u) << 16 | ((uint32_t)kRows - h) << 20 | h << 25,
-                      B[0] | B[1] << 16, B[2] | B[3] << 16, 0u};
+    uint32_t cols = 0;
+    for (int k = 0; k < 4; ++k) cols |= ((sw.x >> (4 * k)) & 0xFu) << (8 * k);
+    return CarveShape{(sw.x & 0xFFFFu) | ((uint32_t)kCols - w + 1u) << 16 | ((uint32_t)kRows - h) << 24, cols, 0u, 0u,
+                      {B[0], B[1], B[2], B[3]}};
 }
 
 __device__ __forceinline__ DShape shape_of(const CarveShape* table, uint32_t piece, uint32_t rotations) {
     const CarveShape e = table[piece * 4u + (rotations & 3u)];             // get_tetromino (:60-61); `table` = the wave's LDS copy
-    return DShape{e.x & 0xFFFFu, (e.x >> 16) & 15u, (e.x >> 20) & 31u, e.x, e.b01, e.b23};
+    return DShape{e.x & 0xFFFFu, (e.x >> 16) & 0xFFu, e.x >> 24, e.cols, {e.B[0], e.B[1], e.B[2], e.B[3]}};
 }
 
 constexpr int kPadCols = 3;                // columns behind column 9 (empty: the sentinel alone), for pieces narrower than four at the right edge
@@ -92,8 +96,7 @@ constexpr int kColStride = 64;             // words between consecutive columns 
 constexpr uint32_t kFloor = 1u << kRows;   // the sentinel every column word carries in LDS
 
 __device__ __forceinline__ uint32_t column_key(uint32_t column, const DShape& s, int k) {
-    const uint32_t B = k < 2 ? (s.b01 >> (16 * k)) & 0xFFFFu : (s.b23 >> (16 * (k - 2))) & 0xFFFFu;
-    return __umul24((uint32_t)__builtin_ctz(column), 129u) + B;
+    return __umul24((uint32_t)__builtin_ctz(column), 129u) + s.B[k];
 }
 __device__ __forceinline__ uint32_t least_key(const uint32_t* d, const DShape& s) {
     uint32_t best = column_key(d[0], s, 0);
@@ -118,7 +121,7 @@ __device__ __forceinline__ bool try_carve(const uint32_t* d, int drop, const DSh
     uint32_t missing = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t m = ((s.pat16 >> (4 * k)) & 0xFu) << shift;
+        const uint32_t m = ((s.cols >> (8 * k)) & 0xFFu) << shift;
         missing |= m & ~d[k];
         after[k] = d[k] & ~m;                                               // :332-337
     }
@@ -141,7 +144,7 @@ __device__ __forceinline__ bool carve(const uint32_t* col, const DShape& s, uint
     // instructions and two branches -- would be paid by every carve of every trip)
     bool ok = try_carve(d, drop, s, allow_partial, after);
     if (!ok && allow_partial) {
-        const int h = (int)(s.x >> 25);
+        const int h = (int)kRows - (int)s.room;
         for (int t = 1; t < h && !ok; ++t) {
             --drop;
             ok = try_carve(d, drop, s, true, after);
@@ -492,9 +495,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             // attempts begin between bursts, so within one every running lane is at trip `iters + r` of its attempt: the cut-off
             // is a comparison of the burst's own (scalar) counter with what the lane has left, and `iters` moves once per burst
             const uint32_t left = limit - g.iters;
+            const uint32_t stop = left < (1u << shift) ? left : 1u << shift;  // the burst's end and the cut-off as ONE per-lane bound
 #pragma unroll 1
-            for (uint32_t r = 0; r < (1u << shift); ++r) {
-                if (solved(g) || r >= left) break;
+            for (uint32_t r = 0;; ++r) {
+                if (solved(g) || r >= stop) break;
 #ifdef TPL_CARVE_DIAG
                 ++d_iters;
 #endif
@@ -605,7 +609,7 @@ extern "C" int tpl_generate_configs_device_waves(int32_t L, int32_t M, uint64_t 
     TPL_HIP(hipMemsetAsync(p.next, 0, 64, (hipStream_t)stream));
     // LDS per block padded to a quarter of a CU's 160 KB: no CU takes more than four blocks (one wave of each per SIMD), so a
     // full launch of 1024 blocks sits four to every CU instead of three here and five there
-    constexpr size_t kLdsPerBlock = 160 * 1024 / 4, kLdsStatic = 29696;
+    constexpr size_t kLdsPerBlock = 160 * 1024 / 4, kLdsStatic = 31744;
     static_assert(kLdsStatic <= kLdsPerBlock, "the kernel's LDS arrays outgrew the padding");
     hipLaunchKernelGGL(carve_kernel, dim3((unsigned)blocks), dim3(256), kLdsPerBlock - kLdsStatic, (hipStream_t)stream, p);
     TPL_HIP(hipGetLastError());
