@@ -330,7 +330,11 @@ __device__ __forceinline__ int burst_shift(int L) { return L >= 8 ? 5 : 3; }
 
 // waves_per_eu(4, 4): the register count is reported high enough that a SIMD holds no more than four of these waves --
 // with the LDS padding at the launch (four blocks to a CU) the only placement left is four waves on every SIMD
-__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void carve_kernel(const CarveArgs p) {
+#ifndef TPL_CARVE_WAVES_PER_SIMD
+#define TPL_CARVE_WAVES_PER_SIMD 4
+#endif
+constexpr int kWavesPerSimd = TPL_CARVE_WAVES_PER_SIMD;
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(kWavesPerSimd, kWavesPerSimd))) void carve_kernel(const CarveArgs p) {
     const int lane = (int)threadIdx.x & 63, wave_in_block = (int)threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block;
     const int64_t slot = wave * 64 + lane;
@@ -563,7 +567,7 @@ using namespace tpl;
 
 // work memory: one slice per lane of the launch (never more lanes than configurations, rounded up to whole waves, and never
 // more than kMaxWaves waves: four to a SIMD of the chip), then the queue's counter on a line of its own
-constexpr int64_t kMaxWaves = 4096;
+constexpr int64_t kMaxWaves = 1024 * kWavesPerSimd;
 static size_t work_stride_bytes(int32_t M) { return (256 + 512 + (size_t)(M / 7 + 3) * 44 + 63) / 64 * 64; }
 static size_t work_slices(int64_t count) {                        // whole blocks of four waves
     int64_t waves = ((count + 63) / 64 + 3) / 4 * 4;
@@ -609,7 +613,7 @@ extern "C" int tpl_generate_configs_device_waves(int32_t L, int32_t M, uint64_t 
     TPL_HIP(hipMemsetAsync(p.next, 0, 64, (hipStream_t)stream));
     // LDS per block padded to a quarter of a CU's 160 KB: no CU takes more than four blocks (one wave of each per SIMD), so a
     // full launch of 1024 blocks sits four to every CU instead of three here and five there
-    constexpr size_t kLdsPerBlock = 160 * 1024 / 4, kLdsStatic = 31744;
+    constexpr size_t kLdsPerBlock = 160 * 1024 / kWavesPerSimd, kLdsStatic = 31744;
     static_assert(kLdsStatic <= kLdsPerBlock, "the kernel's LDS arrays outgrew the padding");
     hipLaunchKernelGGL(carve_kernel, dim3((unsigned)blocks), dim3(256), kLdsPerBlock - kLdsStatic, (hipStream_t)stream, p);
     TPL_HIP(hipGetLastError());
