@@ -202,7 +202,7 @@ def test_restart_rule_host_generator_equals_the_oracle(oracle, L, M, n, cutoff):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("L,M,n", [(5, 20, 10000), (10, 40, 3000), (15, 40, 96), (1, 1, 65), (3, 254, 40)])
+@pytest.mark.parametrize("L,M,n", [(5, 20, 10000), (10, 40, 3000), (15, 40, 96), (1, 1, 65), (3, 254, 40), (16, 40, 24), (12, 254, 48), (2, 7, 700)])
 def test_device_generator_equals_the_oracle_and_the_host_generator(oracle, L, M, n):
     """tpl_generate_configs_device (one configuration per lane) against the ORACLE's generator (pinned to the
     reference's carving loop, game/tetris.py:226-352, by the decision tapes) -- boards, piece lists, solutions -- and
