@@ -6,7 +6,7 @@ lanes' time was useful.  Time is counted in search trips; the restart rule is th
 configuration may use c trips for a < 12, 2c for 12..17, 4c for 18..23; the answer is the lowest attempt that ends within
 its cut-off, known once every lower one has failed.
 
-    tools/carve_pool_sim.py [per_lane=1] [cutoff=3328] [groups=400]
+    tools/carve_pool_sim.py [per_lane=1] [cutoff=3328] [groups=400] [schedule, e.g. 4x5,4x10,4x16,6x32,6x64]
 
 `per_lane` = configurations per lane of the launch (1: the 262,144-configuration batch on 4096 waves; 4: 2^20).  The lengths
 are those of 20,000 configurations at L = 10, M = 40 without the restart rule (profiles/r04_carve/search_lengths_L10_M40.npz,
@@ -25,7 +25,19 @@ groups = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 A, BURST = 24, 32
 
 
+# the cut-off schedule: the product's, or (4th argument) one to try, as comma-separated "count x multiplier of C in sixteenths"
+SCHEDULE = None
+if len(sys.argv) > 4:
+    SCHEDULE = []
+    for part in sys.argv[4].split(","):
+        cnt, mult = part.split("x")
+        SCHEDULE += [max(1, C * int(mult) // 16)] * int(cnt)
+    assert len(SCHEDULE) == A, len(SCHEDULE)
+
+
 def limit(a):
+    if SCHEDULE is not None:
+        return SCHEDULE[a]
     return C << (0 if a < 12 else (a - 12) // 6 + 1)
 
 
@@ -126,8 +138,9 @@ def run(lanes, helpers, rng, order="fewest", reserve=0):
 
 rng = np.random.default_rng(7)
 print(f"{per_lane} configuration(s) per lane, cut-off {C}, {groups} groups each; a launch of 4096 waves ends with its slowest group")
-for lanes, helpers, order, reserve in ((64, 12, "fewest", 0), (64, 4, "fewest", 0), (64, 24, "fewest", 0), (128, 12, "fewest", 0),
-                                       (256, 12, "fewest", 0), (256, 24, "fewest", 0), (1024, 12, "fewest", 0)):
+CASES = ((64, 12, "fewest", 0),) if SCHEDULE is not None else ((64, 12, "fewest", 0), (64, 4, "fewest", 0), (64, 24, "fewest", 0), (128, 12, "fewest", 0),
+                                       (256, 12, "fewest", 0), (256, 24, "fewest", 0), (1024, 12, "fewest", 0))
+for lanes, helpers, order, reserve in CASES:
     n = max(8, groups * 64 // lanes)
     r = [run(lanes, helpers, rng, order, reserve) for _ in range(n)]
     ends = np.array([x[0] for x in r])
