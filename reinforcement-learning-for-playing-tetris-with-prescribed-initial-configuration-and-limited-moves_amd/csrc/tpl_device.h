@@ -435,8 +435,8 @@ __host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
 // words.  A word serves one trip of the search loop (decision_word below) or one other decision, reduced to [lo, hi] as
 // lo + (((d >> 8) * (hi - lo + 1)) >> 24)  -- a 24-bit multiply; the ranges drawn from have at most ten values (a bias below
 // 10 / 2^24), and at most 255 fit.
-// (Through round 2 every decision was a 64-bit splitmix round and a 64-bit multiply-high: some seven quarter-rate
-// multiplies each, three decisions per iteration of the search; in round 3 the stride was one constant for every stream,
+// (Through round 2 every decision was a 64-bit splitmix round and a 64-bit multiply-high: some seven 32-bit multiplies and
+// twice as many shifts, xors and carries each, three decisions per iteration of the search; in round 3 the stride was one constant for every stream,
 // so all streams walked one 2^32-cycle from different offsets.)
 struct DecisionStream { uint32_t key, stride; };
 __host__ __device__ __forceinline__ DecisionStream decision_stream(uint64_t seed, uint64_t index, uint32_t attempt) {
@@ -446,7 +446,7 @@ __host__ __device__ __forceinline__ DecisionStream decision_stream(uint64_t seed
 // One trip of the search loop (:234-279) makes three decisions -- which piece of the bag (:85), how many rotations (:250), where
 // (:253) -- and takes ONE word of the stream for them: bits 31-20 -> the bag index, (field * n_bag) >> 12; bits 19-18 -> the
 // rotations; bits 17-0 -> the location, (field * places) >> 18 (biases below 7 / 4096 and 10 / 2^18).  Three hashes a trip
-// were a fifth of what a trip cost on the device (two quarter-rate multiplies each).  Every other decision (the shuffles
+// were a fifth of a trip's instructions on the device.  Every other decision (the shuffles
 // of the padding, :93) takes a word of its own through decision().
 __host__ __device__ __forceinline__ uint32_t decision_word(DecisionStream& s) {
     const uint32_t w = fmix32(s.key);
@@ -455,7 +455,7 @@ __host__ __device__ __forceinline__ uint32_t decision_word(DecisionStream& s) {
 }
 __host__ __device__ __forceinline__ int word_bag_index(uint32_t w, int n_bag) {
 #ifdef __HIP_DEVICE_COMPILE__
-    return (int)(__umul24(w >> 20, (uint32_t)n_bag) >> 12);        // twelve bits by three: the full-rate 24-bit multiply
+    return (int)(__umul24(w >> 20, (uint32_t)n_bag) >> 12);        // twelve bits by three: the product fits the 24-bit multiply
 #else
     return (int)(((w >> 20) * (uint32_t)n_bag) >> 12);
 #endif

@@ -93,8 +93,8 @@ __device__ __forceinline__ uint64_t piece_word_at(const uint8_t* rec, uint32_t w
     return *(const uint64_t*)(rec + 32u + 8u * (w - 1u));
 }
 
-// the same for an action below 1029 (a uint8 action, a policy's action): one 24-bit multiply (full rate) instead of a
-// multiply-high (quarter rate)
+// the same for an action below 1029 (a uint8 action, a policy's action): one 24-bit multiply and a shift instead of a
+// multiply-high by a 32-bit reciprocal and its correction
 __device__ __forceinline__ void split_small_action(uint32_t action, uint32_t& rot, uint32_t& loc) {
     rot = __umul24(action, 205u) >> 11;
     loc = action - __umul24(rot, 10u);
@@ -105,8 +105,8 @@ __device__ __forceinline__ void split_small_action(uint32_t action, uint32_t& ro
 //
 // The draws come in PAIRS: steps 2j and 2j + 1 of a board share ONE 32-bit hash of (seed, global board index, j) and take
 // sixteen bits of it each, reduced to [0, 40) by a 24-bit multiply: (half * 40) >> 16, every action within 40 / 65536 of
-// 1/40.  (Round 2 spent a hash and a multiply-high on every step: five quarter-rate multiplies, 120 of the 550 cycles a
-// wave-step of the multi-step kernel took; this is one hash every other step -- and still a function of the step index
+// 1/40.  (Round 2 spent a hash and a multiply-high on every step -- five multiplies and the shifts and xors between them, a fifth of
+// the instructions of a wave-step of the multi-step kernel; this is one hash every other step -- and still a function of the step index
 // alone, so any step can be drawn without the ones before it.)  The decision at epsilon < 1 is a hash of its own, of
 // the pair word and the step's parity: it costs nothing when every action is replaced.
 __device__ __forceinline__ uint32_t explore_base(uint64_t seed, uint64_t gidx) {
