@@ -9,7 +9,10 @@
 // the piece at a per-lane address, works on that local copy -- everything a carve looks at lies in those four columns --
 // and writes them back when it stands (through round 2 the columns sat in registers: a 23-blend network to pick the four,
 // a 64-bit shift and ten extracts to put the piece back).  The number of filled cells in the bottom row, which ends the
-// search at eight (:234), is kept as a count.  The 7-bag is seven 3-bit fields of one register, and a slice of `work`
+// search at eight (:234), is kept as a count.  Every column word carries a sentinel bit at row 20 (an empty column's top
+// reads 20 with no preparation), and the four columns under a piece are ranked by ONE minimum of per-column keys (CarveShape
+// below): the loop is bound by the number of vector instructions a trip takes (profiles/NOTES.md, round 4, steps 7-13), and
+// these two took a fifth of them.  The 7-bag is seven 3-bit fields of one register, and a slice of `work`
 // memory holds the piece list, the solution and the checkpoints.  The lists are kept in REVERSE order: the reference
 // prepends each carved piece (`insert(0, ...)`, :258-260), so the list at any checkpoint is a suffix of every later list;
 // appending to the reversed arrays and truncating on a reload gives the same lists without ever copying them, and a
