@@ -257,6 +257,35 @@ def test_device_generator_under_restarts_equals_the_host_generator(oracle, L, M,
 
 
 @pytest.mark.gpu
+def test_device_generator_randomised_sweep_of_geometries_cutoffs_and_wave_counts(oracle):
+    """Sixteen draws of (L, M, batch, cut-off, waves, seed, first) over the argument range (M large enough for L rows to be
+    carved at all): device == host for every configuration (boards, piece lists, solutions), host == oracle on a spread of
+    them.  A cut-off of half the table's makes every other attempt fail, so most configurations are the work of several."""
+    import tetris_piclim as T
+    rng = np.random.default_rng(404)
+    for case in range(16):
+        L = int(rng.integers(1, 14))
+        M = int(rng.choice([m for m in (3, 7, 8, 20, 33, 40, 41, 100, 254) if m >= 4 * L]))
+        n = int(rng.choice([1, 63, 64, 65, 200, 1000]))
+        base = oracle.carve_attempt_limit(L, 0, 0)
+        cutoff = int(rng.choice([0, 0, max(8, base // 2), 2 * base]))
+        waves = int(rng.choice([0, 1, 2, 5, 10 ** 6]))
+        seed, first = int(rng.integers(0, 1 << 40)), int(rng.integers(0, 1 << 33))
+        what = (case, L, M, n, cutoff, waves, seed, first)
+        env = T.BatchedTetris(L, M, 64)
+        rows, pieces, sol, sol_len = T.generate_configs(L, M, n, seed=seed, first=first, cutoff=cutoff, with_solutions=True)
+        d_rows, d_pieces, d_sol, d_len = env.carved_configs(n, seed=seed, first=first, with_solutions=True, cutoff=cutoff, waves=waves)
+        assert np.array_equal(d_rows.cpu().numpy().view(np.uint16), rows), what
+        assert np.array_equal(d_pieces.cpu().numpy(), pieces), what
+        assert np.array_equal(d_len.cpu().numpy(), sol_len) and np.array_equal(d_sol.cpu().numpy(), sol), what
+        for k in range(0, n, max(1, n // 8)):
+            it, r, p_, s_ = oracle.generate_config_seeded(L, M, seed, first + k, cutoff)
+            assert it >= 0 and np.array_equal(r, rows[k]) and np.array_equal(p_, pieces[k]), what
+            assert np.array_equal(s_, sol[k, : sol_len[k]]), what
+        env.terminate()
+
+
+@pytest.mark.gpu
 def test_device_generator_reports_configurations_that_cannot_be_carved():
     """Every attempt runs into its cut-off (M = 12 pieces cannot clear 10 rows; a cut-off of 4 keeps it short): status 1
     and zeroed outputs for those, the launch ends, the others are untouched -- host and device alike."""
