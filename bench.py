@@ -147,6 +147,13 @@ def measure_fused_rollout(torch, T, env, actions, first, K, chunk, compact=False
     return timed(torch, dev, run, 1) / (launches * chunk)
 
 
+def action_rows(actions):
+    """The rows of an [S, n] action tensor as S views made ONCE.  `actions[t]` inside a loop builds a new view object per step
+    (0.8 us of Python): nothing at 2^20 boards, a seventh of the period at a shard's 131,072, where the host's calls per second
+    are the limit (tools/step_issue_rate.py, tools/step_issue_breakdown.py) -- and no part of what is being measured."""
+    return list(actions.unbind(0))
+
+
 def measure_weak_job(torch, T, dev, rank, world, L, M, per_gpu, seed, K, barrier, max_over_ranks):
     """Side figure for N > 1 (the headline is BASELINE configs[3], fixed total work): `per_gpu` boards on EVERY rank,
     i.e. a job that grows with the node.  Same pool on every rank, everything keyed by the global board index."""
@@ -163,12 +170,13 @@ def measure_weak_job(torch, T, dev, rank, world, L, M, per_gpu, seed, K, barrier
         env.synthetic_actions(t, out=actions[t])
     reward = torch.empty(shard.boards, dtype=torch.float32, device=dev)
     done = torch.empty(shard.boards, dtype=torch.uint8, device=dev)
+    rows_of = action_rows(actions)
     for t in range(20):
-        env.step_into(actions[t % S], reward, done)
+        env.step_into(rows_of[t % S], reward, done)
     torch.cuda.synchronize(dev)
     barrier()
     step = iter(range(S))
-    ms = max_over_ranks(timed(torch, dev, lambda: env.step_into(actions[next(step)], reward, done), S))
+    ms = max_over_ranks(timed(torch, dev, lambda: env.step_into(rows_of[next(step)], reward, done), S))
     env.terminate()
     gbs = ALGO_BYTES_PER_BOARD_STEP * per_gpu / (ms * 1e-3) / 1e9
     return {"scaling": "weak", "boards_per_gpu": per_gpu, "global_boards": shard.global_boards, "unit": "env-steps/s",
@@ -196,8 +204,9 @@ def measure_shard_run(torch, T, dev, L, M, seed, total, ranks, chunk):
         env.synthetic_actions(t, out=actions[t])
     reward = torch.empty(n, dtype=torch.float32, device=dev)
     done = torch.empty(n, dtype=torch.uint8, device=dev)
+    rows_of = action_rows(actions)
     for t in range(50):
-        env.step_into(actions[t % S], reward, done)
+        env.step_into(rows_of[t % S], reward, done)
     torch.cuda.synchronize(dev)
 
     def leg(ms, **more):
@@ -205,7 +214,7 @@ def measure_shard_run(torch, T, dev, L, M, seed, total, ranks, chunk):
         return dict({"us_per_step": ms * 1e3, "value_per_gpu": float(n) / (ms * 1e-3), "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
                      f"value_x{ranks}_if_every_rank_matches": float(n) * ranks / (ms * 1e-3)}, **more)
     step = iter(range(S))
-    ms_step = timed(torch, dev, lambda: env.step_into(actions[next(step)], reward, done), S)
+    ms_step = timed(torch, dev, lambda: env.step_into(rows_of[next(step)], reward, done), S)
     rs = torch.empty((chunk, n), dtype=torch.float32, device=dev)
     ds = torch.empty((chunk, n), dtype=torch.uint8, device=dev)
     replay = env.capture_steps(actions[:chunk], rs, ds)
@@ -450,11 +459,12 @@ def measure_config1(torch, T, dev, seed, chunk):
         env.synthetic_actions(t, out=actions[t])
     reward = torch.empty(n, dtype=torch.float32, device=dev)
     done = torch.empty(n, dtype=torch.uint8, device=dev)
+    rows_of = action_rows(actions)
     for t in range(50):
-        env.step_into(actions[t], reward, done)
+        env.step_into(rows_of[t], reward, done)
     torch.cuda.synchronize(dev)
     step = iter(range(K))
-    ms = timed(torch, dev, lambda: env.step_into(actions[next(step)], reward, done), K)
+    ms = timed(torch, dev, lambda: env.step_into(rows_of[next(step)], reward, done), K)
     out = {"workload": f"{n} boards, random initial configs, L={L} M={M}, auto-reset, uniform actions", "unit": "env-steps/s",
            "value": float(n) / (ms * 1e-3), "ms_per_step": ms,
            "roofline": {"bound": "hbm", "achieved": ALGO_BYTES_PER_BOARD_STEP * n / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
@@ -478,13 +488,13 @@ def measure_config1(torch, T, dev, seed, chunk):
     step = iter(range(2 * K))
 
     def two_launches():
-        env.step_into(actions[next(step) % K], reward, done)
+        env.step_into(rows_of[next(step) % K], reward, done)
         env.observe(out=obs)
     for t in range(20):
-        env.step_observe_into(actions[t], reward, done, obs)
+        env.step_observe_into(rows_of[t], reward, done, obs)
     torch.cuda.synchronize(dev)
     ms_two = timed(torch, dev, two_launches, K)
-    ms_one = timed(torch, dev, lambda: env.step_observe_into(actions[next(step) % K], reward, done, obs), K)
+    ms_one = timed(torch, dev, lambda: env.step_observe_into(rows_of[next(step) % K], reward, done, obs), K)
     bytes_moved = (32 + 32 + 1 + 4 + 1 + 217 * 4) * n            # state in and out, action, reward, done, observation
     out["obs_step"] = {"unit": "env-steps/s", "observation": "float32 [n, 217] written every step",
                        "step_then_observe": {"value": float(n) / (ms_two * 1e-3), "ms_per_step": ms_two, "launches": 2},
@@ -633,8 +643,9 @@ def main():
     # warm-up steps is enqueued after the synchronize, directly ahead of the first timed launch ("between two
     # stream-synchronised hipEvents, excluding one warm-up"): a launch into a queue that has run dry pays the GPU's
     # wake-up (20-160 us by how long it idled, tools/launch_probe.py), which is not a property of a step.
+    rows_of = action_rows(actions)              # the row views, made once: at a shard's size the host's call rate is the period
     for t in range(max(W - 1, 0)):
-        env.step_into(actions[t % S], reward, done)
+        env.step_into(rows_of[t % S], reward, done)
     T.sharding.mean_episodic_return(env.stats_tensor(), env.reward_params)   # load the reduction kernels / RCCL rings
     torch.cuda.synchronize(dev)
     barrier()
@@ -644,10 +655,10 @@ def main():
     t0 = time.perf_counter()
     ev_w.record()                                                 # same stream as the kernel launches
     if W >= 1:
-        env.step_into(actions[(W - 1) % S], reward, done)        # warm-up step W of W: takes the idle queue's wake-up
+        env.step_into(rows_of[(W - 1) % S], reward, done)        # warm-up step W of W: takes the idle queue's wake-up
     ev_a.record()
     for t in range(W, W + K):
-        env.step_into(actions[t % S], reward, done)
+        env.step_into(rows_of[t % S], reward, done)
     ev_c.record()
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
