@@ -68,14 +68,14 @@ struct CarveArgs {
 };
 
 // A shape as this kernel reads it (32 bytes of the wave's LDS table, made from kShapeTable at the kernel's start):
-//   x   = column nibbles (16 bits) | places the piece can stand, 10 - w + 1, << 16 | 20 - h << 24 (a byte each)
+//   x    = column nibbles (16 bits) | places the piece can stand, 10 - w + 1, << 16 | 20 - h << 24 (a byte each)
+//   cols = the column nibbles again, a BYTE each: a byte of a register is an operand (SDWA), a nibble takes an extract
 //   B[k] = per column k the constant 128 bias_k + 32 k,  bias_k = 3 - reverse topography, or 64 past the width (a word each:
 //          an operand as it is read).
 // With c_k = the top of column k (v_ffbl: the columns carry a sentinel bit at row 20, so an empty one reads 20), the KEY
 // 129 c_k + B_k = 128 (c_k + bias_k) + 32 k + c_k orders the columns by c_k + bias_k, equal sums by k (c_k <= 20 < 32), and
 // carries c_k in its low five bits: the minimum of four keys is np.argmin's column (:298), its c_k and its sum in one go --
 // three instructions a column where compare / minimum / select on two values were six.
-//   cols = the column nibbles again, a BYTE each: a byte of a register is an operand (SDWA), a nibble takes an extract
 struct alignas(16) CarveShape { uint32_t x, cols, spare0, spare1, B[4]; };
 struct DShape { uint32_t pat16, places, room, cols, B[4]; };              // room = 20 - h: the deepest drop that stays inside
 
@@ -325,6 +325,15 @@ template <typename T> __device__ __forceinline__ void lds_store(T* p, T v) {
 // while 64-thread blocks land wherever a slot is free -- with 4096 of them some SIMDs ran six waves and some two, and a
 // persistent wave keeps its place for the whole launch (trips of 1.2 to 2.7 us side by side, profiles/r04_carve/NOTES).
 constexpr int kWavesPerBlock = 4;
+// what one wave keeps in LDS
+struct WaveLds {
+    uint32_t col[kCols + kPadCols][kColStride];     // the boards' columns, lane-major
+    uint32_t top[kCols + 1][kColStride];            // the top checkpoint of every lane: ten columns, then length | bottom << 16
+    // per configuration taken from the queue by lane i of this wave (indexed by i, its "home"): state word, tickets handed out
+    unsigned long long state[64];
+    uint32_t ticket[64];
+    CarveShape shape[32];                           // the shape table
+};
 constexpr int kQueueChunk = 16;            // configurations a wave takes from the queue per atomic
 // trips of the search between two looks at the queue, the helpers and the state words: 32 where a search takes hundreds of
 // trips or more (L >= 8: median 400 and up), 8 below (measured at L = 10, 2^20 configurations: 4 -> 50 M/s, 8 -> 55, 16 -> 56,
@@ -347,17 +356,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     w.cps = w.sol_rev + 512u;
 
     // everything in LDS is per WAVE (no barrier anywhere: a wave runs in lockstep with itself)
-    __shared__ uint32_t s_col_all[kWavesPerBlock][kCols + kPadCols][kColStride];
-    __shared__ uint32_t s_top_all[kWavesPerBlock][kCols + 1][kColStride];
-    // per configuration taken from the queue by lane i of this wave (indexed by i, its "home"): state word, tickets handed out
-    __shared__ unsigned long long s_state_all[kWavesPerBlock][64];
-    __shared__ uint32_t s_ticket_all[kWavesPerBlock][64];
-    __shared__ CarveShape s_shape_all[kWavesPerBlock][32];
-    uint32_t (*s_col)[kColStride] = s_col_all[wave_in_block];
-    uint32_t (*s_top)[kColStride] = s_top_all[wave_in_block];
-    unsigned long long* s_state = s_state_all[wave_in_block];
-    uint32_t* s_ticket = s_ticket_all[wave_in_block];
-    CarveShape* s_shape = s_shape_all[wave_in_block];
+    __shared__ WaveLds s_lds[kWavesPerBlock];
+    WaveLds& mine = s_lds[wave_in_block];
+    uint32_t (*s_col)[kColStride] = mine.col;
+    uint32_t (*s_top)[kColStride] = mine.top;
+    unsigned long long* s_state = mine.state;
+    uint32_t* s_ticket = mine.ticket;
+    CarveShape* s_shape = mine.shape;
     if (lane < 32) s_shape[lane] = carve_shape(kShapeTable[lane]);
     Search g;
     g.col = &s_col[0][lane];
@@ -616,7 +621,7 @@ extern "C" int tpl_generate_configs_device_waves(int32_t L, int32_t M, uint64_t 
     TPL_HIP(hipMemsetAsync(p.next, 0, 64, (hipStream_t)stream));
     // LDS per block padded to a quarter of a CU's 160 KB: no CU takes more than four blocks (one wave of each per SIMD), so a
     // full launch of 1024 blocks sits four to every CU instead of three here and five there
-    constexpr size_t kLdsPerBlock = 160 * 1024 / kWavesPerSimd, kLdsStatic = 31744;
+    constexpr size_t kLdsPerBlock = 160 * 1024 / kWavesPerSimd, kLdsStatic = sizeof(WaveLds) * kWavesPerBlock;
     static_assert(kLdsStatic <= kLdsPerBlock, "the kernel's LDS arrays outgrew the padding");
     hipLaunchKernelGGL(carve_kernel, dim3((unsigned)blocks), dim3(256), kLdsPerBlock - kLdsStatic, (hipStream_t)stream, p);
     TPL_HIP(hipGetLastError());
