@@ -117,7 +117,9 @@ __device__ __forceinline__ int rest_of(const uint32_t* d, const DShape& s) { ret
 // Straight-line: its three tests (inside the board :317-318, every cell of the piece filled :321-329, the piece comes to rest
 // where it was carved :341-349) are all computed and combined.  Early exits here were nested divergent regions that a wave
 // of 64 searches entered on every trip anyway -- some lane passes each test -- at a dozen scalar instructions and two branches
-// a test.  (A drop outside the board may shift the piece onto the sentinel; it is refused whatever the other tests say.)
+// a test.  (A drop outside the board -- an empty column under the piece reads 20 -- would shift the piece onto the sentinel:
+// the sentinel is put back with the same instruction that takes the piece out, so that no column is ever zero when its top is
+// asked for, and the carve is refused by the first test whatever the others say.)
 __device__ __forceinline__ bool try_carve(const uint32_t* d, int drop, const DShape& s, bool allow_partial, uint32_t* after) {
     const bool inside = (uint32_t)drop <= s.room;                           // :317-318: 0 <= drop and drop + h <= 20, as one comparison
     const uint32_t shift = (uint32_t)drop & 31u;
@@ -126,7 +128,7 @@ __device__ __forceinline__ bool try_carve(const uint32_t* d, int drop, const DSh
     for (int k = 0; k < 4; ++k) {
         const uint32_t m = ((s.cols >> (8 * k)) & 0xFFu) << shift;
         missing |= m & ~d[k];
-        after[k] = d[k] & ~m;                                               // :332-337
+        after[k] = (d[k] & ~m) | kFloor;                                    // :332-337 (one three-input bit operation; see below)
     }
     const bool rests = rest_of(after, s) == drop;                           // :341-349: the piece must come to rest there
     return inside & (allow_partial | (missing == 0u)) & rests;              // :321-329
