@@ -304,9 +304,9 @@ def measure_config_supply(torch, T, dev, L, M, seed):
 def measure_live_supply(torch, T, env, actions, reward, done, seed, count=65536, min_swaps=3, min_steps=4000, max_steps=40000, **where):
     """The replenished supply under load (game/tetris.py:195-211, 473-488: producers feed the reset queue while games
     run): PoolRefresher carves `count` configurations at a time on a side stream while the main stream steps, and each
-    finished batch becomes the current pool (boards in mid-episode finish on the buffer they started from).  Runs until
-    `min_swaps` batches have been swapped in (and at least `min_steps` steps); the supply rate is batches between the
-    first and the last swap over the wall time between them.  `where` = PoolRefresher's waves / reserved_cus / low_priority."""
+    finished batch becomes the current pool (boards in mid-episode finish on the buffer they started from).  Steady state:
+    the timed region starts at the FIRST swap and runs until `min_swaps` more batches have been swapped in (and at least
+    `min_steps` steps); the supply rate is those batches over the wall time between the first and the last swap.  `where` = PoolRefresher's waves / reserved_cus / low_priority."""
     n, dev, S = env.num_envs, env.device, actions.shape[0]
     rows, pieces = T.generate_configs(env.L, env.M, 4096, seed=seed)          # something carved to start from
     if env.n_configs:
@@ -318,14 +318,21 @@ def measure_live_supply(torch, T, env, actions, reward, done, seed, count=65536,
     torch.cuda.synchronize(dev)
     ms_alone = timed(torch, dev, lambda: env.step_into(actions[0], reward, done), 500)
     feeder = T.PoolRefresher(env, count, seed=seed, first=4096, **where)
+    # the supplier's first batch is its start-up (the generator's code is loaded, its work memory and the batch's tensors are
+    # allocated -- a hipMalloc is a device synchronisation): stepped through untimed, the timed region begins at the first swap
+    lead = 0
+    while lead < max_steps and not feeder.poll():
+        for t in range(32):
+            env.step_into(actions[(lead + t) % S], reward, done)
+        lead += 32
     episodes0 = env.stats()["episodes"]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    swap_times = []
+    swap_times = [time.perf_counter()]
     e0.record()
     steps = 0
-    while steps < max_steps and (steps < min_steps or len(swap_times) < min_swaps):
+    while steps < max_steps and (steps < min_steps or len(swap_times) < min_swaps + 1):
         for t in range(32):
-            env.step_into(actions[(steps + t) % S], reward, done)
+            env.step_into(actions[(lead + steps + t) % S], reward, done)
         steps += 32
         if feeder.poll():
             swap_times.append(time.perf_counter())       # the host loop runs a bounded queue ahead of the GPU: wall time tracks it
@@ -336,7 +343,8 @@ def measure_live_supply(torch, T, env, actions, reward, done, seed, count=65536,
     feeder.close()
     fresh_per_s = (len(swap_times) - 1) * count / (swap_times[-1] - swap_times[0]) if len(swap_times) >= 2 else None
     return {"unit": "env-steps/s", "value": float(n) / (ms * 1e-3), "ms_per_step": ms, "ms_per_step_without_refresher": ms_alone,
-            "slowdown": ms / ms_alone, "configurations_per_batch": count, "pool_swaps": len(swap_times), "steps": steps,
+            "slowdown": ms / ms_alone, "configurations_per_batch": count, "pool_swaps": len(swap_times) - 1, "steps": steps,
+            "steps_before_the_first_swap_untimed": lead,
             "configurations_supplied_per_s": fresh_per_s, "resets_per_s": resets_per_s,
             # the reference's reset() blocks on queue.get() (game/tetris.py:445-447): every episode a fresh game, factor 1
             "pool_reuse_factor": (resets_per_s / fresh_per_s) if fresh_per_s else None}
