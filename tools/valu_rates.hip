@@ -129,6 +129,18 @@ KERNEL(k_one_cndmask_e64_in_eight, DECL32_VCC, C24)
 #define C25(i) asm volatile("v_cndmask_b32 %0, %1, %1, vcc" : "=v"(r[i]) : "v"(a));
 KERNEL(k_cndmask_b32_vcc_independent, DECL32_VCC, C25)
 
+// shifts: left and right, by a constant and by a register
+#define D1(i) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(r[i]));
+KERNEL(k_lshlrev_b32_by_3, DECL32, D1)
+#define D2(i) asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(r[i]) : "v"(a));
+KERNEL(k_lshlrev_b32_by_vgpr, DECL32, D2)
+#define D3(i) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(r[i]) : "v"(a));
+KERNEL(k_lshrrev_b32_by_vgpr, DECL32, D3)
+#define D4(i) asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(r[i]));
+KERNEL(k_ashrrev_i32, DECL32, D4)
+#define D5(i) asm volatile("v_sub_u32 %0, %1, %0" : "+v"(r[i]) : "v"(a));
+KERNEL(k_subrev_like, DECL32, D5)
+
 // 64-bit destinations
 #define DECL64                                                                                                         \
     uint64_t r[8]; uint32_t a = seed + threadIdx.x; uint64_t a64 = ((uint64_t)seed << 32) | threadIdx.x;              \
@@ -176,7 +188,8 @@ int main() {
         {"v_cmp_lt_u32 -> vcc", k_cmp_lt_u32_to_vcc}, {"v_cndmask_b32 (vcc, set)", k_cndmask_b32_vcc_set}, {"v_cndmask_b32_e64 (vcc)", k_cndmask_b32_e64_vcc},
         {"v_cndmask_b32 (vcc) dest != src", k_cndmask_b32_vcc_independent},
         {"1 cndmask(vcc) + 7 mul_u24", k_one_cndmask_vcc_in_eight}, {"1 cndmask_e64 + 7 mul_u24", k_one_cndmask_e64_in_eight},
-        {"v_addc_co_u32 (vcc)", k_addc_co_u32}, {"v_or_b32", k_or_b32}, {"v_lshrrev_b32", k_lshrrev_b32}, {"v_max_u32", k_max_u32}, {"v_mul_f32", k_mul_f32},
+        {"v_addc_co_u32 (vcc)", k_addc_co_u32}, {"v_or_b32", k_or_b32}, {"v_lshrrev_b32", k_lshrrev_b32}, {"v_lshlrev_b32 by 3", k_lshlrev_b32_by_3}, {"v_lshlrev_b32 by a register", k_lshlrev_b32_by_vgpr},
+        {"v_lshrrev_b32 by a register", k_lshrrev_b32_by_vgpr}, {"v_ashrrev_i32", k_ashrrev_i32}, {"v_sub_u32 (operands swapped)", k_subrev_like}, {"v_max_u32", k_max_u32}, {"v_mul_f32", k_mul_f32},
         {"v_xad_u32", k_xad_u32}, {"v_lshl_add_u32", k_lshl_add_u32}, {"v_mul_lo_u32", k_mul_lo_u32}, {"v_mul_hi_u32", k_mul_hi_u32}, {"v_mul_u32_u24", k_mul_u32_u24},
         {"v_mul_i32_i24", k_mul_i32_i24}, {"v_mad_u32_u24", k_mad_u32_u24}, {"v_ffbl_b32", k_ffbl_b32}, {"v_bcnt_u32_b32", k_bcnt_u32_b32},
         {"v_bitop3_b32", k_bitop3_b32}, {"v_add3_u32", k_add3_u32}, {"v_lshl_or_b32", k_lshl_or_b32},
