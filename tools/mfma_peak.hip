@@ -53,6 +53,25 @@ __global__ __launch_bounds__(256) void mfma32_kernel(float* out, int iters, unsi
     if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = c1 - c0; clocks[1] = r1 - r0; }
 }
 
+// the float32 pipe: v_mfma_f32_16x16x4_f32 (2048 flops an instruction), eight independent accumulators
+__global__ __launch_bounds__(256) void mfma_f32_kernel(float* out, int iters, unsigned long long* clocks) {
+    float a = 0.001f * (float)threadIdx.x, b = 0.002f * (float)(threadIdx.x * 3);
+    f32x4 acc[8];
+    for (int k = 0; k < 8; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[k], 0, 0, 0);
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+    float s = 0.f;
+    for (int k = 0; k < 8; ++k) s += acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = c1 - c0; clocks[1] = r1 - r0; }
+}
+
 int main() {
     float* out; unsigned long long* clocks;
     CK(hipMalloc(&out, 4096)); CK(hipMalloc(&clocks, 16));
@@ -88,6 +107,20 @@ int main() {
         const double flops = 2.0 * 32 * 32 * 16 * 16.0 * iters * (double)blocks * 4;
         printf("32x32x16: %d wave(s) per SIMD, %6d x 16 MFMAs per wave: %8.3f ms = %7.1f TFLOP/s = %.3f of 2500; shader clock in the loop %.3f GHz\n",
                waves_per_simd, iters, ms, flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12 / 2500.0, (double)h[0] / ((double)h[1] * 10.0));
+    }
+    for (int waves_per_simd : {1, 2, 4}) {
+        const int iters = 60000, blocks = 256 * waves_per_simd;
+        hipLaunchKernelGGL(mfma_f32_kernel, dim3(blocks), dim3(256), 0, 0, out, 200, clocks);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(mfma_f32_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, clocks);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        unsigned long long h[2]; CK(hipMemcpy(h, clocks, 16, hipMemcpyDeviceToHost));
+        const double flops = 2.0 * 16 * 16 * 4 * 32.0 * iters * (double)blocks * 4;
+        printf("f32 16x16x4: %d wave(s) per SIMD, %6d x 32 MFMAs per wave: %8.3f ms = %7.1f TFLOP/s = %.3f of 157.3; shader clock in the loop %.3f GHz\n",
+               waves_per_simd, iters, ms, flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12 / 157.3, (double)h[0] / ((double)h[1] * 10.0));
     }
     return 0;
 }
