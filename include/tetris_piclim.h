@@ -288,11 +288,18 @@ int tpl_set_tuning(tpl_env* env, int32_t boards_per_lane, int32_t block_threads)
  * first+i draws decision k as a 32-bit hash of key + k * stride, (key, stride) = the halves of rng(seed, 4, first+i, a),
  * top 24 bits reduced to [lo, hi] by a multiply; (2) the restart rule -- the reference's search loop has no bound and an
  * exponentially distributed length, so configuration first+i is the outcome of the FIRST attempt a = 0, 1, ... 23 that ends
- * within its iteration cut-off: `cutoff` for attempts 0-11, twice that for 12-17, four times for 18-23 -- with cutoff = 0,
- * about twice the median search length at this L.
- * The output depends on (L, M, seed, first+i, cutoff) only -- not on `threads`, and it is the same on the device.  If all
- * 24 attempts run into their cut-off (an (L, M) that cannot be carved, e.g. M pieces too few for L rows) the
- * configuration's outputs are zeroed and the call returns TPL_ERR_STATE after finishing the others.  1 <= L <= 16. */
+ * within its iteration cut-off: `cutoff` for attempts 0-11, then doubling with every attempt (2 x for attempt 12, 4 x for 13,
+ * ... 256 x for 19 and for 20-23; never above 2^28) -- with cutoff = 0, about twice the median search length at this L as
+ * measured at M = 40 (an M close to the fewest pieces that can clear L rows searches far longer: the doubling is for that).
+ * ABI NOTE (library version 0.2): this argument was `max_iters` through library 0.1 as shipped in round 3 -- ONE search per
+ * configuration, 0 = unbounded.  It is now the restart rule's base cut-off, 0 = by L: a caller written against the old meaning
+ * gets different configurations (the type is the same, nothing fails); tpl_version() tells the two apart.
+ * The output depends on (L, M, seed, first+i, cutoff) only -- not on `threads`, and it is the same on the device.  Before a
+ * batch goes out ONE fixed configuration is tried on the host (the verdict is kept per (L, M, cutoff)): TPL_ERR_ARG when M is
+ * below the fewest pieces that can dig two columns of L cells (ceil(L / 2)), TPL_ERR_STATE when all of its 24 attempts run
+ * into their cut-offs -- nothing is generated then.  If all 24 attempts of a configuration of the batch run into their
+ * cut-offs its outputs are zeroed and the call returns TPL_ERR_STATE after finishing the others ("did not finish within the
+ * rule's bound", not "cannot be carved": a larger `cutoff` searches on).  1 <= L <= 16. */
 int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count, int32_t threads,
                          int64_t cutoff, uint16_t* rows, uint8_t* pieces, uint8_t* solution,
                          int32_t* solution_len);
@@ -300,6 +307,8 @@ int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t first, int
 /* The same generator on the GPU: same decisions, same restart rule, same output as tpl_generate_configs, for
  * refreshing a device pool without the host (whose container may own only a few CPUs).  DEVICE pointers; `status`
  * [count] (optional) is 1 for a configuration whose 24 attempts all ran into their cut-off (outputs zeroed), else 0.
+ * The same host-side pilot as tpl_generate_configs runs before the launch (an (L, M) that does not carve would otherwise be
+ * a kernel that runs for minutes): TPL_ERR_ARG / TPL_ERR_STATE, nothing launched.
  * `work`: tpl_generate_configs_device_work_bytes(M, count) bytes, 8-byte aligned. */
 size_t tpl_generate_configs_device_work_bytes(int32_t M, int64_t count);
 /* The kernel is persistent: its lanes take configurations from a queue until none are left (a lane that held one

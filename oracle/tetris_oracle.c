@@ -572,7 +572,8 @@ int64_t to_generate_config_tape(int L, int M, const int32_t* tape, int64_t n, in
  * takes a stream word of its own, its top 24 bits reduced to [lo, hi] as lo + ((top24 * (hi - lo + 1)) >> 24).
  *
  * Restart rule: the configuration is what the FIRST attempt a = 0, 1, ... 23 builds whose search loop (:234) ends within
- * limit(a) trips -- base for attempts 0-11, 2 base for 12-17, 4 base for 18-23 -- base = `cutoff` if positive, else the table
+ * limit(a) trips -- base for attempts 0-11, then doubling with every attempt (2 base for 12, 4 base for 13, ... 256 base for
+ * 19 and for 20-23; never above 2^28) -- base = `cutoff` if positive, else the table
  * below (about twice the median search length at that L).  Every attempt starts from the full stack with its own stream.  If all 24 attempts run into their limit the
  * configuration is capped: all-zero rows and pieces, no solution, return value -1. */
 typedef struct { uint32_t key, stride, counter, word; int asked, searching; } seeded_ctx;
@@ -602,7 +603,8 @@ static const int64_t carve_base_limit[17] = {0, 64, 64, 64, 128, 256, 384, 512, 
 
 int64_t to_carve_attempt_limit(int L, int64_t cutoff, int attempt) {
     int64_t base = cutoff > 0 ? cutoff : carve_base_limit[L < 1 ? 1 : L > 16 ? 16 : L];
-    return base << (attempt < 12 ? 0 : (attempt - 12) / 6 + 1);
+    int64_t grown = base << (attempt < 12 ? 0 : attempt - 11 < 8 ? attempt - 11 : 8);
+    return grown < ((int64_t)1 << 28) ? grown : ((int64_t)1 << 28);
 }
 
 int64_t to_generate_config_seeded(int L, int M, uint64_t seed, uint64_t index, int64_t cutoff,

@@ -221,13 +221,15 @@ def carve(rows, piece: int, rotations: int, location: int, allow_partial: bool):
     return bool(ok.value), r
 
 
-def generate_configs(L: int, M: int, count: int = 0, seed: int = 0, first: int = 0, threads: int = 0,
+def generate_configs(L: int, M: int, count: int = 0, seed: int = 0, first: int = 0, threads: int = 0, *,
                      cutoff: int = 0, with_solutions: bool = False, python_seeds=None, max_iters: int = 0):
     """Carved (solvable) prescribed configurations, produced on the host cores (game/tetris.py:226-352).
 
     Returns (rows uint16 [count, 20], pieces uint8 [count, M+1]) and, with_solutions, also
     (solution uint8 [count, M, 2], solution_len int32 [count]).  Configuration i is the first attempt of (seed, first + i)
-    that ends within the restart rule's iteration cut-off (`cutoff` overrides it; 0 = by L).  With
+    that ends within the restart rule's iteration cut-off (`cutoff` overrides its base; 0 = by L).  Everything after `threads`
+    is keyword only: through round 3 the seventh positional argument was `max_iters` (one search, 0 = unbounded), since round 4
+    it is the restart rule's `cutoff` -- a positional caller would silently get the other meaning.  With
     python_seeds=[s0, s1, ...] configuration i is exactly what the reference builds after random.seed(s_i) (CPython's
     random stream is reproduced; one search each, `max_iters` > 0 bounds it)."""
     import numpy as np

@@ -14,7 +14,10 @@
 
 #include <atomic>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 namespace tpl {
@@ -116,7 +119,7 @@ inline bool carve(uint32_t* col, int piece, int rotations, int loc, bool allow_p
 // _generate_initial_config (:226-284) for one configuration.  Returns false if max_iters (> 0) was reached.
 template <typename Random>
 bool generate_one(int L, int M, Random& rnd, int64_t max_iters, uint16_t* rows_out, uint8_t* pieces_out,
-                  uint8_t* sol_out, int32_t* sol_len) {
+                  uint8_t* sol_out, int32_t* sol_len, const std::atomic<bool>* stop = nullptr) {
     Game g;
     const uint32_t filled = L >= kRows ? kColMask : (((1u << L) - 1u) << (kRows - L));
     for (int c = 0; c < kCols; ++c) g.col[c] = filled;                      // :228 L full rows
@@ -134,6 +137,7 @@ bool generate_one(int L, int M, Random& rnd, int64_t max_iters, uint16_t* rows_o
     auto bottom_cells = [&] { int k = 0; for (int c = 0; c < kCols; ++c) k += (g.col[c] >> (kRows - 1)) & 1u; return k; };
     while (bottom_cells() > 8) {                                            // :234
         if (max_iters > 0 && iters++ >= max_iters) return false;
+        if (stop && (iters & 4095) == 0 && stop->load(std::memory_order_relaxed)) return false;   // the pilot's other attempts
         bool fresh_bag = false;                                             // _regenerate (:71-81)
         if (n_bag == 0) { for (int k = 0; k < 7; ++k) bag[k] = (uint8_t)k; n_bag = 7; fresh_bag = true; }
         int idx, rotations;
@@ -185,6 +189,64 @@ bool generate_one(int L, int M, Random& rnd, int64_t max_iters, uint16_t* rows_o
 }  // namespace
 }  // namespace tpl
 
+
+// One configuration tried on the host before a batch goes out (tpl_internal.h).  The restart rule bounds every
+// configuration at some 1,500 base cut-offs; a batch of an (L, M) that cannot be carved at all would spend that on EVERY
+// configuration -- minutes of host threads, or a kernel that runs for minutes -- so the generators first run the rule on
+// one fixed configuration (seed 0x7E7215, index 0; the verdict is kept per (L, M, cut-off)): attempts 0-11 one after the
+// other (a normal (L, M) is through with the first: a third of a millisecond at L = 10), the doubled ones side by side.
+int tpl::carve_pilot(int32_t L, int32_t M, int64_t cutoff) {
+    if (M < carve_fewest_pieces(L))
+        return fail_msg(TPL_ERR_ARG, "L=%d cannot be carved with M=%d pieces: two columns of %d cells need at least %d", L, M, L,
+                        carve_fewest_pieces(L));
+    static std::mutex mu;
+    static std::map<std::tuple<int32_t, int32_t, int64_t>, bool> verdicts;
+    const auto key = std::make_tuple(L, M, cutoff);
+    bool known = false, ok = false;
+    {
+        std::lock_guard<std::mutex> hold(mu);
+        const auto it = verdicts.find(key);
+        if (it != verdicts.end()) { known = true; ok = it->second; }
+    }
+    if (!known) {
+        constexpr uint64_t kPilotSeed = 0x7E7215ULL;
+        uint16_t rows[kRows];
+        uint8_t pieces[256];
+        for (int a = 0; a < 12 && !ok; ++a) {
+            Decisions rnd(kPilotSeed, 0, (uint32_t)a);
+            ok = generate_one(L, M, rnd, carve_cutoff(L, cutoff, a), rows, pieces, nullptr, nullptr);
+        }
+        if (!ok) {
+            std::atomic<bool> found{false};
+            std::atomic<int> next{12};
+            auto work = [&] {
+                uint16_t r[kRows];
+                uint8_t p[256];
+                for (;;) {
+                    const int a = next.fetch_add(1);
+                    if (a >= kCarveAttempts || found.load()) return;
+                    Decisions rnd(kPilotSeed, 0, (uint32_t)a);
+                    if (generate_one(L, M, rnd, carve_cutoff(L, cutoff, a), r, p, nullptr, nullptr, &found)) found.store(true);
+                }
+            };
+            int threads = (int)std::thread::hardware_concurrency();
+            threads = threads < 1 ? 1 : threads > kCarveAttempts - 12 ? kCarveAttempts - 12 : threads;
+            std::vector<std::thread> pool;
+            for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+            work();
+            for (auto& th : pool) th.join();
+            ok = found.load();
+        }
+        std::lock_guard<std::mutex> hold(mu);
+        verdicts[key] = ok;
+    }
+    if (!ok)
+        return fail_msg(TPL_ERR_STATE, "L=%d M=%d: the pilot configuration did not finish within %d attempts (base cut-off %lld "
+                        "trips, the last ones at %lld): not finished within the restart rule's bound -- a larger `cutoff` searches on",
+                        L, M, kCarveAttempts, (long long)carve_cutoff(L, cutoff, 0), (long long)carve_cutoff(L, cutoff, kCarveAttempts - 1));
+    return TPL_OK;
+}
+
 // `build(k)` fills configuration k's outputs and says whether it finished
 template <typename BuildOne>
 static int run_generator(int32_t L, int32_t M, int64_t count, int32_t threads, uint16_t* rows, uint8_t* pieces, BuildOne build) {
@@ -209,8 +271,8 @@ static int run_generator(int32_t L, int32_t M, int64_t count, int32_t threads, u
     work();
     for (auto& th : pool) th.join();
     if (failed.load() >= 0)
-        return fail_msg(TPL_ERR_STATE, "configuration %lld did not finish (every attempt ran into its iteration limit)",
-                        (long long)failed.load());
+        return fail_msg(TPL_ERR_STATE, "configuration %lld did not finish: every attempt of the restart rule ran into its cut-off "
+                        "(L=%d M=%d; a larger `cutoff` searches on)", (long long)failed.load(), L, M);
     return TPL_OK;
 }
 
@@ -220,6 +282,7 @@ extern "C" int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t
     using namespace tpl;
     if (first < 0) return fail_msg(TPL_ERR_ARG, "first is negative");
     if (cutoff < 0 || cutoff > ((int64_t)1 << 28)) return fail_msg(TPL_ERR_ARG, "cutoff outside [0, 2^28]");
+    if (L >= 1 && L <= 16 && M >= 1 && M <= 254) { const int rc = carve_pilot(L, M, cutoff); if (rc != TPL_OK) return rc; }
     return run_generator(L, M, count, threads, rows, pieces, [=](int64_t k) {
         uint8_t* sol = solution ? solution + k * (int64_t)M * 2 : nullptr;
         int32_t* len = solution_len ? solution_len + k : nullptr;

@@ -772,7 +772,7 @@ extern "C" {
 
 const char* tpl_last_error(void) { return g_err; }
 
-const char* tpl_version(void) { return "tetris_piclim 0.1.0 (gfx950)"; }
+const char* tpl_version(void) { return "tetris_piclim 0.2.0 (gfx950)"; }
 
 size_t tpl_workspace_bytes(int64_t num_envs, int32_t M) {
     if (num_envs <= 0 || M < 1) return 0;

@@ -481,12 +481,21 @@ __host__ __device__ __forceinline__ int decision(DecisionStream& s, int lo, int 
 // stream, each starting from the full stack) that ends within  carve_cutoff(L, cutoff, a)  trips of the while loop.  A
 // cut-off of about twice the median search costs 1-3 % more iterations in total (a memoryless search loses only its
 // warm-up when restarted) and bounds every attempt -- which is what lets the device generator run the attempts of one
-// straggling configuration on many lanes at once and still return exactly this configuration (carve_device.hip).  After
-// kCarveAttempts failed attempts the configuration is reported as capped (all-zero outputs); the cut-off doubles after twelve
-// attempts and again after eighteen, for an (L, M) whose searches are longer than the table's.
+// straggling configuration on many lanes at once and still return exactly this configuration (carve_device.hip).
+// The table's cut-offs were measured at M = 40.  Where M is close to the fewest pieces that can dig two columns down to the
+// bottom row (L = 15 with M = 16: a search of a million trips against the table's 64,000) almost every attempt at the base
+// cut-off fails, so from the thirteenth attempt on the cut-off DOUBLES with every attempt until it is 256 times the base
+// (attempts 19-23; never above 2^28 trips): the trips lost to failed attempts stay within a small multiple of the one that
+// succeeds, and a search may be 256 times as long as the table expects (2^24 trips at L = 15) before anything is given up.
+// Only when all kCarveAttempts attempts have run into their cut-offs is the configuration reported as capped (all-zero
+// outputs): "this (L, M) did not finish within 256 x the base cut-off" -- not "cannot be carved": a caller who wants to
+// search on passes a larger `cutoff` (up to 2^28).  The bound is there because an unbounded search on the DEVICE is a kernel
+// that may never end; the generators also try ONE configuration on the host before a batch goes out (carve_pilot).
 constexpr int kCarveAttempts = 24;
-// iterations allowed to attempt `attempt`: `cutoff` if the caller gave one, else about twice the measured median search
-// length at this L (M = 40; M matters little unless it is close to the fewest pieces that can clear L rows)
+constexpr int kCarveDoublings = 8;
+constexpr int64_t kCarveCutoffMax = (int64_t)1 << 28;
+// iterations allowed to attempt `attempt`: base = `cutoff` if the caller gave one, else about twice the measured median search
+// length at this L (M = 40)
 __host__ __device__ __forceinline__ int64_t carve_cutoff(int L, int64_t cutoff, int attempt) {
     int64_t c = cutoff;
     if (c <= 0) {                                          // a switch, not a table load: no constant memory on the device side
@@ -498,11 +507,18 @@ __host__ __device__ __forceinline__ int64_t carve_cutoff(int L, int64_t cutoff, 
             default: c = 132000; break;
         }
     }
-    // twelve attempts at the base cut-off, six at twice, six at four times it.  (Doubling from the seventh attempt on, as this
+    // twelve attempts at the base cut-off, then 2, 4, 8, ... 256 times it (attempts 12 ... 19), 256 times for the last four.  (Doubling from the seventh attempt on, as this
     // first was, made the unluckiest configuration of EVERY large batch -- one in 4,000 fails six times -- wait for an attempt
-    // of 2 c trips: the slowest wave of a launch ran 10,000 trips past the queue's end where the median ran 5,100.)
-    return c << (attempt < 12 ? 0 : (attempt - 12) / 6 + 1);
+    // of 2 c trips: the slowest wave of a launch ran 10,000 trips past the queue's end where the median ran 5,100.  Twelve
+    // failures at a cut-off of twice the median happen to one configuration in 10^7.)
+    const int64_t grown = c << (attempt < 12 ? 0 : attempt - 11 < kCarveDoublings ? attempt - 11 : kCarveDoublings);
+    return grown < kCarveCutoffMax ? grown : kCarveCutoffMax;
 }
+// fewest pieces with which the search loop (:234) can end at all: it ends when two cells of the bottom row are gone, a cell can
+// only be carved once its column is empty above it (the piece must come to rest where it is taken out, :341-349), and a piece
+// takes four cells: 2 L cells, ceil(L / 2) pieces.  A necessary condition only -- the generators refuse what fails it and
+// find out about the rest by the restart rule.
+__host__ __device__ __forceinline__ int carve_fewest_pieces(int L) { return (L + 1) / 2; }
 
 // which pool entry the episode of global board `g` = global_offset + i that begins at step `birth` starts from.
 // hash mode: (g, birth, seed) folded into 32 bits, one round of a 32-bit finaliser (a bijection), range-reduced with

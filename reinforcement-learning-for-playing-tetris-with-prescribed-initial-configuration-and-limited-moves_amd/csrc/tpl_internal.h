@@ -66,6 +66,11 @@ int fail_msg(int code, const char* fmt, ...);
 int check_can_advance(tpl_env* e);
 void count_steps(tpl_env* e, int64_t steps);
 
+// carve_generator.hip: the restart rule tried on ONE fixed configuration on the host (verdict kept per (L, M, cutoff)): TPL_OK,
+// or TPL_ERR_ARG / TPL_ERR_STATE with the message set when this (L, M) cannot be carved / does not finish within the rule's bound.
+// Both generators call it before a batch goes out -- on the device the alternative is a kernel that runs for minutes.
+int carve_pilot(int32_t L, int32_t M, int64_t cutoff);
+
 // observe.hip: the [N,217] observation with 16-byte stores (needs a 16-byte aligned output)
 bool observe_fast_path(const void* out);
 int launch_observe(const uint4* plane_a, const uint4* plane_b, int64_t n, uint32_t L, uint32_t M, void* out, int32_t dtype,

@@ -201,14 +201,15 @@ class BatchedTetris:
             raise _lib.TplError("the step clocks of the board groups disagree")
         return first
 
-    def carved_configs(self, count: int, seed: Optional[int] = None, first: int = 0, with_solutions: bool = False,
-                       cutoff: int = 0, waves: int = 0):
+    def carved_configs(self, count: int, seed: Optional[int] = None, first: int = 0, with_solutions: bool = False, *,
+                       cutoff: int = 0, waves: int = 0, return_status: bool = False):
         """Carved (solvable) configurations generated ON THE DEVICE (a persistent kernel whose lanes take configurations
         from a queue; `waves` = how many 64-lane waves share it, 0 = automatic) -- the same configurations
         generate_configs(L, M, count, seed, first) builds on the host.  Returns device tensors (rows int16 [count, 20],
         pieces uint8 [count, M+1]) and, with_solutions, (solution uint8 [count, M, 2], solution_len int32 [count]).
-        `cutoff` overrides the restart rule's iteration cut-off (0 = by L); raises if every attempt of a configuration ran
-        into it (an (L, M) that cannot be carved)."""
+        `cutoff` (keyword only) overrides the restart rule's base cut-off (0 = by L: csrc/tpl_device.h `carve_cutoff`); raises
+        if every attempt of some configuration ran into its cut-off -- unless `return_status`, which appends the int32 status
+        tensor (0 finished, 1 capped: all-zero outputs) and leaves the decision to the caller."""
         seed = self.seed if seed is None else seed
         d = self.device
         rows = torch.empty((count, 20), dtype=torch.int16, device=d)
@@ -221,9 +222,13 @@ class BatchedTetris:
         check(self._lib.tpl_generate_configs_device_waves(self.L, self.M, seed, first, count, int(cutoff), int(waves), _ptr(rows),
                                                           _ptr(pieces), _ptr(sol), _ptr(sol_len), _ptr(status), _ptr(work), nbytes,
                                                           self._stream()))
+        out = (rows, pieces, sol, sol_len) if with_solutions else (rows, pieces)
+        if return_status:
+            return out + (status,)
         if bool(status.any()):
-            raise _lib.TplError(f"{int(status.sum())} configuration(s) could not be carved: every attempt ran into its iteration cut-off")
-        return (rows, pieces, sol, sol_len) if with_solutions else (rows, pieces)
+            raise _lib.TplError(f"{int(status.sum())} of {count} configuration(s) did not finish: every attempt of the restart rule ran "
+                                f"into its cut-off (L={self.L} M={self.M} cutoff={int(cutoff) or 'by L'}; a larger `cutoff` searches on)")
+        return out
 
     def synthetic_configs(self, count: int, seed: Optional[int] = None, first: int = 0):
         """The synthetic boards / piece lists of SURVEY 8(d), generated on the device."""

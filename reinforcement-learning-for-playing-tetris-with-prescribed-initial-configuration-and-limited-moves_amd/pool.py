@@ -30,6 +30,7 @@ def side_stream(env, reserved_cus: int = 0, low_priority: bool = False):
 
 
 _CONCURRENT = {}          # (device index, stepping stream) -> a torch stream whose kernels were SEEN to run beside it
+_UNTESTED = {}            # device index -> the one side stream handed out when the probe could not tell (never a new one per call)
 
 
 def concurrent_stream(env):
@@ -39,9 +40,10 @@ def concurrent_stream(env):
     streams on one queue do not overlap: a generator kernel submitted between two steps makes the next step wait until it
     has finished -- 30 ms for a batch of 65,536 configurations, which is what every fourth stream of torch's pool did to
     the step loop (profiles/r03_live_supply/hardware_queue_aliasing.log).  Nothing in the API says which queue a stream
-    is on, so the candidates are tried: a generator launch of a few milliseconds goes onto the candidate, a tiny launch
+    is on, so the candidates are tried: a generator launch of some ten milliseconds goes onto the candidate, a tiny launch
     onto the stepping stream behind it, and the candidate is good if the tiny launch is done while the generator is still
-    running.  The first good one is kept for the life of the process."""
+    running.  The first good one is kept for the life of the process.  The probe synchronises the device: it must not be
+    called while the stepping stream is being captured into a graph (PoolRefresher does not)."""
     import ctypes as C
     import torch
     from ._lib import check
@@ -49,10 +51,10 @@ def concurrent_stream(env):
     key = (env._index, main.cuda_stream)                   # tested against THIS stepping stream
     if key in _CONCURRENT:
         return _CONCURRENT[key]
-    # The probe launch does not depend on the environment: L = 16 with an iteration cut-off of 256 -- no attempt of a
-    # 16-row stack ends that early, so every lane runs its 24 attempts to their cut-offs (256 x (12 + 6 x 2 + 6 x 4) = 12,288
-    # iterations) whatever the seed: about ten milliseconds on one wave, and its output is discarded.
-    L, M, count = 16, 40, 64
+    # The probe launch does not depend on the environment: 64 configurations at L = 12, M = 40 on ONE wave -- searches of
+    # 4,600 trips at the median, the slowest of 64 some four times that: ten to thirty milliseconds whatever the seed -- and its
+    # output is discarded.
+    L, M, count = 12, 40, 64
     rows = torch.empty((count, 20), dtype=torch.int16, device=d)
     pieces = torch.empty((count, M + 1), dtype=torch.uint8, device=d)
     status = torch.empty(count, dtype=torch.int32, device=d)
@@ -64,7 +66,7 @@ def concurrent_stream(env):
     for attempt in range(12):
         cand = torch.cuda.Stream(d)
         busy, quick = torch.cuda.Event(), torch.cuda.Event()
-        check(env._lib.tpl_generate_configs_device_waves(L, M, 0x5EED, 0, count, 256, 1, C.c_void_p(rows.data_ptr()),
+        check(env._lib.tpl_generate_configs_device_waves(L, M, 0x5EED, attempt * count, count, 0, 1, C.c_void_p(rows.data_ptr()),
                                                          C.c_void_p(pieces.data_ptr()), None, None, C.c_void_p(status.data_ptr()),
                                                          C.c_void_p(work.data_ptr()), nbytes, cand.cuda_stream))
         busy.record(cand)
@@ -88,9 +90,9 @@ def concurrent_stream(env):
         else:
             warnings.warn("the stream probe was inconclusive (its generator launch ended before it could be compared): "
                           "using an untested side stream")
-            chosen = torch.cuda.Stream(d)
-            _CONCURRENT.pop(key, None)
-            return chosen                         # not cached: the next refresher tries again
+            if env._index not in _UNTESTED:
+                _UNTESTED[env._index] = torch.cuda.Stream(d)
+            return _UNTESTED[env._index]          # not cached as tested: the next refresher tries again
     _CONCURRENT[key] = chosen
     return chosen
 
@@ -113,26 +115,34 @@ class PoolRefresher:
     """
 
     def __init__(self, env, count: int, seed: int = 0, first: int = 0, waves: int = 0, reserved_cus: int = 0,
-                 low_priority: bool = False, cutoff: int = 0):
+                 low_priority: bool = False, cutoff: int = 0, strict: bool = False, max_capped_batches: int = 3):
         """waves: how many persistent 64-lane waves share the generator's queue (0 = count / 256): its footprint beside
         the stepping environment.  What a footprint costs and supplies is in bench.py's `live_supply_run`
         (`by_generator_footprint`; profiles/NOTES.md has the history).  (The step kernel raises its waves'
         issue priority above the generator's; without that any generator wave on a SIMD cost the whole launch 18-29 %.)
         reserved_cus > 0 runs the generator on a CU-masked stream of that many compute units (`tpl_stream_create`),
         low_priority on a lowest-priority stream: both measured 3x SLOWER steps than a plain side stream -- kept as
-        options because the review of round 2 asked for the comparison, not because they help."""
+        options because the review of round 2 asked for the comparison, not because they help.
+        An (L, M, cutoff) whose pilot configuration does not finish is refused HERE (TplError from the first start()).  A batch
+        in which some configuration ran into all of its cut-offs is dropped: `strict` raises at once; otherwise a warning names
+        (L, M, cutoff), and after `max_capped_batches` such batches IN A ROW the refresher stops (`stopped`; poll() returns
+        False from then on) instead of spending the generator's worst case beside the training loop for ever."""
         import torch
         self.env, self.count, self.seed, self.next_first = env, int(count), int(seed), int(first)
         self.cutoff = int(cutoff)     # the restart rule's iteration cut-off (0 = by L), as generate_configs / carved_configs take it
         self.waves = int(waves) or max(1, self.count // 256)       # beside a stepping environment: a quarter of the lanes a lone generator takes
+        self.strict, self.max_capped_batches = bool(strict), int(max_capped_batches)
         self._masked = bool(reserved_cus or low_priority)
         self.side = side_stream(env, reserved_cus, low_priority) if self._masked else concurrent_stream(env)
         self._stepping = torch.cuda.current_stream(env.device).cuda_stream      # the stream `side` was tested against
+        self._retest = False          # stepping has moved to another stream: test a side stream against it at the next start()
         self._ready = None            # event recorded behind the batch being generated
         self._bad_host = None         # pinned: the batch's count of configurations that could not be carved
         self._batch = None
         self.swaps = 0
         self.capped_batches = 0       # batches dropped because a configuration's attempts all ran into their cut-off
+        self._capped_in_a_row = 0
+        self.stopped = False
         self.start()
 
     def start(self) -> None:
@@ -141,6 +151,13 @@ class PoolRefresher:
         import torch
         from ._lib import check
         env, d, n = self.env, self.env.device, self.count
+        if self._retest and not torch.cuda.is_current_stream_capturing():
+            # stepping has moved to another stream since the side stream was tested: HIP may have put the two on one hardware
+            # queue (a 30-ms stall per swap).  Tested here, between batches (the probe synchronises the device: never while the
+            # stepping stream is being captured); cached per stepping stream, so a loop that alternates between two pays once each.
+            self.side = concurrent_stream(env)
+            self._stepping = torch.cuda.current_stream(d).cuda_stream
+            self._retest = False
         with torch.cuda.stream(self.side):
             rows = torch.empty((n, 20), dtype=torch.int16, device=d)
             pieces = torch.empty((n, env.M + 1), dtype=torch.uint8, device=d)
@@ -158,39 +175,45 @@ class PoolRefresher:
             self._bad_host.copy_(status.sum().reshape(1), non_blocking=True)
             self._ready = torch.cuda.Event()
             self._ready.record(self.side)
-        self._batch = (rows, pieces, status, work, self.next_first)
+        self._batch = (rows, pieces, status, work, self.next_first, self.side)
         self.next_first += n
 
     def poll(self) -> bool:
         """Swap the finished batch in if it is ready and the handle can take it; True when a swap happened."""
         import torch
-        if self._ready is None or not self._ready.query() or self.env.pool_info()["steps_until_swap"] > 0:
+        if self.stopped or self._ready is None or not self._ready.query() or self.env.pool_info()["steps_until_swap"] > 0:
             return False
-        rows, pieces, _, _, first = self._batch
+        rows, pieces, _, _, first, made_on = self._batch
         bad = int(self._bad_host[0])                               # host memory, written ahead of the event that has fired
         if bad:
-            # every attempt of a configuration ran into its cut-off: under the restart rule that means this (L, M) cannot be
-            # carved (for one that can, 24 failures in a row have a probability below 1e-14).  The batch is dropped, the
-            # pool stays as it is, the run goes on; said once.
+            # every attempt of some configuration ran into its cut-off although the pilot configuration of this (L, M, cutoff)
+            # finished: the cut-off is marginal for this (L, M).  The batch is dropped, the pool stays as it is.
+            import warnings
             self.capped_batches += 1
+            self._capped_in_a_row += 1
+            what = (f"{bad} configuration(s) of the batch at {first} ran into every cut-off of the restart rule "
+                    f"(L={self.env.L}, M={self.env.M}, cutoff={self.cutoff or 'by L'}): batch dropped, the pool is not refreshed")
+            if self.strict:
+                self._ready = self._batch = None
+                raise RuntimeError(what)
+            if self._capped_in_a_row >= self.max_capped_batches:
+                self.stopped = True
+                self._ready = self._batch = None
+                warnings.warn(what + f"; {self._capped_in_a_row} batches in a row: the refresher has STOPPED (pass a larger cutoff)")
+                return False
             if self.capped_batches == 1:
-                import warnings
-                warnings.warn(f"{bad} configuration(s) of the batch at {first} could not be carved (L={self.env.L}, M={self.env.M}): "
-                              "batch dropped, the pool is not refreshed")
+                warnings.warn(what)
             self.start()
             return False
+        self._capped_in_a_row = 0
         main = torch.cuda.current_stream(self.env.device)
         if main.cuda_stream != self._stepping and not self._masked:
-            # stepping has moved to another stream since the side stream was tested: HIP may have put the two on one hardware
-            # queue (a 30-ms stall per swap).  concurrent_stream() is cached per stepping stream; the batch in flight stays
-            # on the stream it was launched on, the next one goes to the newly tested stream.
-            self.side.synchronize()
-            self.side = concurrent_stream(self.env)
-            self._stepping = main.cuda_stream
-        self.side.wait_stream(main)                                # launches that still read the buffer being replaced
-        with torch.cuda.stream(self.side):
+            self._retest = True                                    # the NEXT batch goes to a stream tested against `main` (start())
+        # the finished batch is packed on the stream that made it: its tensors belong to that stream's allocations
+        made_on.wait_stream(main)                                  # launches that still read the buffer being replaced
+        with torch.cuda.stream(made_on):
             self.env.load_configs(rows, pieces, validate=False)    # the generator cannot emit an invalid piece id
-        main.wait_stream(self.side)                                # the next step sees the packed pool
+        main.wait_stream(made_on)                                  # the next step sees the packed pool
         for mem in self.env._pool_mems:                            # allocated on the side stream, read on the stepping one
             if mem is not None:
                 mem.record_stream(main)
@@ -199,9 +222,10 @@ class PoolRefresher:
         self.start()
         return True
 
-
     def close(self) -> None:
         """Waits for the batch in flight and drops it (the side stream itself lives as long as the process)."""
+        if self._batch is not None:
+            self._batch[5].synchronize()
         self.side.synchronize()
         self._ready = self._batch = None
 
