@@ -26,6 +26,12 @@ pays the GPU's wake-up, 20-160 us by how long it idled (tools/launch_probe.py), 
 event ahead of that launch puts its duration in the line (`timing.launch_after_synchronize_ms`).  `roofline.kernel_ms`
 is the launch period over the K timed launches; `roofline.sustained` is the same loop over 2000 launches right after.
 
+The headline cannot be lost to what follows it: every side figure runs under a guard (`SideFigures`: an exception becomes
+`{"error": ...}` under the figure's key; at N > 1 the ranks agree before and after each figure over a gloo group of host
+tensors, so none waits in a collective for one that raised; figures past `--side-budget` seconds are skipped; a figure still
+running after `--side-timeout` is abandoned and the line printed with what there is).  A failure INSIDE the timed region is
+not guarded: the run ends with a non-zero status.
+
 Prints ONE JSON line (rank 0).  `roofline` prices the step kernel against HBM with the canonical
 96 B/board-step of SURVEY 8(d); `cpu_baseline` is the CPU oracle (a scalar C port of the reference's move)
 timed on this box's host cores over a bounded sample of the same workload, with the NumPy per-board restatement
@@ -99,7 +105,7 @@ def cpu_baseline(L, M, seed, numpy_leg, seconds=2.0):
     out = {"value": done / sec, "unit": "env-steps/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
            "sample": f"{boards} boards x {steps} lockstep steps, L={L} M={M}, auto-reset, {cores} threads, {sec:.1f}s",
            "numpy_port": numpy_leg}
-    if numpy_leg:
+    if numpy_leg and "per_core" in numpy_leg:
         out["c_port_over_numpy_port_per_core"] = (done / sec / cores) / numpy_leg["per_core"]
     try:
         # the Python reference itself cannot travel to this box; its rate beside both restatements was measured in
@@ -122,6 +128,121 @@ def timed(torch, dev, fn, reps):
     e1.record()
     torch.cuda.synchronize(dev)
     return e0.elapsed_time(e1) / reps
+
+
+class SideFigures:
+    """Runs the side figures of the line so that none of them can take the headline with it (round-4 review: an exception in a
+    side figure lost the line, and at N > 1 left the other ranks in a collective until the process group timed out).
+
+    * `run(name, fn)` calls fn() under a guard: an exception becomes `{"error": "<type>: <message>"}` under that key.
+    * At world > 1 a figure runs on every rank or on none, and every collective of a figure happens OUTSIDE fn: before it the
+      ranks agree whether to start (one of them may be out of time), after it whether all of them came through -- both over
+      `ctl`, a gloo group of host tensors that a sick GPU cannot take down.  Only then are the ranks' numbers combined
+      (`max_over_ranks`), so no rank ever waits in a collective for one that raised.
+    * `budget_s`: figures that would start after that many seconds of side figures are skipped (`{"skipped": ...}`).
+    * `watchdog(seconds, emit)`: if the side figures are still running after that long, `emit()` (rank 0: print the line with
+      what there is) is called from a timer thread and the process exits with status 0 -- a hung side figure cannot turn a
+      measured headline into a killed run.
+    `inject` names figures made to fail on purpose ("name" or "name@rank", comma separated; TPL_BENCH_INJECT_FAILURE): the
+    tests' way to see all of the above happen."""
+
+    def __init__(self, world=1, rank=0, dist=None, ctl=None, budget_s=None, inject="", clock=time.perf_counter):
+        self.world, self.rank, self.dist, self.ctl = world, rank, dist, ctl
+        self.budget_s, self.clock, self.t0 = budget_s, clock, clock()
+        self.inject = [x.strip() for x in (inject or "").split(",") if x.strip()]
+        self.log = []                 # (name, seconds, outcome) in the order run
+        self.running = None
+        self._timer = None
+
+    # -- host-side agreement between the ranks (gloo)
+    def _gather(self, value):
+        if self.world == 1:
+            return [float(value)]
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        got = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(got, t, group=self.ctl)
+        return [float(g.item()) for g in got]
+
+    def max_over_ranks(self, value):
+        return max(self._gather(value))
+
+    def _injected(self, name):
+        return any(x == name or x == f"{name}@{self.rank}" for x in self.inject)
+
+    def run(self, name, fn):
+        over = self.budget_s is not None and self.clock() - self.t0 > self.budget_s
+        if any(self._gather(1.0 if over else 0.0)):
+            self.log.append((name, 0.0, "skipped"))
+            return {"skipped": f"the side figures had used their {self.budget_s:.0f} s (--side-budget) when this one's turn came"}
+        self.running = name
+        t0 = self.clock()
+        result = error = None
+        try:
+            if self._injected(name):
+                raise RuntimeError(f"failure injected into '{name}' (TPL_BENCH_INJECT_FAILURE)")
+            result = fn()
+        except Exception as e:        # noqa: BLE001 -- whatever it is, the headline survives it
+            error = f"{type(e).__name__}: {e}"[:400]
+        failed = [r for r, f in enumerate(self._gather(0.0 if error is None else 1.0)) if f]
+        self.running = None
+        self.log.append((name, self.clock() - t0, "ok" if not failed else "failed"))
+        if failed:
+            out = {"error": error or f"rank(s) {failed} failed; this rank's own measurement was dropped with theirs"}
+            if self.world > 1:
+                out["failed_ranks"] = failed
+            return out
+        return result
+
+    @staticmethod
+    def ok(result):
+        return isinstance(result, dict) and "error" not in result and "skipped" not in result
+
+    def summary(self):
+        return {"seconds": {n: round(s, 3) for n, s, _ in self.log}, "failed": [n for n, _, o in self.log if o == "failed"],
+                "skipped": [n for n, _, o in self.log if o == "skipped"], "total_seconds": round(self.clock() - self.t0, 3)}
+
+    def watchdog(self, seconds, emit):
+        import threading
+
+        def fire():
+            try:
+                emit(self.running)
+            finally:
+                sys.stdout.flush()
+                os._exit(0)
+        self._timer = threading.Timer(seconds, fire)
+        self._timer.daemon = True
+        self._timer.start()
+
+    def disarm(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+
+
+def releases_envs(fn):
+    """The measure_* functions that build environments of their own register them through `keep(...)`: whatever happens
+    inside -- the function's guard in SideFigures.run turns an exception into an {"error": ...} entry -- their handles and
+    device memory are released before the next figure starts."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        made = []
+
+        def keep(env):
+            made.append(env)
+            return env
+        try:
+            return fn(*args, keep=keep, **kwargs)
+        finally:
+            for env in made:
+                try:
+                    env.terminate()
+                except Exception:      # noqa: BLE001
+                    pass
+    return wrapper
 
 
 def measure_fused_rollout(torch, T, env, actions, first, K, chunk, compact=False):
@@ -155,38 +276,45 @@ def action_rows(actions):
     return list(actions.unbind(0))
 
 
-def measure_weak_job(torch, T, dev, rank, world, L, M, per_gpu, seed, K, barrier, max_over_ranks):
+def measure_weak_job(torch, T, dev, rank, world, L, M, per_gpu, seed, K):
     """Side figure for N > 1 (the headline is BASELINE configs[3], fixed total work): `per_gpu` boards on EVERY rank,
-    i.e. a job that grows with the node.  Same pool on every rank, everything keyed by the global board index."""
+    i.e. a job that grows with the node.  Same pool on every rank, everything keyed by the global board index.  Returns this
+    rank's ms per step; no collective in here (SideFigures.run), the ranks start together within the agreement that precedes it."""
     shard = T.sharding.weak_shard(rank, world, per_gpu)
     env = T.BatchedTetris(L, M, shard.boards, device=dev, seed=seed, global_offset=shard.global_offset,
                           auto_reset=True, assign="hash")
-    rows, pieces = env.synthetic_configs(per_gpu, first=0)
-    env.load_configs(rows, pieces)
-    del rows, pieces
-    env.reset()
-    S = max(1, min(K, 200))
-    actions = torch.empty((S, shard.boards), dtype=torch.uint8, device=dev)
-    for t in range(S):
-        env.synthetic_actions(t, out=actions[t])
-    reward = torch.empty(shard.boards, dtype=torch.float32, device=dev)
-    done = torch.empty(shard.boards, dtype=torch.uint8, device=dev)
-    rows_of = action_rows(actions)
-    for t in range(20):
-        env.step_into(rows_of[t % S], reward, done)
-    torch.cuda.synchronize(dev)
-    barrier()
-    step = iter(range(S))
-    ms = max_over_ranks(timed(torch, dev, lambda: env.step_into(rows_of[next(step)], reward, done), S))
-    env.terminate()
+    try:
+        rows, pieces = env.synthetic_configs(per_gpu, first=0)
+        env.load_configs(rows, pieces)
+        del rows, pieces
+        env.reset()
+        S = max(1, min(K, 200))
+        actions = torch.empty((S, shard.boards), dtype=torch.uint8, device=dev)
+        for t in range(S):
+            env.synthetic_actions(t, out=actions[t])
+        reward = torch.empty(shard.boards, dtype=torch.float32, device=dev)
+        done = torch.empty(shard.boards, dtype=torch.uint8, device=dev)
+        rows_of = action_rows(actions)
+        for t in range(20):
+            env.step_into(rows_of[t % S], reward, done)
+        torch.cuda.synchronize(dev)
+        step = iter(range(S))
+        ms = timed(torch, dev, lambda: env.step_into(rows_of[next(step)], reward, done), S)
+    finally:
+        env.terminate()
+    return {"ms": ms, "steps": S, "global_boards": shard.global_boards}
+
+
+def weak_job_line(ms, steps, per_gpu, global_boards):
     gbs = ALGO_BYTES_PER_BOARD_STEP * per_gpu / (ms * 1e-3) / 1e9
-    return {"scaling": "weak", "boards_per_gpu": per_gpu, "global_boards": shard.global_boards, "unit": "env-steps/s",
-            "value": float(shard.global_boards) / (ms * 1e-3), "ms_per_step": ms, "steps": S,
+    return {"scaling": "weak", "boards_per_gpu": per_gpu, "global_boards": global_boards, "unit": "env-steps/s",
+            "value": float(global_boards) / (ms * 1e-3), "ms_per_step": ms, "steps": steps,
             "per_gpu_roofline_frac": gbs / HBM_PEAK_GBS,
             "note": "NOT the BASELINE workload for N > 1 (that is 1,048,576 boards in total): a job N times as large"}
 
 
-def measure_shard_run(torch, T, dev, L, M, seed, total, ranks, chunk):
+@releases_envs
+def measure_shard_run(torch, T, dev, L, M, seed, total, ranks, chunk, keep=None):
     """What ONE rank of an 8-GPU run of BASELINE configs[3] does, measured on this one GPU: rank 0's shard of `total`
     boards over `ranks` GPUs (131,072 boards at the defaults), over the whole `total`-entry pool, in the three forms the
     library offers: one tpl_step launch per step (the headline's form), `chunk` such steps as one replayed HIP graph, and
@@ -194,7 +322,7 @@ def measure_shard_run(torch, T, dev, L, M, seed, total, ranks, chunk):
     96 B per board-step ON THE SHARD's boards."""
     shard = T.sharding.strong_shard(0, ranks, total)
     n = shard.boards
-    env = T.BatchedTetris(L, M, n, device=dev, seed=seed, global_offset=shard.global_offset, auto_reset=True, assign="hash")
+    env = keep(T.BatchedTetris(L, M, n, device=dev, seed=seed, global_offset=shard.global_offset, auto_reset=True, assign="hash"))
     rows, pieces = env.synthetic_configs(total, first=0)
     env.load_configs(rows, pieces)
     del rows, pieces
@@ -232,10 +360,11 @@ def measure_shard_run(torch, T, dev, L, M, seed, total, ranks, chunk):
             "note": "measured on ONE GPU; an N-GPU run's headline is global_boards / (the slowest rank's tpl_step period)"}
 
 
-def measure_out_of_cache(torch, T, dev, L, M, seed, boards=1 << 23, pool=1 << 21, steps=100):
+@releases_envs
+def measure_out_of_cache(torch, T, dev, L, M, seed, boards=1 << 23, pool=1 << 21, steps=100, keep=None):
     """The step loop where nothing fits the 256 MiB Infinity Cache: 2^23 boards (256 MiB of state) over a 2^21-entry
     pool (another 256 MiB).  Reported per 2^20 boards so that it reads beside the main line."""
-    env = T.BatchedTetris(L, M, boards, device=dev, seed=seed, auto_reset=True, assign="hash")
+    env = keep(T.BatchedTetris(L, M, boards, device=dev, seed=seed, auto_reset=True, assign="hash"))
     rows, pieces = env.synthetic_configs(pool)
     env.load_configs(rows, pieces)
     del rows, pieces
@@ -259,14 +388,15 @@ def measure_out_of_cache(torch, T, dev, L, M, seed, boards=1 << 23, pool=1 << 21
             "note": "state (32 B/board) + pool (128 B/entry) = 512 MiB, twice the Infinity Cache: every launch streams from HBM"}
 
 
-def measure_config_supply(torch, T, dev, L, M, seed):
+@releases_envs
+def measure_config_supply(torch, T, dev, L, M, seed, keep=None):
     """rates of the prescribed-configuration suppliers (side figures).  Carving on the device
     (a persistent kernel: lanes take configurations from a queue, and once it is dry run further attempts of their wave's
     stragglers under the restart rule) and on the host cores produce the same configurations; the forward generator +
     solver is host code.  Device rates by batch size (a launch lasts as long as its slowest wave) and at the reference's
     own test configuration L = 15, M = 40 (game/main.py:33,50)."""
     import numpy as np
-    env = T.BatchedTetris(L, M, 64, device=dev, seed=seed)
+    env = keep(T.BatchedTetris(L, M, 64, device=dev, seed=seed))
 
     def device_rate(e, count, reps=2):
         e.carved_configs(count)                                  # load the kernel, and let torch's allocator keep the buffers
@@ -286,7 +416,7 @@ def measure_config_supply(torch, T, dev, L, M, seed):
     dt_host = time.perf_counter() - t0
     same = bool(np.array_equal(rows.cpu().numpy().view(np.uint16), hrows))
     env.terminate()
-    ref_env = T.BatchedTetris(15, 40, 64, device=dev, seed=seed)
+    ref_env = keep(T.BatchedTetris(15, 40, 64, device=dev, seed=seed))
     rate_ref, _ = device_rate(ref_env, 1 << 18, reps=1)
     ref_env.terminate()
     games = 4000
@@ -320,29 +450,31 @@ def measure_live_supply(torch, T, env, actions, reward, done, seed, count=65536,
     torch.cuda.synchronize(dev)
     ms_alone = timed(torch, dev, lambda: env.step_into(actions[0], reward, done), 500)
     feeder = T.PoolRefresher(env, count, seed=seed, first=4096, **where)
-    # the supplier's first batch is its start-up (the generator's code is loaded, its work memory and the batch's tensors are
-    # allocated -- a hipMalloc is a device synchronisation): stepped through untimed, the timed region begins at the first swap
-    lead = 0
-    while lead < max_steps and not feeder.poll():
-        for t in range(32):
-            env.step_into(actions[(lead + t) % S], reward, done)
-        lead += 32
-    episodes0 = env.stats()["episodes"]
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    swap_times = [time.perf_counter()]
-    e0.record()
-    steps = 0
-    while steps < max_steps and (steps < min_steps or len(swap_times) < min_swaps + 1):
-        for t in range(32):
-            env.step_into(actions[(lead + steps + t) % S], reward, done)
-        steps += 32
-        if feeder.poll():
-            swap_times.append(time.perf_counter())       # the host loop runs a bounded queue ahead of the GPU: wall time tracks it
-    e1.record()
-    torch.cuda.synchronize(dev)
-    ms = e0.elapsed_time(e1) / steps
-    resets_per_s = (env.stats()["episodes"] - episodes0) / (ms * 1e-3 * steps)
-    feeder.close()
+    try:
+        # the supplier's first batch is its start-up (the generator's code is loaded, its work memory and the batch's tensors are
+        # allocated -- a hipMalloc is a device synchronisation): stepped through untimed, the timed region begins at the first swap
+        lead = 0
+        while lead < max_steps and not feeder.poll():
+            for t in range(32):
+                env.step_into(actions[(lead + t) % S], reward, done)
+            lead += 32
+        episodes0 = env.stats()["episodes"]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        swap_times = [time.perf_counter()]
+        e0.record()
+        steps = 0
+        while steps < max_steps and (steps < min_steps or len(swap_times) < min_swaps + 1):
+            for t in range(32):
+                env.step_into(actions[(lead + steps + t) % S], reward, done)
+            steps += 32
+            if feeder.poll():
+                swap_times.append(time.perf_counter())       # the host loop runs a bounded queue ahead of the GPU: wall time tracks it
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / steps
+        resets_per_s = (env.stats()["episodes"] - episodes0) / (ms * 1e-3 * steps)
+    finally:
+        feeder.close()                                        # whatever happened, no generator keeps running beside the next figure
     fresh_per_s = (len(swap_times) - 1) * count / (swap_times[-1] - swap_times[0]) if len(swap_times) >= 2 else None
     return {"unit": "env-steps/s", "value": float(n) / (ms * 1e-3), "ms_per_step": ms, "ms_per_step_without_refresher": ms_alone,
             "slowdown": ms / ms_alone, "configurations_per_batch": count, "pool_swaps": len(swap_times) - 1, "steps": steps,
@@ -370,9 +502,10 @@ def measure_carved_pool(torch, T, env, actions, reward, done, W, K, pool, seed):
             "win_rate": st["wins"] / max(st["episodes"], 1)}
 
 
-def measure_actor_loop(torch, T, dev, L, M, boards, seed):
+@releases_envs
+def measure_actor_loop(torch, T, dev, L, M, boards, seed, keep=None):
     """BASELINE configs[4]: boards driven by the policy MLP, obs -> action -> step on the device, three ways."""
-    env = T.BatchedTetris(L, M, boards, device=dev, seed=seed, auto_reset=True, assign="hash")
+    env = keep(T.BatchedTetris(L, M, boards, device=dev, seed=seed, auto_reset=True, assign="hash"))
     rows, pieces = env.synthetic_configs(boards)
     env.load_configs(rows, pieces)
     env.reset()
@@ -456,11 +589,12 @@ def measure_actor_loop(torch, T, dev, L, M, boards, seed):
     return out
 
 
-def measure_config1(torch, T, dev, seed, chunk):
+@releases_envs
+def measure_config1(torch, T, dev, seed, chunk, keep=None):
     """BASELINE configs[1]: 65,536 boards, random prescribed initial configurations, L=5, M=20, one GPU.  Side figure
     with its own roofline: a launch this small is bound by the dispatch period of dependent launches, not by HBM."""
     n, L, M, K = 65536, 5, 20, 400
-    env = T.BatchedTetris(L, M, n, device=dev, seed=seed, auto_reset=True, assign="hash")
+    env = keep(T.BatchedTetris(L, M, n, device=dev, seed=seed, auto_reset=True, assign="hash"))
     rows, pieces = env.synthetic_configs(n)
     env.load_configs(rows, pieces)
     env.reset()
@@ -551,9 +685,17 @@ def main():
                     help="N = 1 only: also run rank 0's shard of the job over this many GPUs (`shard_run`; 0 = skip)")
     ap.add_argument("--no-weak-job", action="store_true", help="N > 1: skip the weak-scaling side figure (--boards per GPU)")
     ap.add_argument("--no-out-of-cache", action="store_true", help="skip the 2^23-board side run (N = 1 only)")
+    ap.add_argument("--no-side-figures", action="store_true", help="the headline, its roofline and the CPU baseline only")
+    ap.add_argument("--side-budget", type=float, default=240.0,
+                    help="seconds of side figures after which the remaining ones are skipped (the headline is never skipped)")
+    ap.add_argument("--side-timeout", type=float, default=480.0,
+                    help="seconds after which a side figure that is STILL running is abandoned: the line is printed with what there is")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
         ap.error("--gpus and --steps must be positive, --warmup non-negative")
+    if args.no_side_figures:
+        args.actor_boards = args.carved_pool = args.chunk = args.sustained = args.shard_ranks = 0
+        args.no_config1 = args.no_weak_job = args.no_out_of_cache = True
 
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args))
@@ -568,8 +710,11 @@ def main():
     # (rank 0 of any world size: the other ranks wait for it in init_process_group)
     numpy_leg = None
     if rank == 0 and not args.no_cpu_baseline:
-        import tetris_piclim as T0
-        numpy_leg = numpy_port_leg(args.L, args.M, args.seed, T0._lib.cpu_budget())
+        try:
+            import tetris_piclim as T0
+            numpy_leg = numpy_port_leg(args.L, args.M, args.seed, T0._lib.cpu_budget())
+        except Exception as e:        # noqa: BLE001 -- a reported baseline, not the measurement
+            numpy_leg = {"error": f"{type(e).__name__}: {e}"[:400]}
 
     import torch
     import torch.distributed as dist
@@ -579,13 +724,17 @@ def main():
     backend = os.environ.get("TPL_BENCH_BACKEND", "nccl")
     if os.environ.get("TPL_BENCH_ONE_GPU") == "1":
         local = 0
+    ctl = None
     if world > 1:
+        import datetime
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+        # the ranks' agreements around the side figures travel over a gloo group of HOST tensors (SideFigures)
+        ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=max(600.0, 2 * args.side_timeout)))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -610,28 +759,34 @@ def main():
         dist.all_gather(got, t)
         return [float(g.item()) for g in got]
 
+    side = SideFigures(world, rank, dist, ctl, budget_s=args.side_budget, inject=os.environ.get("TPL_BENCH_INJECT_FAILURE", ""))
+
     # BASELINE configs[2] (N = 1) / configs[3] (N > 1): ONE batch of `total` boards, sharded by global board index
     total, L, M, K, W = args.boards, args.L, args.M, args.steps, args.warmup
     shard = T.sharding.strong_shard(rank, world, total)           # contiguous blocks of global board indices
     n = shard.boards                                              # this rank's boards
+    figures = {"actor_loop": None, "config_supply": None, "config1_run": None, "weak_scaling_job": None, "shard_run": None}
 
     def own_board_figures():
-        actor = supply = config1 = weak = shard_run = None
+        """The side figures that build boards of their own (never part of `value`), each under SideFigures' guard."""
         if world == 1:
             if args.actor_boards > 0:
-                actor = measure_actor_loop(torch, T, dev, L, M, args.actor_boards, args.seed)
+                figures["actor_loop"] = side.run("actor_loop", lambda: measure_actor_loop(torch, T, dev, L, M, args.actor_boards, args.seed))
             if args.carved_pool > 0:
-                supply = measure_config_supply(torch, T, dev, L, M, args.seed)
+                figures["config_supply"] = side.run("config_supply", lambda: measure_config_supply(torch, T, dev, L, M, args.seed))
             if not args.no_config1:
-                config1 = measure_config1(torch, T, dev, args.seed, args.chunk)
+                figures["config1_run"] = side.run("config1_run", lambda: measure_config1(torch, T, dev, args.seed, args.chunk))
             if args.shard_ranks > 1 and args.chunk > 0:
-                shard_run = measure_shard_run(torch, T, dev, L, M, args.seed, total, args.shard_ranks, args.chunk)
+                figures["shard_run"] = side.run("shard_run", lambda: measure_shard_run(torch, T, dev, L, M, args.seed, total,
+                                                                                          args.shard_ranks, args.chunk))
         elif not args.no_weak_job:
-            weak = measure_weak_job(torch, T, dev, rank, world, L, M, total, args.seed, K, barrier, max_over_ranks)
-        return actor, supply, config1, weak, shard_run
+            got = side.run("weak_scaling_job", lambda: measure_weak_job(torch, T, dev, rank, world, L, M, total, args.seed, K))
+            if side.ok(got):          # every rank came through: only now are their numbers combined
+                got = weak_job_line(side.max_over_ranks(got["ms"]), got["steps"], total, got["global_boards"])
+            figures["weak_scaling_job"] = got
 
     if args.side_figures_first:
-        actor, supply, config1, weak, shard_run = own_board_figures()
+        own_board_figures()
 
     pool = args.pool or total
     env = T.BatchedTetris(L, M, n, device=dev, seed=args.seed, global_offset=shard.global_offset, auto_reset=True,
@@ -658,6 +813,8 @@ def main():
     # warm-up steps is enqueued after the synchronize, directly ahead of the first timed launch ("between two
     # stream-synchronised hipEvents, excluding one warm-up"): a launch into a queue that has run dry pays the GPU's
     # wake-up (20-160 us by how long it idled, tools/launch_probe.py), which is not a property of a step.
+    # NOTHING in here is guarded: a failure inside the timed region ends the run with a non-zero status (under
+    # torch.distributed.run that takes the other ranks down with it) -- an unmeasured headline must not look measured.
     rows_of = action_rows(actions)              # the row views, made once: at a shard's size the host's call rate is the period
     for t in range(max(W - 1, 0)):
         env.step_into(rows_of[t % S], reward, done)
@@ -691,76 +848,6 @@ def main():
     wall_ms = max_over_ranks((t3 - t0) * 1e3)
     collective_ms = max_over_ranks((t2 - t1) * 1e3)
 
-    # ---- the same loop, sustained: `--sustained` launches with an event every 50, right after the timed region
-    sustained = None
-    if args.sustained >= 100:
-        groups = args.sustained // 50
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(groups + 1)]
-        evs[0].record()
-        for g in range(groups):
-            for t in range(50):
-                env.step_into(actions[(g * 50 + t) % S], reward, done)
-            evs[g + 1].record()
-        torch.cuda.synchronize(dev)
-        per = [evs[g].elapsed_time(evs[g + 1]) / 50 for g in range(groups)]
-        sustained = {"launches": groups * 50, "kernel_ms_mean": max_over_ranks(evs[0].elapsed_time(evs[-1]) / (groups * 50)),
-                     "kernel_ms_median_of_50s": statistics.median(per), "kernel_ms_min_of_50s": min(per),
-                     "kernel_ms_max_of_50s": max(per)}
-        sustained["value"] = float(total) / (sustained["kernel_ms_mean"] * 1e-3)
-        sustained["frac"] = ALGO_BYTES_PER_BOARD_STEP * n / (sustained["kernel_ms_median_of_50s"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-
-    # ---- side figures on the main boards (after the timed region)
-    fused = None
-    if args.chunk > 0:
-        if S < max(2 * args.chunk, 200):                          # the fused form wants whole chunks of distinct steps
-            S = max(2 * args.chunk, 200)
-            actions = torch.empty((S, n), dtype=torch.uint8, device=dev)
-            for t in range(S):
-                env.synthetic_actions(t, out=actions[t])
-        barrier()
-        ms = max_over_ranks(measure_fused_rollout(torch, T, env, actions, 0, S // args.chunk * args.chunk, args.chunk))
-        fused = {"value": float(total) / (ms * 1e-3), "unit": "env-steps/s", "steps_per_launch": args.chunk,
-                 "ms_per_step": ms, "outputs": "per-step reward f32 + done u8 written", "kernel": "rollout_kernel<auto_reset>"}
-        # the same steps recorded as the compact trajectory (one byte per board-step, decoded on the learner's side)
-        ms_c = max_over_ranks(measure_fused_rollout(torch, T, env, actions, 0, S // args.chunk * args.chunk, args.chunk, compact=True))
-        fused["compact_trajectory"] = {"value": float(total) / (ms_c * 1e-3), "ms_per_step": ms_c, "steps_per_launch": args.chunk,
-                                       "outputs": "one byte per board-step (rows cleared, how the move ended, reset, frozen), "
-                                                  "a dword per board every fourth step; tpl_decode_trajectory -> reward f32, done u8"}
-        # ... and with 200 steps per launch (a launch's fixed part -- the 64 B per board of state in and out, the launch gap --
-        # is some 20 us: a quarter of a 50-step launch's step time, a fifteenth of a 200-step one's)
-        ms_c200 = max_over_ranks(measure_fused_rollout(torch, T, env, actions, 0, 200, 200, compact=True))
-        ms_o200 = max_over_ranks(measure_fused_rollout(torch, T, env, actions, 0, 200, 200))
-        fused["at_200_steps_per_launch"] = {"compact_trajectory": float(total) / (ms_c200 * 1e-3),
-                                            "reward_f32_and_done_u8": float(total) / (ms_o200 * 1e-3)}
-        # the same kernel under the uniform random policy drawn on the device (no actions staged, no per-step outputs)
-        env.rollout_random(100, seed=args.seed)
-        torch.cuda.synchronize(dev)
-        ms_r = max_over_ranks(timed(torch, dev, lambda: env.rollout_random(100, seed=args.seed), 4) / 100)
-        fused["device_random_policy"] = {"value": float(total) / (ms_r * 1e-3), "ms_per_step": ms_r, "steps_per_launch": 100,
-                                         "outputs": "reward sums and episode counts only"}
-    carved = live = None
-    if args.carved_pool > 0 and world == 1:
-        carved = measure_carved_pool(torch, T, env, actions, reward, done, W, K, args.carved_pool, args.seed)
-        live = measure_live_supply(torch, T, env, actions, reward, done, args.seed)
-        # the same run by the generator's footprint: how many persistent waves share its queue, and -- the form the
-        # round-2 review asked for -- confined to 32 compute units by a CU-masked stream (which turns out to be the
-        # expensive way: profiles/r03_live_supply)
-        live["generator"] = "PoolRefresher defaults: a plain side stream, waves = count / 256"
-        keep = ("ms_per_step", "slowdown", "pool_swaps", "steps", "configurations_per_batch", "configurations_supplied_per_s",
-                "pool_reuse_factor")
-        live["by_generator_footprint"] = [
-            dict(generator=name, **{k: v for k, v in measure_live_supply(torch, T, env, actions, reward, done, args.seed, **kw).items() if k in keep})
-            for name, kw in (("1024 waves", dict(waves=1024)), ("1024 waves, batches of 2^20 (a pool's worth)", dict(waves=1024, count=1 << 20)),
-                             ("64 waves", dict(waves=64)), ("256 waves on a 32-CU stream", dict(waves=256, reserved_cus=32)))]
-    env.terminate()
-    del actions
-    out_of_cache = None
-    if world == 1 and not args.no_out_of_cache:
-        out_of_cache = measure_out_of_cache(torch, T, dev, L, M, args.seed)
-    # ---- side figures that own their boards (never part of `value`): last, so that the timed region is the first thing the GPU
-    # does in this process (behind the matrix kernels of the actor loop the same twenty steps read 0.2 us a step slower)
-    if not args.side_figures_first:
-        actor, supply, config1, weak, shard_run = own_board_figures()
     # each rank's kernel priced on the boards of ITS shard
     per_rank_roofline = []
     for r, ms_r in enumerate(per_rank_ms):
@@ -768,7 +855,12 @@ def main():
         gbs = ALGO_BYTES_PER_BOARD_STEP * nb / (ms_r * 1e-3) / 1e9
         per_rank_roofline.append({"rank": r, "boards": nb, "kernel_ms": ms_r, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS})
 
-    if rank == 0:
+    # ---- the headline is complete from here on; everything below adds side keys to it and none of it can lose it
+    more = {"sustained": None, "fused_rollout": None, "carved_pool_run": None, "live_supply_run": None, "out_of_cache": None,
+            "cpu_baseline": None}
+
+    def line(abandoned=None):
+        """The one JSON line, from what has been measured so far (rank 0 only)."""
         achieved = ALGO_BYTES_PER_BOARD_STEP * n / (steady_ms * 1e-3) / 1e9
         # HBM bytes per launch by the PMC counters: these cannot be read from inside this process (rocprofv3 collects them
         # in passes of their own), so the figure comes from the committed profile of this same command and says so
@@ -783,8 +875,9 @@ def main():
                     traffic_dec = tj["decomposed_estimate_bytes"] * (n / float(1 << 20))
                 traffic_source = (f"NOT measured in this run: rocprofv3 --pmc passes of this command, {tj.get('source')}"
                                   f" (commit {tj.get('commit')}, source digest {str(tj.get('source_digest'))[:12]}), scaled to {n} boards")
-            except Exception:
+            except Exception:         # noqa: BLE001
                 traffic = traffic_source = traffic_dec = None
+        sustained = more["sustained"] if side.ok(more["sustained"]) else None
         out = {
             "metric": "env-steps/sec (whole node) at 1M parallel 20x10 boards",
             "value": float(total) * K / (region_ms * 1e-3),
@@ -825,7 +918,7 @@ def main():
                          # the gathers (the guide's formula doubles every read request)
                          "traffic_decomposed": traffic_dec,
                          "frac_traffic_decomposed": (traffic_dec / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic_dec else None,
-                         "out_of_cache": out_of_cache,
+                         "out_of_cache": more["out_of_cache"],
                          "kernel": "step_kernel<action, auto_reset>", "kernel_ms": steady_ms, "boards_per_launch": n,
                          "priced_on": "rank 0's shard of the job over the slowest rank's launch period",
                          "kernel_ms_source": "launch period over the K timed launches (HIP events on the launch stream)",
@@ -833,26 +926,132 @@ def main():
                          "kernel_ms_median": (sustained or {}).get("kernel_ms_median_of_50s"),
                          "frac_median": (sustained or {}).get("frac"),
                          "launch_after_synchronize_ms": wake_ms,
-                         "sustained": sustained,
+                         "sustained": more["sustained"],
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BOARD_STEP * n,
                          "node": {"achieved": ALGO_BYTES_PER_BOARD_STEP * total / (steady_ms * 1e-3) / 1e9,
                                   "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                                   "frac": ALGO_BYTES_PER_BOARD_STEP * total / (steady_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)}},
-            "fused_rollout": fused,
-            "shard_run": shard_run,
-            "weak_scaling_job": weak,
-            "carved_pool_run": carved,
-            "live_supply_run": live,
-            "config1_run": config1,
-            "config_supply": supply,
-            "actor_loop": actor,
+            "fused_rollout": more["fused_rollout"],
+            "shard_run": figures["shard_run"],
+            "weak_scaling_job": figures["weak_scaling_job"],
+            "carved_pool_run": more["carved_pool_run"],
+            "live_supply_run": more["live_supply_run"],
+            "config1_run": figures["config1_run"],
+            "config_supply": figures["config_supply"],
+            "actor_loop": figures["actor_loop"],
             "mean_episodic_return": mean_return if episodes else None,
             "episodes": episodes,
+            "side_figures": dict(side.summary(), guard="each side figure runs under a guard (an exception becomes {\"error\": ...} under "
+                                 "its key; at N > 1 the ranks agree over a gloo group before and after each); the timed region is not guarded"),
         }
+        if abandoned is not None:
+            out["side_figures"]["abandoned"] = (f"'{abandoned}' was still running {args.side_timeout:.0f} s into the side figures "
+                                                "(--side-timeout): the line was printed by the watchdog with what had been measured")
         if not args.no_cpu_baseline:
-            # rank 0's host cores, after every collective of the job (the other ranks are on their way out)
-            out["cpu_baseline"] = cpu_baseline(L, M, args.seed, numpy_leg)
-        print(json.dumps(out), flush=True)
+            out["cpu_baseline"] = more["cpu_baseline"]
+        return out
+
+    def emit(abandoned=None):
+        if rank == 0:
+            print(json.dumps(line(abandoned)), flush=True)
+
+    side.watchdog(args.side_timeout, emit)
+
+    # ---- the same loop, sustained: `--sustained` launches with an event every 50, right after the timed region
+    def sustained_pass():
+        groups = args.sustained // 50
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(groups + 1)]
+        evs[0].record()
+        for g in range(groups):
+            for t in range(50):
+                env.step_into(actions[(g * 50 + t) % S], reward, done)
+            evs[g + 1].record()
+        torch.cuda.synchronize(dev)
+        per = [evs[g].elapsed_time(evs[g + 1]) / 50 for g in range(groups)]
+        return {"launches": groups * 50, "kernel_ms_mean_this_rank": evs[0].elapsed_time(evs[-1]) / (groups * 50),
+                "kernel_ms_median_of_50s": statistics.median(per), "kernel_ms_min_of_50s": min(per), "kernel_ms_max_of_50s": max(per)}
+    if args.sustained >= 100:
+        sustained = side.run("sustained", sustained_pass)
+        if side.ok(sustained):
+            sustained["kernel_ms_mean"] = side.max_over_ranks(sustained.pop("kernel_ms_mean_this_rank"))
+            sustained["value"] = float(total) / (sustained["kernel_ms_mean"] * 1e-3)
+            sustained["frac"] = ALGO_BYTES_PER_BOARD_STEP * n / (sustained["kernel_ms_median_of_50s"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        more["sustained"] = sustained
+
+    # ---- side figures on the main boards (after the timed region)
+    def fused_figures():
+        """This rank's milliseconds per step in each form of the fused rollout (no collective in here)."""
+        nonlocal S, actions
+        if S < max(2 * args.chunk, 200):                          # the fused form wants whole chunks of distinct steps
+            S = max(2 * args.chunk, 200)
+            actions = torch.empty((S, n), dtype=torch.uint8, device=dev)
+            for t in range(S):
+                env.synthetic_actions(t, out=actions[t])
+        whole = S // args.chunk * args.chunk
+        ms = {"f32_u8": measure_fused_rollout(torch, T, env, actions, 0, whole, args.chunk),
+              # the same steps recorded as the compact trajectory (one byte per board-step, decoded on the learner's side)
+              "compact": measure_fused_rollout(torch, T, env, actions, 0, whole, args.chunk, compact=True),
+              # ... and with 200 steps per launch (a launch's fixed part -- the 64 B per board of state in and out, the launch
+              # gap -- is some 20 us: a quarter of a 50-step launch's step time, a fifteenth of a 200-step one's)
+              "compact_200": measure_fused_rollout(torch, T, env, actions, 0, 200, 200, compact=True),
+              "f32_u8_200": measure_fused_rollout(torch, T, env, actions, 0, 200, 200)}
+        # the same kernel under the uniform random policy drawn on the device (no actions staged, no per-step outputs)
+        env.rollout_random(100, seed=args.seed)
+        torch.cuda.synchronize(dev)
+        ms["device_random"] = timed(torch, dev, lambda: env.rollout_random(100, seed=args.seed), 4) / 100
+        return ms
+    if args.chunk > 0:
+        fused = side.run("fused_rollout", fused_figures)
+        if side.ok(fused):
+            ms = {k: side.max_over_ranks(v) for k, v in sorted(fused.items())}
+            fused = {"value": float(total) / (ms["f32_u8"] * 1e-3), "unit": "env-steps/s", "steps_per_launch": args.chunk,
+                     "ms_per_step": ms["f32_u8"], "outputs": "per-step reward f32 + done u8 written", "kernel": "rollout_kernel<auto_reset>",
+                     "compact_trajectory": {"value": float(total) / (ms["compact"] * 1e-3), "ms_per_step": ms["compact"],
+                                            "steps_per_launch": args.chunk,
+                                            "outputs": "one byte per board-step (rows cleared, how the move ended, reset, frozen), "
+                                                       "a dword per board every fourth step; tpl_decode_trajectory -> reward f32, done u8"},
+                     "at_200_steps_per_launch": {"compact_trajectory": float(total) / (ms["compact_200"] * 1e-3),
+                                                 "reward_f32_and_done_u8": float(total) / (ms["f32_u8_200"] * 1e-3)},
+                     "device_random_policy": {"value": float(total) / (ms["device_random"] * 1e-3), "ms_per_step": ms["device_random"],
+                                              "steps_per_launch": 100, "outputs": "reward sums and episode counts only"}}
+        more["fused_rollout"] = fused
+    if args.carved_pool > 0 and world == 1:
+        more["carved_pool_run"] = side.run("carved_pool_run", lambda: measure_carved_pool(torch, T, env, actions, reward, done, W, K,
+                                                                                           args.carved_pool, args.seed))
+
+        def live_figures():
+            live = measure_live_supply(torch, T, env, actions, reward, done, args.seed)
+            # the same run by the generator's footprint: how many persistent waves share its queue, and -- the form the
+            # round-2 review asked for -- confined to 32 compute units by a CU-masked stream (which turns out to be the
+            # expensive way: profiles/r03_live_supply)
+            live["generator"] = "PoolRefresher defaults: a plain side stream, waves = count / 256"
+            keep = ("ms_per_step", "slowdown", "pool_swaps", "steps", "configurations_per_batch", "configurations_supplied_per_s",
+                    "pool_reuse_factor")
+            live["by_generator_footprint"] = [
+                dict(generator=name, **{k: v for k, v in measure_live_supply(torch, T, env, actions, reward, done, args.seed, **kw).items() if k in keep})
+                for name, kw in (("1024 waves", dict(waves=1024)), ("1024 waves, batches of 2^20 (a pool's worth)", dict(waves=1024, count=1 << 20)),
+                                 ("64 waves", dict(waves=64)), ("256 waves on a 32-CU stream", dict(waves=256, reserved_cus=32)))]
+            return live
+        more["live_supply_run"] = side.run("live_supply_run", live_figures)
+    try:
+        env.terminate()
+    except Exception:                 # noqa: BLE001 -- a side figure may have left the handle in a state it cannot be destroyed from
+        pass
+    del actions
+    if world == 1 and not args.no_out_of_cache:
+        more["out_of_cache"] = side.run("out_of_cache", lambda: measure_out_of_cache(torch, T, dev, L, M, args.seed))
+    # ---- side figures that own their boards (never part of `value`): last, so that the timed region is the first thing the GPU
+    # does in this process (behind the matrix kernels of the actor loop the same twenty steps read 0.2 us a step slower)
+    if not args.side_figures_first:
+        own_board_figures()
+    if rank == 0 and not args.no_cpu_baseline:
+        # rank 0's host cores, after every collective of the job (the other ranks are on their way out)
+        try:
+            more["cpu_baseline"] = cpu_baseline(L, M, args.seed, numpy_leg)
+        except Exception as e:        # noqa: BLE001
+            more["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+    side.disarm()
+    emit()
     if world > 1:
         dist.destroy_process_group()
 

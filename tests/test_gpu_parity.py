@@ -914,6 +914,51 @@ def test_benched_configuration_in_lockstep_with_the_oracle(T, oracle):
     gpu.terminate()
 
 
+def test_configs3_shard_geometry_eight_shards_of_131072_equal_the_one_gpu_job(T, oracle):
+    """BASELINE configs[3] in its exact geometry, on one GPU: EIGHT handles of 131,072 boards at global offsets k x 131,072
+    (`sharding.strong_shard(k, 8, 2^20)`: what the eight ranks of `bench.py --gpus 8` build), every one over the same
+    2^20-entry pool, stepped 60 times through step_into() with their own slice of the synthetic actions.  Per step the
+    eight shards' rewards and dones, concatenated, are the oracle's over the ONE 2^20-board job; at the end so are the state,
+    the summed statistics and the mean episodic return the ranks' all-reduce would give (the sum of the eight [return sum,
+    episodes] pairs).  Reference: boards are independent objects (game/tetris.py:354-449; one board per Tetris instance)."""
+    import os
+    import torch
+    L, M, total, ranks, seed = 10, 40, 1 << 20, 8, 0
+    steps = int(os.environ.get("TPL_BENCH_PARITY_STEPS", "60"))
+    shards = [T.sharding.strong_shard(k, ranks, total) for k in range(ranks)]
+    assert [(s.boards, s.global_offset) for s in shards] == [(131072, k * 131072) for k in range(ranks)]
+    envs = [T.BatchedTetris(L, M, s.boards, seed=seed, global_offset=s.global_offset, auto_reset=True, assign="hash") for s in shards]
+    rows, pieces = envs[0].synthetic_configs(total, first=0)          # the same pool on every rank, as bench.py loads it
+    for e in envs:
+        e.load_configs(rows, pieces)
+        e.reset()
+    cpu = oracle.Env(total, L, M, 0, seed)
+    cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
+    cpu.set_options(auto_reset=True, assign_mode=0)
+    cpu.reset()
+    dev = envs[0].device
+    reward = [torch.empty(s.boards, dtype=torch.float32, device=dev) for s in shards]
+    done = [torch.empty(s.boards, dtype=torch.uint8, device=dev) for s in shards]
+    for t in range(steps):
+        acts = [e.synthetic_actions(t) for e in envs]                # keyed by the GLOBAL board index
+        for e, a, r, d in zip(envs, acts, reward, done):
+            e.step_into(a, r, d)
+        r_c, d_c = cpu.step(_np(torch.cat(acts)))
+        assert np.array_equal(_np(torch.cat(reward)), r_c) and np.array_equal(_np(torch.cat(done)), d_c), t
+    got = [_state(e) for e in envs]
+    _assert_state_equal({k: np.concatenate([g[k] for g in got]) for k in got[0]}, cpu.get_state(), "eight shards")
+    summed = {k: sum(e.stats()[k] for e in envs) for k in envs[0].stats()}
+    assert summed == cpu.stats() and summed["episodes"] > 4 * total
+    assert all(e.step_clock() == steps for e in envs)
+    # what the job's one collective computes: the SUM over ranks of [return sum, episodes]
+    acc = sum(T.sharding.return_sum(e.stats_tensor(), e.reward_params) for e in envs)
+    one = T.sharding.return_sum(torch.tensor([cpu.stats()[k] for k in ("episodes", "lines", "wins", "topouts")], dtype=torch.int64),
+                                envs[0].reward_params)
+    assert torch.equal(acc.cpu(), one)
+    for e in envs:
+        e.terminate()
+
+
 def test_config1_shape_in_lockstep_with_the_oracle(T, oracle):
     """BASELINE configs[1] as bench.py's config1_run drives it: 65,536 boards, L=5, M=20, pool = boards, auto-reset, hash,
     fused rollouts of 50 steps and single steps interleaved."""

@@ -56,15 +56,20 @@ def test_two_hip_ranks_equal_one_process_and_the_oracle(tmp_path, oracle, mode):
     assert np.array_equal(got["reward_sum"], rsum) and cpu.stats()["episodes"] == episodes
 
 
-def _bench(gpus, extra=()):
+def _bench(gpus, extra=(), boards=65536, inject=None, base=("--sustained", "100", "--actor-boards", "0", "--carved-pool", "0",
+                                                             "--no-config1", "--no-out-of-cache")):
     env = dict(os.environ, TPL_BENCH_ONE_GPU="1", TPL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("RANK", None)
     env.pop("WORLD_SIZE", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "20", "--warmup", "5", "--boards", "65536",
-           "--sustained", "100", "--actor-boards", "0", "--carved-pool", "0", "--no-config1", "--no-out-of-cache", *extra]
+    if inject:
+        env["TPL_BENCH_INJECT_FAILURE"] = inject
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "20", "--warmup", "5", "--boards", str(boards),
+           *base, *extra]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
-    return json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                 # ONE JSON line, whatever happened to the side figures
+    return json.loads(lines[0])
 
 
 @pytest.mark.gpu
@@ -107,6 +112,43 @@ def test_bench_gpus_2_headline_is_the_one_gpu_job_sharded():
         assert sr[form]["us_per_step"] > 0 and 0 < sr[form]["frac"] < 1
         assert sr[form]["frac"] == pytest.approx(96 * 32768 / (sr[form]["us_per_step"] * 1e-6) / 8e12, rel=1e-6)
     assert sr["tpl_rollout"]["us_per_step"] < sr["tpl_step"]["us_per_step"]
+
+
+@pytest.mark.gpu
+def test_bench_sharded_job_of_1048576_boards_on_four_ranks_is_the_one_gpu_job():
+    """BASELINE configs[3]'s job -- 1,048,576 boards IN TOTAL, sharded by global board index, `--steps 20 --warmup 5`, side
+    figures off -- through bench.py itself with FOUR ranks sharing this box's one GPU over gloo (a GPU box of this pool lets
+    at most six processes use its card at once, so the eight-rank form cannot be rehearsed here: its shard geometry is
+    tests/test_gpu_parity.py::test_configs3_shard_geometry_..., its control flow with eight ranks tests/test_bench_guards.py).
+    The line must be the one-GPU line's job: the same episodes and the same mean episodic return."""
+    out = _bench(4, boards=1 << 20, base=("--no-side-figures", "--no-cpu-baseline"))
+    assert out["n_gpus"] == 4 and out["ranks_seen"] == 4 and out["scaling"] == "strong"
+    assert [(r["rank"], r["boards"]) for r in out["per_rank_roofline"]] == [(k, 262144) for k in range(4)]
+    assert all(0 < r["frac"] < 1 for r in out["per_rank_roofline"])
+    assert out["config"]["global_boards"] == 1 << 20 and out["config"]["boards_per_gpu"] == 262144
+    assert out["value"] == pytest.approx((1 << 20) / (out["ms_per_step"] * 1e-3), rel=1e-9)
+    assert out["fused_rollout"] is None and out["weak_scaling_job"] is None and "cpu_baseline" not in out
+    assert out["side_figures"]["failed"] == [] and out["side_figures"]["seconds"] == {}
+    one = _bench(1, boards=1 << 20, base=("--no-side-figures", "--no-cpu-baseline"))
+    assert one["episodes"] > 1 << 20
+    for k in ("episodes", "mean_episodic_return"):
+        assert out[k] == one[k], k
+
+
+@pytest.mark.gpu
+def test_bench_headline_survives_failing_side_figures_on_one_and_on_two_ranks():
+    """A side figure that raises (injected: TPL_BENCH_INJECT_FAILURE) costs its own key, nothing else: the run ends with status 0
+    and ONE line whose headline, roofline and remaining side figures are there.  With two ranks the failure is on rank 1 ONLY:
+    rank 0 must not be left in a collective (the run would end at the process group's timeout instead), and the figure after it
+    (the weak job) still runs on both."""
+    one = _bench(1, inject="fused_rollout", extra=("--no-cpu-baseline", "--shard-ranks", "2"))
+    assert one["value"] > 0 and 0 < one["roofline"]["frac"] < 1 and one["episodes"] > 65536
+    assert "injected" in one["fused_rollout"]["error"] and one["side_figures"]["failed"] == ["fused_rollout"]
+    assert one["roofline"]["sustained"]["launches"] == 100 and one["shard_run"]["tpl_step"]["us_per_step"] > 0
+    two = _bench(2, inject="fused_rollout@1", extra=("--no-cpu-baseline",))
+    assert two["ranks_seen"] == 2 and two["value"] > 0 and two["episodes"] == one["episodes"]
+    assert two["fused_rollout"]["failed_ranks"] == [1] and "rank(s) [1] failed" in two["fused_rollout"]["error"]
+    assert two["weak_scaling_job"]["value"] > 0 and two["side_figures"]["failed"] == ["fused_rollout"]
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
