@@ -531,31 +531,48 @@ def test_randomised_mix_of_steps_rollouts_resets_and_pool_swaps(T, oracle):
 
 
 @pytest.mark.gpu
-def test_pool_refresher_drops_a_batch_that_cannot_be_carved_and_the_run_goes_on(T):
-    """An (L, M) that cannot be carved (the search ends when two cells of the bottom row are gone: two shafts through sixteen
-    rows take eight pieces, there are six): every attempt of every configuration runs into its cut-off, the generator reports
-    it, and poll() -- which used to raise and end the run -- drops the batch, says so once, keeps the pool as it is and starts
-    the next batch; stepping is unaffected."""
+def test_pool_refresher_drops_capped_batches_goes_on_and_stops_after_three_in_a_row(T, oracle):
+    """A cut-off that is marginal for its (L, M) -- L = 8, M = 40 with a base cut-off of 2 trips (512 for the last attempts,
+    where a search takes 400): the pilot configuration finishes, but a few configurations in a thousand run into all 24
+    cut-offs.  By the oracle, batches 0 and 1 of 512 hold such configurations, 2-4 do not, 5-7 do.  poll() drops a capped batch
+    (said once, naming L, M and the cut-off), keeps the pool, starts the next; a clean batch is swapped in; after
+    `max_capped_batches` = 3 capped batches IN A ROW the refresher stops instead of burning the generator's worst case beside
+    the loop for ever (round-4 advisor finding).  `strict=True` raises at the first capped batch.  An (L, M) whose pilot does
+    not finish is refused at construction."""
     import warnings
     import torch
-    L, M, n = 16, 6, 2048
+    L, M, n, count, cutoff, seed = 8, 40, 2048, 512, 2, 1
+    capped = [any(oracle.generate_config_seeded(L, M, seed, b * count + k, cutoff)[0] < 0 for k in range(count)) for b in range(8)]
+    assert capped == [True, True, False, False, False, True, True, True]
     env = T.BatchedTetris(L, M, n, seed=1, auto_reset=True)
     rows, pieces = env.synthetic_configs(256)
     env.load_configs(rows, pieces)
     env.reset()
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter("always")
-        feeder = T.PoolRefresher(env, 128, seed=1, cutoff=8)
-        swapped = 0
-        for t in range(400):
+        feeder = T.PoolRefresher(env, count, seed=seed, cutoff=cutoff)
+        for t in range(4000):
             env.step(env.synthetic_actions(t), observe=False)
-            swapped += bool(feeder.poll())
-            if feeder.capped_batches >= 2:
+            feeder.poll()
+            if feeder.stopped:
                 break
         torch.cuda.synchronize()
-    assert swapped == 0 and feeder.swaps == 0 and feeder.capped_batches >= 2
-    said = [w for w in caught if "could not be carved" in str(w.message)]
-    assert len(said) == 1
-    assert env.pool_info()["n_configs"] == 256                    # the pool the run started with
+    assert feeder.stopped and feeder.swaps == 3 and feeder.capped_batches == 5
+    said = [str(w.message) for w in caught if "ran into every cut-off" in str(w.message)]
+    assert len(said) == 2 and "L=8, M=40, cutoff=2" in said[0] and "STOPPED" in said[1] and "STOPPED" not in said[0]
+    assert env.pool_info()["n_configs"] == count                  # the last clean batch
+    assert feeder.poll() is False                                 # stays stopped, launches nothing
     feeder.close()
+    strict = T.PoolRefresher(env, count, seed=seed, cutoff=cutoff, strict=True)
+    with pytest.raises(RuntimeError, match="ran into every cut-off"):
+        for t in range(4000):
+            env.step(env.synthetic_actions(t), observe=False)
+            strict.poll()
+    strict.close()
+    with pytest.raises(T.TplError, match="pilot"):
+        T.PoolRefresher(env, count, seed=seed, cutoff=1)
+    env.terminate()
+    env = T.BatchedTetris(16, 6, 64, seed=1)
+    with pytest.raises(T.TplError, match="at least 8"):          # two shafts through sixteen rows take eight pieces
+        T.PoolRefresher(env, 128, seed=1)
     env.terminate()

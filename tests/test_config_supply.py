@@ -335,25 +335,17 @@ def test_device_generator_reports_configurations_that_cannot_be_carved():
 
 @pytest.mark.gpu
 def test_device_generator_reports_single_configurations_that_run_into_every_cutoff(oracle):
-    """The pilot passes but SOME configurations of the batch fail all 24 attempts (a cut-off of 6 trips at L = 5, 1,536 for the
-    last attempts against a median search of 190): status 1 and zeroed outputs for exactly those the oracle caps, the launch
-    ends, every other configuration is the oracle's."""
+    """The pilot passes but SOME configurations of the batch fail all 24 attempts (L = 8, M = 40 at a base cut-off of 2 trips,
+    512 for the last attempts, against a median search of 400): status 1 and zeroed outputs for exactly those the oracle caps
+    (4 of the first 512 at seed 1), the launch ends, every other configuration is the oracle's."""
     import torch
     import tetris_piclim as T
-    L, M, n, cutoff, seed = 5, 20, 512, 0, 11
+    L, M, n, cutoff, seed = 8, 40, 512, 2, 1
     env = T.BatchedTetris(L, M, 64)
-    # find a cut-off at which the pilot passes and a few of the batch do not: deterministic, searched here on the host side
-    for cutoff in (1, 2, 3, 4, 6, 8):
-        capped = [oracle.generate_config_seeded(L, M, seed, k, cutoff)[0] < 0 for k in range(n)]
-        try:
-            T.generate_configs(L, M, 1, seed=seed, cutoff=cutoff)
-            pilot_ok = True
-        except T.TplError as e:
-            pilot_ok = "pilot" not in str(e)
-        if pilot_ok and 0 < sum(capped) < n:
-            break
-    else:
-        pytest.skip("no cut-off separates the pilot from the batch at this seed")
+    capped = [oracle.generate_config_seeded(L, M, seed, k, cutoff)[0] < 0 for k in range(n)]
+    assert sum(capped) == 4
+    with pytest.raises(T.TplError, match="4 of 512"):
+        env.carved_configs(n, seed=seed, cutoff=cutoff)
     rows, pieces, status = env.carved_configs(n, seed=seed, cutoff=cutoff, return_status=True)
     status = status.cpu().numpy()
     assert np.array_equal(status != 0, np.array(capped))
