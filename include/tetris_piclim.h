@@ -349,6 +349,19 @@ int tpl_forward_generate(int32_t L, int32_t M, int32_t initial_height_max, int32
                          int64_t count, int32_t threads, uint16_t* rows, uint8_t* sequence, uint8_t* winnable,
                          int32_t* failed_attempts, uint8_t* solution, uint8_t* solver_stack, int32_t* solution_len);
 
+/* The same generator + solver on the GPU, one game per lane (a lane carries its own CPython-compatible MT19937): the same
+ * games, seed for seed, as tpl_forward_generate and as the reference.  DEVICE pointers throughout, `seeds` included; the
+ * optional outputs may be null; rows of `solution` / `solver_stack` past solution_len are zero.  `work`:
+ * tpl_forward_generate_device_work_bytes(M, count) bytes (the generator states and the solver's frames), 4-byte aligned.
+ * count < 2^31.  Exists so that a pool blending both of the reference's producers (game/tetris.py:195-211, 482-488) can be
+ * built without the host; not a fast kernel -- the reference runs this supplier over the same hundred seeds per batch
+ * (tetris_algo_main/main.py:39-40). */
+size_t tpl_forward_generate_device_work_bytes(int32_t M, int64_t count);
+int tpl_forward_generate_device(int32_t L, int32_t M, int32_t initial_height_max, int32_t max_attempts, const uint64_t* seeds,
+                                int64_t count, uint16_t* rows, uint8_t* sequence, uint8_t* winnable, int32_t* failed_attempts,
+                                uint8_t* solution, uint8_t* solver_stack, int32_t* solution_len, void* work, size_t work_bytes,
+                                void* stream);
+
 /* Replaces Tetris.carve(piece, rotations, location, allow_partial) (game/tetris.py:286-352), the inverse of a move
  * and the carving generator's building block, on ONE board in HOST memory: rows[20] is modified in place when the
  * carve succeeds; *carved = 1 / 0.  (The reference does not clamp here: a location that puts the piece outside the

@@ -20,7 +20,7 @@ def __getattr__(name):
     if name in ("BatchedTetris", "Tetris", "Snapshot", "OBS_DIM", "NUM_ACTIONS", "RUNNING", "WON", "LOST", "env"):
         env = importlib.import_module(__name__ + ".env")
         return env if name == "env" else getattr(env, name)
-    if name in ("save_pool", "load_pool", "PoolRefresher"):
+    if name in ("save_pool", "load_pool", "PoolRefresher", "ForwardGames", "blend"):
         return getattr(importlib.import_module(__name__ + ".pool"), name)
     if name in ("sharding", "actor", "pool"):
         return importlib.import_module(__name__ + "." + name)

@@ -27,7 +27,7 @@ _LIBDIR = os.path.join(_ROOT, "lib")
 LIB_PATH = os.path.join(_LIBDIR, "libtetris_piclim_diag.so" if _DIAG else
                         f"libtetris_piclim_{_EXTRA}.so" if _EXTRA else "libtetris_piclim.so")
 _UNITS = [os.path.join(_CSRC, f) for f in ("tetris_piclim.hip", "carve_generator.hip", "carve_device.hip",
-                                           "forward_generator.hip", "policy_mlp.hip", "policy_f32.hip", "policy_split.hip", "observe.hip")]
+                                           "forward_generator.hip", "forward_device.hip", "policy_mlp.hip", "policy_f32.hip", "policy_split.hip", "observe.hip")]
 _SOURCES = _UNITS + [os.path.join(_CSRC, "tpl_device.h"), os.path.join(_CSRC, "tpl_internal.h"),
                      os.path.join(_CSRC, "tpl_step.h"), os.path.join(_CSRC, "tpl_observe.h"), os.path.join(_CSRC, "tpl_policy.h"), os.path.join(_CSRC, "py_random.h"),
                      os.path.join(_ROOT, "include", "tetris_piclim.h")]
@@ -38,6 +38,7 @@ SYMBOLS = [
     "tpl_set_options", "tpl_load_configs", "tpl_reset", "tpl_move", "tpl_step", "tpl_step_observe", "tpl_get_state",
     "tpl_expand_obs", "tpl_expand_states", "tpl_get_board", "tpl_carve", "tpl_get_stats", "tpl_shape_info", "tpl_state_ptrs", "tpl_synth_configs",
     "tpl_synth_actions", "tpl_set_tuning", "tpl_rollout", "tpl_rollout_random", "tpl_rollout_trajectory", "tpl_rollout_random_trajectory", "tpl_decode_trajectory", "tpl_decode_actions", "tpl_generate_configs", "tpl_generate_configs_pyseed", "tpl_forward_generate",
+    "tpl_forward_generate_device_work_bytes", "tpl_forward_generate_device",
     "tpl_generate_configs_device_work_bytes", "tpl_generate_configs_device", "tpl_generate_configs_device_waves",
     "tpl_policy_image_bytes", "tpl_policy_pack", "tpl_policy_act",
     "tpl_policy_image_bytes_f32", "tpl_policy_pack_f32", "tpl_policy_act_f32",
@@ -183,6 +184,9 @@ def lib() -> C.CDLL:
     L.tpl_generate_configs_device.argtypes = [i32, i32, u64, i64, i64, i64, vp, vp, vp, vp, vp, vp, sz, vp]
     L.tpl_generate_configs_device_waves.argtypes = [i32, i32, u64, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp, sz, vp]
     L.tpl_forward_generate.argtypes = [i32, i32, i32, i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.tpl_forward_generate_device_work_bytes.restype = sz
+    L.tpl_forward_generate_device_work_bytes.argtypes = [i32, i64]
+    L.tpl_forward_generate_device.argtypes = [i32, i32, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.tpl_synth_configs.argtypes = [vp, u64, i64, i64, vp, vp, vp]
     L.tpl_synth_actions.argtypes = [vp, u64, i64, i64, u64, vp, vp]
     for name in SYMBOLS:

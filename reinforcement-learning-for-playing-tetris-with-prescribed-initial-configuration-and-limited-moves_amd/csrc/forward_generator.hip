@@ -167,6 +167,13 @@ int to_move_rotations(int letter, int rotation) {
 }
 
 }  // namespace
+
+// for forward_device.hip: the same translation, as a table it hands to its kernel
+int forward_move_rotations(int letter, int rotation) {
+    if (letter < 0 || letter > 6 || rotation < 0 || rotation >= kForwardRot[letter]) return 0;
+    return to_move_rotations(letter, rotation);
+}
+
 }  // namespace tpl
 
 extern "C" int tpl_forward_generate(int32_t L, int32_t M, int32_t initial_height_max, int32_t max_attempts,

@@ -71,6 +71,10 @@ void count_steps(tpl_env* e, int64_t steps);
 // Both generators call it before a batch goes out -- on the device the alternative is a kernel that runs for minutes.
 int carve_pilot(int32_t L, int32_t M, int64_t cutoff);
 
+// forward_generator.hip: the rotation count of Tetris.move that shows the same shape as the forward solver's (letter index in
+// IJLOSTZ, rotation) -- the two sub-packages of the reference order their rotations differently
+int forward_move_rotations(int letter, int rotation);
+
 // observe.hip: the [N,217] observation with 16-byte stores (needs a 16-byte aligned output)
 bool observe_fast_path(const void* out);
 int launch_observe(const uint4* plane_a, const uint4* plane_b, int64_t n, uint32_t L, uint32_t M, void* out, int32_t dtype,

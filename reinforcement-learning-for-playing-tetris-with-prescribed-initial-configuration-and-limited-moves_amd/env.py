@@ -230,6 +230,30 @@ class BatchedTetris:
                                 f"into its cut-off (L={self.L} M={self.M} cutoff={int(cutoff) or 'by L'}; a larger `cutoff` searches on)")
         return out
 
+    def forward_configs(self, seeds, initial_height_max: int = 4, max_attempts: int = 1000):
+        """The reference's forward generator + solver (game/tetris_algo_main/) ON THE DEVICE, one game per lane, for the
+        given integer seeds: the same games, seed for seed, as `forward_generate()` builds on the host and as the reference's
+        TetrisGameGenerator(seed, goal=L, tetrominoes=M, initial_height_max) + TetrisSolver(...).solve().  Returns a dict of
+        device tensors over ALL seeds: rows int16 [n, 20], sequence uint8 [n, M] (piece ids of Tetris.move), winnable bool
+        [n], failed_attempts int32 [n], solution uint8 [n, M, 2] (rotations, location), solver_stack uint8 [n, M, 3],
+        solution_len int32 [n]."""
+        seeds = torch.as_tensor(np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64)).view(np.int64)).to(self.device)
+        n, d, M = int(seeds.numel()), self.device, self.M
+        out = dict(rows=torch.empty((n, 20), dtype=torch.int16, device=d), sequence=torch.empty((n, M), dtype=torch.uint8, device=d),
+                   winnable=torch.empty(n, dtype=torch.uint8, device=d), failed_attempts=torch.empty(n, dtype=torch.int32, device=d),
+                   solution=torch.empty((n, M, 2), dtype=torch.uint8, device=d),
+                   solver_stack=torch.empty((n, M, 3), dtype=torch.uint8, device=d),
+                   solution_len=torch.empty(n, dtype=torch.int32, device=d))
+        nbytes = self._lib.tpl_forward_generate_device_work_bytes(M, n)
+        work = torch.empty(nbytes, dtype=torch.uint8, device=d)
+        check(self._lib.tpl_forward_generate_device(self.L, M, int(initial_height_max), int(max_attempts), _ptr(seeds), n,
+                                                    _ptr(out["rows"]), _ptr(out["sequence"]), _ptr(out["winnable"]),
+                                                    _ptr(out["failed_attempts"]), _ptr(out["solution"]), _ptr(out["solver_stack"]),
+                                                    _ptr(out["solution_len"]), _ptr(work), nbytes, self._stream()))
+        work.record_stream(torch.cuda.current_stream(d))
+        out["winnable"] = out["winnable"].view(torch.bool)
+        return out
+
     def synthetic_configs(self, count: int, seed: Optional[int] = None, first: int = 0):
         """The synthetic boards / piece lists of SURVEY 8(d), generated on the device."""
         seed = self.seed if seed is None else seed

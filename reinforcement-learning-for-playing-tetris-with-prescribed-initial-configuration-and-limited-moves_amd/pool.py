@@ -97,6 +97,51 @@ def concurrent_stream(env):
     return chosen
 
 
+class ForwardGames:
+    """The winnable games of the reference's forward generator + solver for a set of seeds (its own: 0..99,
+    tetris_algo_main/main.py:39-40), produced on the device once and kept there, ready to be blended into pools of carved
+    configurations -- the reference's queue has both producers (game/tetris.py:195-211, 482-488).
+
+    `translate(batch)` gives them the way the reference's `translate()` does (game/tetris.py:19-20): ONE random piece put in
+    FRONT of the sequence, so that `pieces` has M + 1 entries -- which also means the game no longer starts with the piece its
+    solver planned for: a translated game is not winnable by construction, in the reference either.  `lead=False` pads at the
+    END instead (the recorded solution still wins; the last piece is never played)."""
+
+    def __init__(self, env, seeds=range(100), initial_height_max: int = 4, max_attempts: int = 1000):
+        import torch
+        out = env.forward_configs(list(seeds), initial_height_max, max_attempts)
+        keep = out["winnable"]                                 # one host sync, at construction
+        self.device, self.M = env.device, env.M
+        self.tried = int(keep.numel())
+        self.rows = out["rows"][keep].contiguous()
+        self.sequence = out["sequence"][keep].contiguous()
+        self.solution = out["solution"][keep].contiguous()
+        self.solution_len = out["solution_len"][keep].contiguous()
+        self.count = int(self.rows.shape[0])
+        self._torch = torch
+
+    def translate(self, seed: int = 0, batch: int = 0, lead: bool = True):
+        """(rows int16 [count, 20], pieces uint8 [count, M + 1]) on the device, enqueued on the current stream (no host wait).
+        The extra piece of game g in batch b is a function of (seed, b, g): rng = numpy's PCG64 seeded with (seed, b)."""
+        torch = self._torch
+        extra = np.random.default_rng((int(seed), int(batch))).integers(0, 7, (self.count, 1)).astype(np.uint8)
+        extra = torch.from_numpy(extra).to(self.device, non_blocking=True)
+        pieces = torch.cat([extra, self.sequence] if lead else [self.sequence, extra], dim=1)
+        return self.rows, pieces
+
+
+def blend(carved, forward_games, seed: int = 0, batch: int = 0, lead: bool = True):
+    """One pool from both of the reference's producers: `carved` = (rows, pieces) device tensors of the carving generator,
+    followed by the winnable forward games as `translate()` hands them over.  (Which entry an episode draws is the
+    environment's assignment; the reference's queue interleaves by arrival.)"""
+    import torch
+    rows, pieces = carved
+    if forward_games is None or forward_games.count == 0:
+        return rows, pieces
+    f_rows, f_pieces = forward_games.translate(seed, batch, lead)
+    return torch.cat([rows, f_rows]), torch.cat([pieces, f_pieces])
+
+
 class PoolRefresher:
     """Keeps a running BatchedTetris supplied with FRESH prescribed configurations -- the analogue of the reference's
     two producer processes feeding the reset queue while games are played (game/tetris.py:195-211, 473-488).
@@ -115,7 +160,8 @@ class PoolRefresher:
     """
 
     def __init__(self, env, count: int, seed: int = 0, first: int = 0, waves: int = 0, reserved_cus: int = 0,
-                 low_priority: bool = False, cutoff: int = 0, strict: bool = False, max_capped_batches: int = 3):
+                 low_priority: bool = False, cutoff: int = 0, strict: bool = False, max_capped_batches: int = 3,
+                 forward_seeds=None, forward_lead: bool = True):
         """waves: how many persistent 64-lane waves share the generator's queue (0 = count / 256): its footprint beside
         the stepping environment.  What a footprint costs and supplies is in bench.py's `live_supply_run`
         (`by_generator_footprint`; profiles/NOTES.md has the history).  (The step kernel raises its waves'
@@ -143,6 +189,8 @@ class PoolRefresher:
         self.capped_batches = 0       # batches dropped because a configuration's attempts all ran into their cut-off
         self._capped_in_a_row = 0
         self.stopped = False
+        self.forward = ForwardGames(env, forward_seeds) if forward_seeds is not None else None
+        self.forward_lead, self._batches = bool(forward_lead), 0
         self.start()
 
     def start(self) -> None:
@@ -212,7 +260,11 @@ class PoolRefresher:
         # the finished batch is packed on the stream that made it: its tensors belong to that stream's allocations
         made_on.wait_stream(main)                                  # launches that still read the buffer being replaced
         with torch.cuda.stream(made_on):
-            self.env.load_configs(rows, pieces, validate=False)    # the generator cannot emit an invalid piece id
+            if self.forward is not None:
+                made_on.wait_stream(main)                          # the forward games were made on the stepping stream
+                rows, pieces = blend((rows, pieces), self.forward, self.seed, self._batches, self.forward_lead)
+            self._batches += 1
+            self.env.load_configs(rows, pieces, validate=False)    # the generators cannot emit an invalid piece id
         main.wait_stream(made_on)                                  # the next step sees the packed pool
         for mem in self.env._pool_mems:                            # allocated on the side stream, read on the stepping one
             if mem is not None:

@@ -430,3 +430,111 @@ def test_generated_pool_replays_to_a_win_on_the_gpu(L, M, n):
     assert bool((s["state"] == T.WON).all()) and bool((s["lines"] >= L).all())
     assert torch.equal(s["moves"].cpu(), torch.from_numpy(sol_len.astype(np.uint8)))
     env.terminate()
+
+
+# ------------------------------------------------------------------------------------- SURVEY 8(f-4) on the device
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["forward_L5_M20.npz", "forward_L3_M20.npz", "forward_L10_M40.npz"])
+def test_device_forward_generator_and_solver_reproduce_the_reference_seed_for_seed(name):
+    """tpl_forward_generate_device (csrc/forward_device.hip: one game per lane, a CPython-compatible MT19937 per lane) against
+    the REFERENCE's own games (tests/golden/make_golden_forward.py ran TetrisGameGenerator.py:15-29,72-106 and
+    TetrisSolver.py:112-163 for these seeds): board, sequence, verdict, failed-attempt count and the solver's stack, seed for
+    seed -- and against the host form for every output, the translated solution included."""
+    import tetris_piclim as T
+    f = load_golden(name)
+    L, M, seeds = int(f["L"]), int(f["M"]), f["seeds"]
+    env = T.BatchedTetris(L, M, 64)
+    dev = {k: v.cpu().numpy() for k, v in env.forward_configs(seeds).items()}
+    assert np.array_equal(dev["rows"].view(np.uint16), f["rows"])
+    assert np.array_equal(dev["sequence"], LETTER_TO_ID[f["sequence"]])
+    assert np.array_equal(dev["winnable"], f["winnable"].astype(bool))
+    assert np.array_equal(dev["failed_attempts"], f["failed_attempts"])
+    assert np.array_equal(dev["solution_len"], f["stack_len"])
+    for k in range(len(seeds)):
+        n = int(f["stack_len"][k])
+        assert np.array_equal(dev["solver_stack"][k, :n], f["stack"][k, :n]), k
+    host = T.forward_generate(L, M, seeds)
+    for key in ("rows", "sequence", "winnable", "failed_attempts", "solution", "solver_stack", "solution_len"):
+        a = dev[key].view(np.uint16) if key == "rows" else dev[key]
+        assert np.array_equal(a, host[key]), key
+    env.terminate()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,M,height,attempts,n", [(3, 20, 4, 1000, 700), (5, 20, 4, 1000, 333), (4, 9, 6, 50, 200), (2, 9, 6, 50, 200), (2, 254, 2, 30, 130),
+                                                  (6, 30, 8, 3000, 96)])
+def test_device_forward_generator_equals_the_host_form_on_other_seeds_and_settings(L, M, height, attempts, n):
+    """Seeds past 2^32 (two 32-bit digits of the seeding key), other height limits and attempt budgets, a ragged last wave, the
+    longest sequence the ABI takes: device == host on every output."""
+    import tetris_piclim as T
+    rng = np.random.default_rng(L * 1000 + M)
+    seeds = np.concatenate([np.arange(n // 2, dtype=np.uint64), rng.integers(0, 1 << 63, n - n // 2).astype(np.uint64)])
+    env = T.BatchedTetris(L, M, 64)
+    dev = {k: v.cpu().numpy() for k, v in env.forward_configs(seeds, initial_height_max=height, max_attempts=attempts).items()}
+    host = T.forward_generate(L, M, seeds, initial_height_max=height, max_attempts=attempts)
+    for key in ("rows", "sequence", "winnable", "failed_attempts", "solution", "solver_stack", "solution_len"):
+        a = dev[key].view(np.uint16) if key == "rows" else dev[key]
+        assert np.array_equal(a, host[key]), key
+    assert (L, M) == (4, 9) or 0 < host["winnable"].sum() < n          # both verdicts occur (at (4, 9) nothing is winnable)
+    env.terminate()
+
+
+@pytest.mark.gpu
+def test_blended_pool_of_carved_and_forward_games_as_the_reference_queue_holds_them():
+    """The reference's reset queue is fed by BOTH producers (game/tetris.py:195-211, 473-488): carved configurations, and the
+    winnable games of the forward generator over seeds 0..99 through translate() (:19-20: one random piece in FRONT of the
+    sequence).  `blend()` builds that pool on the device.  Checked: the carved part replays to wins by its recorded solutions;
+    the forward part, padded at the END instead (lead=False), replays to wins by the solver's solutions -- through
+    Tetris.move's rules on the GPU, whose rotation order differs from the solver's; and the translated form (lead=True) is
+    those same boards with pieces[1:] == the sequence."""
+    import torch
+    import tetris_piclim as T
+    L, M, n = 3, 20, 512
+    env = T.BatchedTetris(L, M, 64)
+    rows, pieces, sol, sol_len = env.carved_configs(n, seed=4, with_solutions=True)
+    games = T.ForwardGames(env, range(100))
+    assert games.tried == 100 and 50 < games.count < 100          # L = 3: most seeds are winnable
+    b_rows, b_pieces = T.blend((rows, pieces), games, seed=4, batch=0, lead=False)
+    assert b_rows.shape == (n + games.count, 20) and b_pieces.shape == (n + games.count, M + 1)
+    both_sol = torch.cat([sol, games.solution])
+    both_len = torch.cat([sol_len, games.solution_len]).cpu().numpy()
+    total = n + games.count
+    play = T.BatchedTetris(L, M, total, assign="sequential", config_pool=(b_rows, b_pieces))
+    play.reset()
+    for t in range(int(both_len.max())):
+        active = torch.from_numpy(t < both_len).to(play.device)
+        play.move(torch.where(active, both_sol[:, t, 0], 0), torch.where(active, both_sol[:, t, 1], 0))
+    s = play.packed_state()
+    assert bool((s["state"] == T.WON).all()) and bool((s["lines"] >= L).all())
+    play.terminate()
+    t_rows, t_pieces = T.blend((rows, pieces), games, seed=4, batch=1, lead=True)
+    assert torch.equal(t_rows, b_rows) and torch.equal(t_pieces[:n], pieces)
+    assert torch.equal(t_pieces[n:, 1:], games.sequence) and int(t_pieces[n:, 0].max()) <= 6
+    again = T.blend((rows, pieces), games, seed=4, batch=1, lead=True)[1]
+    other = T.blend((rows, pieces), games, seed=4, batch=2, lead=True)[1]
+    assert torch.equal(again, t_pieces) and not torch.equal(other[n:, 0], t_pieces[n:, 0])     # the extra piece: a function of the batch
+    env.terminate()
+
+
+@pytest.mark.gpu
+def test_pool_refresher_blends_forward_games_into_every_batch():
+    import torch
+    import tetris_piclim as T
+    L, M, n, count = 3, 20, 4096, 1024
+    env = T.BatchedTetris(L, M, n, seed=2, auto_reset=True)
+    rows, pieces = env.synthetic_configs(256)
+    env.load_configs(rows, pieces)
+    env.reset()
+    feeder = T.PoolRefresher(env, count, seed=2, forward_seeds=range(100))
+    extra = feeder.forward.count
+    assert extra > 50
+    swaps = 0
+    for t in range(600):
+        env.step(env.synthetic_actions(t), observe=False)
+        swaps += bool(feeder.poll())
+        if swaps >= 3:
+            break
+    torch.cuda.synchronize()
+    assert swaps >= 3 and env.pool_info()["n_configs"] == count + extra
+    feeder.close()
+    env.terminate()
