@@ -16,9 +16,13 @@
 // Geometry: as the other policy kernels -- boards on the MFMA's N dimension, 32 boards (two N tiles) per wave, features
 // along M/K in the bf16 kernel's permuted order, so that two consecutive output tiles of a layer, as they leave the matrix
 // core (float32), are the eight k-values of one B fragment of the next.  Here the K-STEPS run outermost in every layer: the B
-// fragment of a k-step is split into its three bf16 pieces once and used by all eight output tiles, whose accumulators stay
-// live (64 registers); the float32 activations of the previous layer (64 registers) are the only other large thing.
-// The three weight planes are 474 KB and stream through two 64-KB LDS buffers in ten chunks per pass, as in policy_f32.hip.
+// fragment of a k-step is split into its three bf16 pieces ONCE and meets all three weight planes of all eight output tiles
+// there and then (their accumulators stay live, 64 registers; the float32 activations of the previous layer, 64 registers, are
+// the only other large thing).  The three weight planes are 474 KB and stream through two 64-KB LDS buffers in ten chunks per
+// pass, as in policy_f32.hip: layer 1 plane by plane, a hidden layer as two chunks of two k-steps each, ALL THREE planes of
+// those k-steps in the chunk (through round 4 a hidden layer's chunks went plane-wise -- the high plane, then the two low
+// ones -- and every activation fragment was split twice, once under each: 2.55 vector instructions per MFMA, a third of
+// them that second split).
 #include "tpl_internal.h"
 #include "tpl_policy.h"
 #include "tpl_step.h"
@@ -37,10 +41,12 @@ constexpr int kKs1 = 7, kKsH = 4, kMt = 8;
 constexpr int kPlane1 = kMt * kKs1 * 1024;     // 57,344: one bf16 plane of layer 1's A fragments
 constexpr int kPlaneH = kMt * kKsH * 1024;     // 32,768: of a hidden layer
 constexpr int kPlane5 = kKsH * 1024;           //  4,096: of the head (one 16-row tile)
-// chunks in the order of use: layer 1 plane by plane; a hidden layer as its high plane, then (low + low-low planes); the head
+// chunks in the order of use: layer 1 plane by plane; a hidden layer as k-steps {0, 1} then {2, 3}, each with its three planes
+// (fragment (k-step s, plane i, tile m) of a hidden layer at ((s & 1) * 3 + i) * kMt + m in chunk s >> 1); the head
 constexpr int kChunks = 10;
-constexpr int kChunkBytes[kChunks] = {kPlane1, kPlane1, kPlane1, kPlaneH, 2 * kPlaneH, kPlaneH, 2 * kPlaneH, kPlaneH, 2 * kPlaneH, 3 * kPlane5};
-constexpr int kChunkOff[kChunks] = {0, 57344, 114688, 172032, 204800, 270336, 303104, 368640, 401408, 466944};
+constexpr int kHalfH = 3 * kPlaneH / 2;        // 49,152: two k-steps x three planes x eight tiles
+constexpr int kChunkBytes[kChunks] = {kPlane1, kPlane1, kPlane1, kHalfH, kHalfH, kHalfH, kHalfH, kHalfH, kHalfH, 3 * kPlane5};
+constexpr int kChunkOff[kChunks] = {0, 57344, 114688, 172032, 221184, 270336, 319488, 368640, 417792, 466944};
 constexpr int kOffB = 479232;
 constexpr int kImageBytes = kOffB + (4 * kHidden + 16) * 4;
 constexpr int kBufBytes = 65536;
@@ -72,8 +78,8 @@ extern "C" int tpl_policy_pack_split(const float* w1, const float* b1, const flo
     if (!w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !w4 || !b4 || !w5 || !b5 || !image)
         return fail_msg(TPL_ERR_ARG, "tpl_policy_pack_split: null pointer");
     std::vector<uint8_t> img((size_t)kImageBytes, 0);
-    // planes[i] = byte offset of piece i's plane of this layer
-    auto pack_layer = [&](const int (&planes)[3], const float* w, int rows, int in, int mt, int ks, bool first) {
+    // where(i, m, s) = byte offset of the A fragment (piece i, output tile m, k-step s) of this layer
+    auto pack_layer = [&](auto where, const float* w, int rows, int in, int mt, int ks, bool first) {
         for (int m = 0; m < mt; ++m)
             for (int s = 0; s < ks; ++s)
                 for (int lane = 0; lane < 64; ++lane)
@@ -89,18 +95,15 @@ extern "C" int tpl_policy_pack_split(const float* w1, const float* b1, const flo
                         uint16_t piece[3];
                         split3(v, piece);
                         for (int i = 0; i < 3; ++i)
-                            ((uint16_t*)(img.data() + planes[i]))[((m * ks + s) * 64 + lane) * 8 + j] = piece[i];
+                            ((uint16_t*)(img.data() + where(i, m, s)))[lane * 8 + j] = piece[i];
                     }
     };
-    const int l1[3] = {kChunkOff[0], kChunkOff[1], kChunkOff[2]};
-    pack_layer(l1, w1, kHidden, kObs, kMt, kKs1, true);
+    pack_layer([](int i, int m, int s) { return kChunkOff[i] + (m * kKs1 + s) * 1024; }, w1, kHidden, kObs, kMt, kKs1, true);
     const float* wh[3] = {w2, w3, w4};
-    for (int l = 0; l < 3; ++l) {
-        const int pl[3] = {kChunkOff[3 + 2 * l], kChunkOff[4 + 2 * l], kChunkOff[4 + 2 * l] + kPlaneH};
-        pack_layer(pl, wh[l], kHidden, kHidden, kMt, kKsH, false);
-    }
-    const int l5[3] = {kChunkOff[9], kChunkOff[9] + kPlane5, kChunkOff[9] + 2 * kPlane5};
-    pack_layer(l5, w5, kOut, kHidden, 1, kKsH, false);
+    for (int l = 0; l < 3; ++l)
+        pack_layer([l](int i, int m, int s) { return kChunkOff[3 + 2 * l + (s >> 1)] + (((s & 1) * 3 + i) * kMt + m) * 1024; },
+                   wh[l], kHidden, kHidden, kMt, kKsH, false);
+    pack_layer([](int i, int m, int s) { (void)m; return kChunkOff[9] + i * kPlane5 + s * 1024; }, w5, kOut, kHidden, 1, kKsH, false);
     float* bias = (float*)(img.data() + kOffB);
     const float* bs[4] = {b1, b2, b3, b4};
     for (int l = 0; l < 4; ++l)
@@ -152,24 +155,25 @@ __device__ __forceinline__ f32x4 mfma(bf16x8 a, const uint4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// float32 pair -> the packed bf16 pair nearest to it, and what is left of the pair after taking it away (exact)
-__device__ __forceinline__ uint32_t take_bf16(float& a, float& b) {
-    const uint32_t packed = pack_bf16(a, b);
-    a -= __uint_as_float(packed << 16);
-    b -= __uint_as_float(packed & 0xFFFF0000u);
+// float32 pair -> the packed bf16 pair nearest to it, and what is left of the pair after taking it away (exact): the two
+// subtractions as ONE packed instruction (v_pk_add_f32 on a register pair)
+__device__ __forceinline__ uint32_t take_bf16(f32x2& v) {
+    const uint32_t packed = pack_bf16(v[0], v[1]);
+    const f32x2 back = {__uint_as_float(packed << 16), __uint_as_float(packed & 0xFFFF0000u)};
+    v -= back;
     return packed;
 }
 
 // The B fragment of k-step s of a hidden layer -- the eight float32 values (tile 2s, registers 0..3; tile 2s+1, registers
-// 0..3) a lane holds of board (t, c) -- as bf16 pieces: all three, or the high one only.
+// 0..3) a lane holds of board (t, c) -- as its three bf16 pieces.
 __device__ __forceinline__ void split_fragment(const f32x4& lo_tile, const f32x4& hi_tile, uint4& xh, uint4& xl, uint4& xll) {
-    float v[8] = {lo_tile[0], lo_tile[1], lo_tile[2], lo_tile[3], hi_tile[0], hi_tile[1], hi_tile[2], hi_tile[3]};
+    f32x2 v[4] = {{lo_tile[0], lo_tile[1]}, {lo_tile[2], lo_tile[3]}, {hi_tile[0], hi_tile[1]}, {hi_tile[2], hi_tile[3]}};
     uint32_t* h = (uint32_t*)&xh; uint32_t* l = (uint32_t*)&xl; uint32_t* ll = (uint32_t*)&xll;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        h[i] = take_bf16(v[2 * i], v[2 * i + 1]);
-        l[i] = take_bf16(v[2 * i], v[2 * i + 1]);
-        ll[i] = pack_bf16(v[2 * i], v[2 * i + 1]);
+        h[i] = take_bf16(v[i]);
+        l[i] = take_bf16(v[i]);
+        ll[i] = pack_bf16(v[i][0], v[i][1]);
     }
 }
 __device__ __forceinline__ uint4 high_fragment(const f32x4& lo_tile, const f32x4& hi_tile) {
@@ -253,16 +257,14 @@ __device__ __forceinline__ void split_logits(uint4 (&s_buf)[2][kBufBytes / 16], 
 #pragma unroll
             for (int m = 0; m < kMt; ++m) { x[m][0] = acc[m][0]; x[m][1] = acc[m][1]; }
             set_bias(acc, s_bias + (layer + 1) * kHidden, g);
-            // Two chunks of THREE products each, so that neither is short against the transfer that runs under it.  (As five and
-            // one -- high + low planes, then the low-low plane -- the second chunk was 64 multiplies per wave under a 64-KB
-            // transfer.  With no transfers at all the kernel runs 13 % faster, a timing experiment said; evening the chunks
-            // out recovered none of it -- 163 us either way -- so it is the stream's average rate, not its bursts.)
-            // chunk 3 + 2 layer: the HIGH plane against all three pieces of the activations
-            TPL_NEXT_CHUNK(4 + 2 * layer);
-            {
+            // two chunks of two k-steps each; a k-step's fragment is split once and multiplied with all three planes
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                TPL_NEXT_CHUNK(4 + 2 * layer + half);
                 lds_byte* w = chunk_base(s_buf[buf], lane);
 #pragma unroll
-                for (int s = 0; s < kKsH; ++s) {
+                for (int sl = 0; sl < 2; ++sl) {
+                    const int s = 2 * half + sl;
                     uint4 xh[2], xl[2], xll[2];
 #pragma unroll
                     for (int t = 0; t < 2; ++t) split_fragment(x[2 * s][t], x[2 * s + 1][t], xh[t], xl[t], xll[t]);
@@ -270,62 +272,29 @@ __device__ __forceinline__ void split_logits(uint4 (&s_buf)[2][kBufBytes / 16], 
                     // the same one (several in a row into one accumulator wait for each other); smallest terms first
 #pragma unroll
                     for (int m = 0; m < kMt; m += 2) {
-                        bf16x8 ah[2];
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) ah[i] = frag(w, 0, (m + i) * kKsH + s);
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int t = 0; t < 2; ++t) acc[m + i][t] = mfma(ah[i], xll[t], acc[m + i][t]);
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int t = 0; t < 2; ++t) acc[m + i][t] = mfma(ah[i], xl[t], acc[m + i][t]);
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int t = 0; t < 2; ++t) acc[m + i][t] = mfma(ah[i], xh[t], acc[m + i][t]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            TPL_CHUNK_DONE();
-            // chunk 4 + 2 layer: the LOW plane against the high and low pieces, the LOW-LOW plane against the high pieces
-            TPL_NEXT_CHUNK(5 + 2 * layer);
-            {
-                lds_byte* w = chunk_base(s_buf[buf], lane);
-#pragma unroll
-                for (int s = 0; s < kKsH; ++s) {
-                    uint4 xh[2], xl[2], unused[2];
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) split_fragment(x[2 * s][t], x[2 * s + 1][t], xh[t], xl[t], unused[t]);
-#pragma unroll
-                    for (int m = 0; m < kMt; m += 2) {
-                        bf16x8 al[2], all[2];
+                        bf16x8 ah[2], al[2], all[2];
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
-                            al[i] = frag(w, 0, (m + i) * kKsH + s);
-                            all[i] = frag(w, kPlaneH, (m + i) * kKsH + s);
+                            ah[i] = frag(w, 0, (sl * 3 + 0) * kMt + m + i);
+                            al[i] = frag(w, 0, (sl * 3 + 1) * kMt + m + i);
+                            all[i] = frag(w, 0, (sl * 3 + 2) * kMt + m + i);
                         }
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int t = 0; t < 2; ++t) acc[m + i][t] = mfma(all[i], xh[t], acc[m + i][t]);
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int t = 0; t < 2; ++t) acc[m + i][t] = mfma(al[i], xl[t], acc[m + i][t]);
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int t = 0; t < 2; ++t) acc[m + i][t] = mfma(al[i], xh[t], acc[m + i][t]);
+#define TPL_TERM(A, X)                                                                          \
+                        _Pragma("unroll") for (int i = 0; i < 2; ++i)                          \
+                            _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[m + i][t] = mfma(A[i], X[t], acc[m + i][t]);
+                        TPL_TERM(all, xh)
+                        TPL_TERM(ah, xll)
+                        TPL_TERM(al, xl)
+                        TPL_TERM(al, xh)
+                        TPL_TERM(ah, xl)
+                        TPL_TERM(ah, xh)
+#undef TPL_TERM
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                TPL_CHUNK_DONE();
             }
-            TPL_CHUNK_DONE();
         }
         // ---- the head: one output tile, all three planes in one chunk; the next pass's first chunk arrives under it
         relu(acc);
