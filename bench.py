@@ -60,6 +60,41 @@ HBM_PEAK_GBS = 8000.0                   # MI355X HBM3E peak (MI355X_MICROARCH.md
 MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3            # f32-input MFMA = the f32 vector rate (MI355X_MICROARCH.md)
 MODEL_FLOPS_PER_BOARD = 2.0 * (217 * 128 + 3 * 128 * 128 + 128 * 14)     # Model(217, 14), model/model.py:9-20: 157,440
+SIMDS, PEAK_CLOCK_GHZ = 1024, 2.4       # 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
+_VALU_ISSUE = None
+
+
+def valu_roofline(form, units_per_s):
+    """The roofline of a kernel that HBM does not bound: VECTOR-INSTRUCTION ISSUE.  A SIMD issues one wave64 vector instruction
+    per c cycles at best -- c = the kernel's instruction mix priced with the issue costs measured on gfx950 (tools/valu_mix.py,
+    tools/valu_rates.hip: 2.5 cycles for a handful of plain opcodes, 4 for the rest) -- and the chip has 1,024 SIMDs, so
+    `peak` = 1024 x 2.4 GHz / c wave-instructions a second.  `achieved` = vector instructions per unit of work (SQ_INSTS_VALU of
+    the committed counter pass of this same form, profiles/valu_issue.json, written by tools/update_valu_issue.py) x the units per
+    second measured HERE.  Like `roofline.traffic`, the per-unit count comes from the committed profile (PMC counters cannot be
+    read from inside the process) and says which."""
+    global _VALU_ISSUE
+    if _VALU_ISSUE is None:
+        try:
+            _VALU_ISSUE = json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))["forms"]
+        except (OSError, KeyError, ValueError):
+            _VALU_ISSUE = {}
+    f = _VALU_ISSUE.get(form)
+    if not f or not units_per_s:
+        return None
+    c = f["cycles_per_valu_instruction"]
+    achieved = f["valu_per_unit"] * units_per_s / 1e9
+    peak = SIMDS * PEAK_CLOCK_GHZ / c
+    out = {"bound": "valu-issue", "achieved": achieved, "peak": peak, "unit": "G wave-instructions/s", "frac": achieved / peak,
+           "valu_instructions_per_" + f["unit"].replace("-", "_"): f["valu_per_unit"], "cycles_per_valu_instruction": c,
+           "lanes_active_per_valu_instruction": f.get("lanes_active_per_valu_instruction"),
+           "in_the_profiled_run": {"frac": f["frac"], "frac_at_the_clock_held": f["frac_at_clock_held"],
+                                   "clock_GHz_held": f["clock_GHz_held"], "duration_ns": f["duration_ns_median"]},
+           "source": f"NOT counted in this run: {f['source']} (commit {f['stamp'].get('git_head')}, source digest "
+                     f"{str(f['stamp'].get('source_digest'))[:12]}), {f['kernel']} at grid {f['grid']}"}
+    if f.get("lanes_active_per_valu_instruction"):
+        # of the lane-slots the issued instructions offer, the share that did work (divergence inside a wave)
+        out["frac_of_lane_slots"] = out["frac"] * f["lanes_active_per_valu_instruction"] / 64.0
+    return out
 
 
 def numpy_port_leg(L, M, seed, cores, seconds=2.0):
@@ -352,11 +387,16 @@ def measure_shard_run(torch, T, dev, L, M, seed, total, ranks, chunk, keep=None)
     ms_graph = timed(torch, dev, replay, 8) / chunk
     ms_fused = measure_fused_rollout(torch, T, env, actions, 0, S, chunk)
     env.terminate()
+    # the multi-step kernel is not an HBM kernel (a board's 64 B cross the memory once per `chunk` steps): priced by vector issue
+    fused_leg = {"us_per_step": ms_fused * 1e3, "value_per_gpu": float(n) / (ms_fused * 1e-3),
+                 f"value_x{ranks}_if_every_rank_matches": float(n) * ranks / (ms_fused * 1e-3), "steps_per_launch": chunk,
+                 "outputs": "per-step reward f32 + done u8 written",
+                 "roofline": valu_roofline("rollout_shard_131072" if n == 131072 else "rollout_f32_u8_50", float(n) / (ms_fused * 1e-3))}
     return {"workload": f"rank 0's shard of {total} boards over {ranks} GPUs = {n} boards, {total}-entry pool, L={L} M={M}",
             "boards": n, "global_boards": total, "ranks": ranks, "unit": "env-steps/s",
             "tpl_step": leg(ms_step, launches_per_step=1),
             "capture_steps": leg(ms_graph, steps_per_graph=chunk),
-            "tpl_rollout": leg(ms_fused, steps_per_launch=chunk, outputs="per-step reward f32 + done u8 written"),
+            "tpl_rollout": fused_leg,
             "note": "measured on ONE GPU; an N-GPU run's headline is global_boards / (the slowest rank's tpl_step period)"}
 
 
@@ -424,7 +464,9 @@ def measure_config_supply(torch, T, dev, L, M, seed, keep=None):
     fw = T.forward_generate(5, 20, np.arange(games))
     dt_fw = time.perf_counter() - t0
     return {"unit": "configurations/s", "L": L, "M": M,
-            "carve_device": {"value": rate_big, "count": count, "batch_of_262144": rate_small,
+            "carve_device": {"value": rate_big, "count": count, "roofline": valu_roofline("carve_1048576", rate_big) if (L, M) == (10, 40) else None,
+                             "roofline_batch_of_262144": valu_roofline("carve_262144", rate_small) if (L, M) == (10, 40) else None,
+                             "batch_of_262144": rate_small,
                              "rate_ratio_2^20_over_2^18": rate_big / rate_small, "batch_of_4194304": rate_huge,
                              "L15_M40_batch_of_262144": rate_ref},
             "carve_host": {"value": host_count / dt_host, "count": host_count, "threads": T._lib.cpu_budget(),
@@ -510,7 +552,7 @@ def measure_actor_loop(torch, T, dev, L, M, boards, seed, keep=None):
     env.load_configs(rows, pieces)
     env.reset()
     out = {"boards": boards, "unit": "env-steps/s", "policy": "MLP 217-128-128-128-128-14, greedy, random init",
-           "arithmetic": {"value": "bf16 operands, f32 accumulation (megakernel)", "fused_mfma_kernel": "bf16 operands, f32 accumulation",
+           "arithmetic": {"value": "float32 accuracy on the bf16 pipe (split_megakernel)", "fused_mfma_kernel": "bf16 operands, f32 accumulation",
                           "fused_f32_kernel": "float32 operands and accumulation: the reference's nn.Linear width (model/model.py:9-20)",
                           "f32_megakernel": "float32 operands and accumulation (v_mfma_f32_16x16x4_f32), T steps per launch",
                           "split_megakernel": "as fused_split_kernel, T steps per launch",
@@ -542,7 +584,6 @@ def measure_actor_loop(torch, T, dev, L, M, boards, seed, keep=None):
                          # the model's FLOPs over the WHOLE iteration (policy, exploration draw, move, trajectory stores): what
                          # the matrix pipe delivers when the per-launch costs (weights into LDS, launch gap) are paid once per T
                          "model_flops_over_whole_step_frac_of_bf16_peak": MODEL_FLOPS_PER_BOARD * boards / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
-    out["value"] = out["megakernel"]["value"]
     # the same loop at the reference's arithmetic width: float32 operands and accumulation, T iterations per launch
     image32m = T.actor.policy_image(T.PolicyMLP(), dev, f32=True)
     iters32 = 10
@@ -557,6 +598,15 @@ def measure_actor_loop(torch, T, dev, L, M, boards, seed, keep=None):
     ms = timed(torch, dev, lambda: env.actor_rollout(image_sm, iters32), 3) / iters32
     out["split_megakernel"] = {"value": boards / (ms * 1e-3), "ms_per_step": ms, "steps_per_launch": iters32,
                                "outputs": "per-step action u8 + reward f32 + done u8 written"}
+    # BASELINE configs[4] is "driven by model/model.py policy": a float32 nn.Linear stack (model/model.py:9-20).  The figure of
+    # this block is therefore the fastest form at FLOAT32 ACCURACY -- the split megakernel (every product from three bf16 pieces
+    # per operand, float32 accumulation; within 2e-5 (1 + max|ref|) of a float64 evaluation, the float32 kernel's own tolerance:
+    # tests/test_policy_kernel.py) -- and the bf16 megakernel a named side key with ITS tolerance
+    out["value"] = out["split_megakernel"]["value"]
+    out["value_is"] = "split_megakernel: float32-accuracy policy (|logit - float64 ref| <= 2e-5 (1 + max|ref|)), T steps per launch"
+    out["bf16_megakernel"] = dict(out["megakernel"], tolerance="|logit - float64 ref| <= 2e-2 (1 + max|ref|): bf16 operands, "
+                                  "f32 accumulation -- NOT the reference's arithmetic width; actions agree with the float64 "
+                                  "policy wherever its margin exceeds twice that")
     # the policy kernel alone against the dense bf16 MFMA peak: USEFUL FLOPs per board -- 2 x (217 x 128 + 3 x 128 x 128 +
     # 128 x 14) = 157,440, the model's own (the kernel issues 159,744: K padded to 224, the head as a 16-row tile)
     # -- over its own duration
@@ -1006,13 +1056,17 @@ def main():
             ms = {k: side.max_over_ranks(v) for k, v in sorted(fused.items())}
             fused = {"value": float(total) / (ms["f32_u8"] * 1e-3), "unit": "env-steps/s", "steps_per_launch": args.chunk,
                      "ms_per_step": ms["f32_u8"], "outputs": "per-step reward f32 + done u8 written", "kernel": "rollout_kernel<auto_reset>",
+                     # priced on rank 0's boards over the slowest rank's time, like the headline's roofline
+                     "roofline": valu_roofline("rollout_f32_u8_50", float(n) / (ms["f32_u8"] * 1e-3)),
                      "compact_trajectory": {"value": float(total) / (ms["compact"] * 1e-3), "ms_per_step": ms["compact"],
+                                            "roofline": valu_roofline("rollout_compact_50", float(n) / (ms["compact"] * 1e-3)),
                                             "steps_per_launch": args.chunk,
                                             "outputs": "one byte per board-step (rows cleared, how the move ended, reset, frozen), "
                                                        "a dword per board every fourth step; tpl_decode_trajectory -> reward f32, done u8"},
                      "at_200_steps_per_launch": {"compact_trajectory": float(total) / (ms["compact_200"] * 1e-3),
                                                  "reward_f32_and_done_u8": float(total) / (ms["f32_u8_200"] * 1e-3)},
                      "device_random_policy": {"value": float(total) / (ms["device_random"] * 1e-3), "ms_per_step": ms["device_random"],
+                                              "roofline": valu_roofline("rollout_random_100", float(n) / (ms["device_random"] * 1e-3)),
                                               "steps_per_launch": 100, "outputs": "reward sums and episode counts only"}}
         more["fused_rollout"] = fused
     if args.carved_pool > 0 and world == 1:

@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--steps-per-launch", type=int, default=100)
     ap.add_argument("--launches", type=int, default=12)
     ap.add_argument("--outputs", type=int, default=0)
+    ap.add_argument("--random", action="store_true", help="the uniform random policy drawn on the device (tpl_rollout_random), no outputs")
     args = ap.parse_args()
     import torch
     import tetris_piclim as T
@@ -36,7 +37,9 @@ def main():
     ds = torch.empty((K, n), dtype=torch.uint8, device=env.device)
     import ctypes
     for _ in range(args.launches):
-        if args.outputs == 2:
+        if args.random:
+            env.rollout_random(K, seed=0)
+        elif args.outputs == 2:
             env.rollout_trajectory(actions, out=traj)
         elif args.outputs:
             T._lib.check(env._lib.tpl_rollout(env._h, ctypes.c_void_p(actions.data_ptr()), actions.stride(0), K,
@@ -46,7 +49,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (args.launches * K)
-    print(f"rollout {K} steps/launch, outputs={args.outputs}: {us:.3f} us/step = {n / us / 1e3:.1f} G env-steps/s")
+    print(f"rollout {K} steps/launch, outputs={'device-drawn policy' if args.random else args.outputs}: {us:.3f} us/step = {n / us / 1e3:.1f} G env-steps/s")
     env.terminate()
 
 
