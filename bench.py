@@ -475,30 +475,39 @@ def measure_config_supply(torch, T, dev, L, M, seed, keep=None):
                                               "winnable_fraction": float(fw["winnable"].mean())}}
 
 
-def measure_live_supply(torch, T, env, actions, reward, done, seed, count=65536, min_swaps=3, min_steps=4000, max_steps=40000, **where):
+def measure_live_supply(torch, T, env, actions, reward, done, seed, count=0, min_swaps=3, min_steps=4000, max_steps=40000,
+                        step_fn=None, **where):
     """The replenished supply under load (game/tetris.py:195-211, 473-488: producers feed the reset queue while games
     run): PoolRefresher carves `count` configurations at a time on a side stream while the main stream steps, and each
     finished batch becomes the current pool (boards in mid-episode finish on the buffer they started from).  Steady state:
     the timed region starts at the FIRST swap and runs until `min_swaps` more batches have been swapped in (and at least
-    `min_steps` steps); the supply rate is those batches over the wall time between the first and the last swap.  `where` = PoolRefresher's waves / reserved_cus / low_priority."""
-    n, dev, S = env.num_envs, env.device, actions.shape[0]
+    `min_steps` steps); the supply rate is those batches over the wall time between the first and the last swap.  `where` = PoolRefresher's waves / reserved_cus / low_priority.
+    count = 0: PoolRefresher's default, pool-sized batches (one configuration per board).  `step_fn(t)` replaces the random-action
+    step (the policy-driven loop of measure_actor_loop)."""
+    n, dev = env.num_envs, env.device
+    S = actions.shape[0] if actions is not None else 1
+    if step_fn is None:
+        def step_fn(t):
+            env.step_into(actions[t % S], reward, done)
     rows, pieces = T.generate_configs(env.L, env.M, 4096, seed=seed)          # something carved to start from
     if env.n_configs:
         env.reset()                                                           # no board left on the buffer about to be replaced
     env.load_configs(rows, pieces)
     env.reset()
     for t in range(50):
-        env.step_into(actions[t % S], reward, done)
+        step_fn(t)
     torch.cuda.synchronize(dev)
-    ms_alone = timed(torch, dev, lambda: env.step_into(actions[0], reward, done), 500)
+    alone = iter(range(50, 10 ** 9))
+    ms_alone = timed(torch, dev, lambda: step_fn(next(alone)), 500 if actions is not None else 100)
     feeder = T.PoolRefresher(env, count, seed=seed, first=4096, **where)
+    count = feeder.count
     try:
         # the supplier's first batch is its start-up (the generator's code is loaded, its work memory and the batch's tensors are
         # allocated -- a hipMalloc is a device synchronisation): stepped through untimed, the timed region begins at the first swap
         lead = 0
         while lead < max_steps and not feeder.poll():
             for t in range(32):
-                env.step_into(actions[(lead + t) % S], reward, done)
+                step_fn(lead + t)
             lead += 32
         episodes0 = env.stats()["episodes"]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -507,7 +516,7 @@ def measure_live_supply(torch, T, env, actions, reward, done, seed, count=65536,
         steps = 0
         while steps < max_steps and (steps < min_steps or len(swap_times) < min_swaps + 1):
             for t in range(32):
-                env.step_into(actions[(lead + steps + t) % S], reward, done)
+                step_fn(lead + steps + t)
             steps += 32
             if feeder.poll():
                 swap_times.append(time.perf_counter())       # the host loop runs a bounded queue ahead of the GPU: wall time tracks it
@@ -515,11 +524,12 @@ def measure_live_supply(torch, T, env, actions, reward, done, seed, count=65536,
         torch.cuda.synchronize(dev)
         ms = e0.elapsed_time(e1) / steps
         resets_per_s = (env.stats()["episodes"] - episodes0) / (ms * 1e-3 * steps)
+        waves = feeder.waves
     finally:
         feeder.close()                                        # whatever happened, no generator keeps running beside the next figure
     fresh_per_s = (len(swap_times) - 1) * count / (swap_times[-1] - swap_times[0]) if len(swap_times) >= 2 else None
     return {"unit": "env-steps/s", "value": float(n) / (ms * 1e-3), "ms_per_step": ms, "ms_per_step_without_refresher": ms_alone,
-            "slowdown": ms / ms_alone, "configurations_per_batch": count, "pool_swaps": len(swap_times) - 1, "steps": steps,
+            "slowdown": ms / ms_alone, "configurations_per_batch": count, "generator_waves": waves, "pool_swaps": len(swap_times) - 1, "steps": steps,
             "steps_before_the_first_swap_untimed": lead,
             "configurations_supplied_per_s": fresh_per_s, "resets_per_s": resets_per_s,
             # the reference's reset() blocks on queue.get() (game/tetris.py:445-447): every episode a fresh game, factor 1
@@ -635,6 +645,18 @@ def measure_actor_loop(torch, T, dev, L, M, boards, seed, keep=None):
                                   "roofline": {"bound": "mfma", "achieved": issued, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                                "frac": issued / MFMA_BF16_PEAK_TFLOPS,
                                                "note": "bf16 FLOPs issued (3-6 per float32-grade product), not model FLOPs"}}
+    # the replenished supply under the POLICY-driven loop (round-4 review: episodes last 2-3 times as long under a policy as
+    # under random play, so the reuse factor a LEARNER sees is this one): the bf16 policy kernel + tpl_step per step, with
+    # PoolRefresher's defaults beside them (pool-sized batches, the footprint `target_slowdown` picks)
+    torch.manual_seed(0)
+    actor = T.Actor(env, T.PolicyMLP(), dtype=torch.bfloat16, use_graph=False, fused=True)
+    live = measure_live_supply(torch, T, env, None, None, None, seed, min_swaps=2, min_steps=1000, max_steps=12000,
+                               step_fn=lambda t: actor.step())
+    out["live_supply"] = dict({k: live[k] for k in ("value", "ms_per_step", "ms_per_step_without_refresher", "slowdown",
+                                                    "configurations_per_batch", "generator_waves", "pool_swaps", "steps",
+                                                    "configurations_supplied_per_s", "resets_per_s", "pool_reuse_factor")},
+                              loop="bf16 policy kernel + tpl_step per step (two launches), greedy, random-init weights; carved pool",
+                              note="the reference's reset() hands every episode a fresh game (game/tetris.py:445-447): factor 1")
     env.terminate()
     return out
 
@@ -1078,13 +1100,16 @@ def main():
             # the same run by the generator's footprint: how many persistent waves share its queue, and -- the form the
             # round-2 review asked for -- confined to 32 compute units by a CU-masked stream (which turns out to be the
             # expensive way: profiles/r03_live_supply)
-            live["generator"] = "PoolRefresher defaults: a plain side stream, waves = count / 256"
-            keep = ("ms_per_step", "slowdown", "pool_swaps", "steps", "configurations_per_batch", "configurations_supplied_per_s",
-                    "pool_reuse_factor")
+            live["generator"] = ("PoolRefresher defaults: a plain side stream, pool-sized batches (one configuration per board), "
+                                 "the footprint its target_slowdown = 1.13 picks from the measured table")
+            keep = ("ms_per_step", "slowdown", "pool_swaps", "steps", "configurations_per_batch", "generator_waves",
+                    "configurations_supplied_per_s", "pool_reuse_factor")
             live["by_generator_footprint"] = [
                 dict(generator=name, **{k: v for k, v in measure_live_supply(torch, T, env, actions, reward, done, args.seed, **kw).items() if k in keep})
-                for name, kw in (("1024 waves", dict(waves=1024)), ("1024 waves, batches of 2^20 (a pool's worth)", dict(waves=1024, count=1 << 20)),
-                                 ("64 waves", dict(waves=64)), ("256 waves on a 32-CU stream", dict(waves=256, reserved_cus=32)))]
+                for name, kw in (("256 waves, batches of 65,536 (the default through round 4)", dict(waves=256, count=65536)),
+                                 ("1024 waves, pool-sized batches", dict(waves=1024)), ("512 waves, pool-sized batches", dict(waves=512)),
+                                 ("64 waves, batches of 65,536", dict(waves=64, count=65536)),
+                                 ("256 waves on a 32-CU stream, batches of 65,536", dict(waves=256, count=65536, reserved_cus=32)))]
             return live
         more["live_supply_run"] = side.run("live_supply_run", live_figures)
     try:

@@ -159,11 +159,29 @@ class PoolRefresher:
             feeder.poll()            # cheap: an event query, no wait on any stream; swaps at most once per M + 1 steps
     """
 
-    def __init__(self, env, count: int, seed: int = 0, first: int = 0, waves: int = 0, reserved_cus: int = 0,
+    # What a footprint costs a 2^20-board step loop and what it supplies, measured (profiles/r05_live_supply/
+    # footprint_grid_waves_x_batch.log: pool-sized batches; L = 10, M = 40): waves -> (step time with the generator beside it /
+    # alone, fresh configurations a second).  The reference hands every reset a FRESH game (reset() blocks on queue.get(),
+    # game/tetris.py:445-447); here a pool is re-dealt until the next batch replaces it, resets / fresh = the reuse factor.
+    FOOTPRINTS = ((64, 1.04, 0.8e6), (256, 1.07, 5.8e6), (512, 1.095, 10.3e6), (768, 1.126, 14.1e6), (1024, 1.155, 16.7e6))
+
+    @classmethod
+    def waves_for(cls, target_slowdown: float) -> int:
+        """The largest measured footprint whose cost stays within `target_slowdown` (at least the smallest)."""
+        fits = [w for w, cost, _ in cls.FOOTPRINTS if cost <= target_slowdown]
+        return max(fits) if fits else cls.FOOTPRINTS[0][0]
+
+    def __init__(self, env, count: int = 0, seed: int = 0, first: int = 0, waves: int = 0, reserved_cus: int = 0,
                  low_priority: bool = False, cutoff: int = 0, strict: bool = False, max_capped_batches: int = 3,
-                 forward_seeds=None, forward_lead: bool = True):
-        """waves: how many persistent 64-lane waves share the generator's queue (0 = count / 256): its footprint beside
-        the stepping environment.  What a footprint costs and supplies is in bench.py's `live_supply_run`
+                 forward_seeds=None, forward_lead: bool = True, target_slowdown: float = 1.13):
+        """count: configurations per batch = the size of the pool the batch becomes (0 = as many as the environment has
+        boards: with fewer, the generator idles between swaps -- a swap has to wait M + 1 steps for the boards still on the
+        other buffer -- and the pool is re-dealt more often for the same cost).
+        waves: how many persistent 64-lane waves share the generator's queue: its footprint beside the stepping environment.
+        0 = chosen by `target_slowdown` from the measured table above (the default 1.13 picks 768 waves: 1.13 x the step
+        time alone for 14 M fresh configurations a second, a pool reuse factor of 330 at 2^20 boards under random play;
+        through round 4 the default was count / 256 waves on batches of 65,536: 1.02-1.10 x, 2 M/s, a factor of 2,300).
+        What a footprint costs and supplies is in bench.py's `live_supply_run`
         (`by_generator_footprint`; profiles/NOTES.md has the history).  (The step kernel raises its waves'
         issue priority above the generator's; without that any generator wave on a SIMD cost the whole launch 18-29 %.)
         reserved_cus > 0 runs the generator on a CU-masked stream of that many compute units (`tpl_stream_create`),
@@ -174,9 +192,10 @@ class PoolRefresher:
         (L, M, cutoff), and after `max_capped_batches` such batches IN A ROW the refresher stops (`stopped`; poll() returns
         False from then on) instead of spending the generator's worst case beside the training loop for ever."""
         import torch
-        self.env, self.count, self.seed, self.next_first = env, int(count), int(seed), int(first)
+        self.env, self.count, self.seed, self.next_first = env, int(count) or int(env.num_envs), int(seed), int(first)
         self.cutoff = int(cutoff)     # the restart rule's iteration cut-off (0 = by L), as generate_configs / carved_configs take it
-        self.waves = int(waves) or max(1, self.count // 256)       # beside a stepping environment: a quarter of the lanes a lone generator takes
+        self.target_slowdown = float(target_slowdown)
+        self.waves = int(waves) or self.waves_for(self.target_slowdown)   # (the launch never has more lanes than configurations)
         self.strict, self.max_capped_batches = bool(strict), int(max_capped_batches)
         self._masked = bool(reserved_cus or low_priority)
         self.side = side_stream(env, reserved_cus, low_priority) if self._masked else concurrent_stream(env)

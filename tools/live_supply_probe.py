@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--count", type=int, default=65536)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--only", default="", help="comma-separated subset of the case keys")
+    ap.add_argument("--grid", default="", help="instead of the named cases: WAVES,..xLOG2COUNT,..  e.g. 256,512,1024x18,19,20")
     args = ap.parse_args()
     import torch
     import tetris_piclim as T
@@ -41,6 +42,10 @@ def main():
     cases += [("1M1024", "1024 waves, batches of 2^20", dict(waves=1024, count=1 << 20), 2),
               ("1M2048", "2048 waves, batches of 2^20", dict(waves=2048, count=1 << 20), 2),
               ("1M4096", "4096 waves, batches of 2^20", dict(waves=4096, count=1 << 20), 2)]
+    if args.grid:
+        waves, counts = args.grid.split("x")
+        cases = [(f"w{w}c{c}", f"{w} waves, batches of 2^{c}", dict(waves=int(w), count=1 << int(c)), 2)
+                 for c in counts.split(",") for w in waves.split(",")]
     for r in range(args.rounds):
         for key, name, kw, bpl in cases:
             if args.only and key not in args.only.split(","):
