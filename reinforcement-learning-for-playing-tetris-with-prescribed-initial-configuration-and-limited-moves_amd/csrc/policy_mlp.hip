@@ -21,9 +21,12 @@
 // (The same kernels were also built on v_mfma_f32_32x32x16_bf16; both shapes take 33-34 us per 262,144 boards.
 // This one is kept because the 14-row head is one 16-row tile and the file has a single geometry.)
 //
-// Geometry of a wave: 32 boards = two N tiles of 16.  Lane l = (c = l & 15, g = l >> 4) owns board (t = g >> 1, c);
-// lanes g and g ^ 1 carry identical copies of it.  For the matrix products every lane needs the features of BOTH
-// boards of its column c (one per N tile); the other one comes from lane l ^ 32 with eight cross-lane moves.
+// Geometry of a wave (this file; kNt = 4): 64 boards = FOUR N tiles of 16, one board per lane.  Lane l = (c = l & 15,
+// g = l >> 4) owns board (t = g, c) -- board 16 t + c of the wave's tile of 64.  For the matrix products every lane needs the
+// features of all four boards of its column c (one per N tile); the other three come from lanes 16 t + c with cross-lane
+// moves (column_features), and of the four tiles' logits the lane keeps its own board's action (own_action).  Every A
+// fragment and bias read feeds four MFMAs.  (The float32 and split kernels -- policy_f32.hip, policy_split.hip -- keep the
+// earlier geometry: 32 boards = two N tiles per wave, lanes g and g ^ 1 holding copies of board (t = g >> 1, c).)
 //
 // Fragment maps (cdna_hip_programming.md section 3): A: lane holds A[row c][k = 8g + j]; B: B[k = 8g + j][col c];
 // C/D: D[row = 4g + reg][col c], reg 0..3.  A layer's output tile m (16 rows) therefore leaves rows 16m + 4g + reg

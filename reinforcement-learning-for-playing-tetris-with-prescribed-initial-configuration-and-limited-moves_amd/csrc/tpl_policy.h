@@ -1,7 +1,10 @@
-// tpl_policy.h -- device pieces shared by the two policy kernels (policy_mlp.hip: bf16 operands; policy_f32.hip: f32
-// operands): the board's features as bits, the cross-lane fetch of the partner board, the argmax of the 14 outputs.
-// Geometry of a wave (both kernels): 32 boards = two N tiles of 16.  Lane l = (c = l & 15, g = l >> 4) owns board
-// (t = g >> 1, c); lanes g and g ^ 1 carry identical copies of it.
+// tpl_policy.h -- device pieces shared by the three policy kernels (policy_mlp.hip: bf16 operands; policy_f32.hip: f32
+// operands; policy_split.hip: three bf16 pieces per number): the board's features as bits, the cross-lane fetch of the partner
+// board, the argmax of the 14 outputs.
+// Geometry of a wave: the float32 and split kernels run 32 boards = two N tiles of 16 -- lane l = (c = l & 15, g = l >> 4)
+// owns board (t = g >> 1, c), lanes g and g ^ 1 carry identical copies of it (both_features below fetches the partner tile's
+// board from lane l ^ 32).  The bf16 kernel runs 64 boards = four N tiles, one board per lane (t = g; its own column_features /
+// own_action are in policy_mlp.hip).  pick_action serves both: all four lanes of a column return the action of the tile asked for.
 #pragma once
 
 #include "tpl_internal.h"
