@@ -36,6 +36,17 @@ int main() {
         int rc = tpl_forward_generate(5, M, 4, 1000, seeds.data(), n, 4, rows.data(), seq.data(), win.data(), failed.data(), sol.data(), stack.data(), len.data());
         if (rc) { printf("forward M=%d rc=%d\n", M, rc); return 1; }
     }
+    {   // the restart rule's doubled cut-offs and the host pilot's threaded branch: a tight move budget carves, one that does not
+        // finish is refused after the pilot (attempts 12-23 on parallel threads), one below the fewest pieces outright
+        const int64_t n = 8;
+        std::vector<uint16_t> rows(n * 20); std::vector<uint8_t> pieces(n * 41); std::vector<int32_t> len(n);
+        int rc = tpl_generate_configs(10, 8, 3, 0, n, 4, 0, rows.data(), pieces.data(), nullptr, len.data());
+        if (rc) { printf("tight budget (10, 8) rc=%d\n", rc); return 1; }
+        for (int64_t k = 0; k < n; ++k) if (len[k] < 5 || len[k] > 8) { printf("tight budget: solution of %d pieces\n", len[k]); return 1; }
+        if (tpl_generate_configs(10, 7, 3, 0, n, 4, 0, rows.data(), pieces.data(), nullptr, nullptr) != TPL_ERR_STATE) { puts("(10, 7) was not refused by the pilot"); return 1; }
+        if (tpl_generate_configs(10, 4, 3, 0, n, 4, 0, rows.data(), pieces.data(), nullptr, nullptr) != TPL_ERR_ARG) { puts("(10, 4) was not refused outright"); return 1; }
+        if (tpl_generate_configs(10, 40, 3, 0, n, 4, 1, rows.data(), pieces.data(), nullptr, nullptr) != TPL_ERR_STATE) { puts("cutoff 1 was not refused"); return 1; }
+    }
     puts("sanitizer run ok");
     return 0;
 }
