@@ -181,8 +181,11 @@ class SideFigures:
     `inject` names figures made to fail on purpose ("name" or "name@rank", comma separated; TPL_BENCH_INJECT_FAILURE): the
     tests' way to see all of the above happen."""
 
-    def __init__(self, world=1, rank=0, dist=None, ctl=None, budget_s=None, inject="", clock=time.perf_counter):
+    def __init__(self, world=1, rank=0, dist=None, ctl=None, budget_s=None, inject="", clock=time.perf_counter, gather=None,
+                 distributed=None):
         self.world, self.rank, self.dist, self.ctl = world, rank, dist, ctl
+        self.distributed = world > 1 if distributed is None else bool(distributed)   # (a forced one-rank group counts)
+        self._gather_fn = gather      # main() hands in the device-tensor gather of the job's own group when no gloo group could be made
         self.budget_s, self.clock, self.t0 = budget_s, clock, clock()
         self.inject = [x.strip() for x in (inject or "").split(",") if x.strip()]
         self.log = []                 # (name, seconds, outcome) in the order run
@@ -191,7 +194,9 @@ class SideFigures:
 
     # -- host-side agreement between the ranks (gloo)
     def _gather(self, value):
-        if self.world == 1:
+        if self._gather_fn is not None:
+            return self._gather_fn(float(value))
+        if not self.distributed:
             return [float(value)]
         import torch
         t = torch.tensor([float(value)], dtype=torch.float64)
@@ -209,7 +214,8 @@ class SideFigures:
         over = self.budget_s is not None and self.clock() - self.t0 > self.budget_s
         if any(self._gather(1.0 if over else 0.0)):
             self.log.append((name, 0.0, "skipped"))
-            return {"skipped": f"the side figures had used their {self.budget_s:.0f} s (--side-budget) when this one's turn came"}
+            return {"skipped": "the side figures had used their budget (--side-budget"
+                               + (f" = {self.budget_s:.0f} s" if self.budget_s is not None else "") + ") on some rank when this one's turn came"}
         self.running = name
         t0 = self.clock()
         result = error = None
@@ -224,7 +230,7 @@ class SideFigures:
         self.log.append((name, self.clock() - t0, "ok" if not failed else "failed"))
         if failed:
             out = {"error": error or f"rank(s) {failed} failed; this rank's own measurement was dropped with theirs"}
-            if self.world > 1:
+            if self.distributed:
                 out["failed_ranks"] = failed
             return out
         return result
@@ -797,41 +803,59 @@ def main():
     if os.environ.get("TPL_BENCH_ONE_GPU") == "1":
         local = 0
     ctl = None
-    if world > 1:
+    # TPL_BENCH_FORCE_DIST=1: a ONE-rank run goes through the process group as an N-rank run does (RCCL all-reduce / all-gather on
+    # device tensors, the gloo control group beside an "nccl" default group): the multi-rank plumbing on real RCCL, on a one-GPU box
+    dist_on = world > 1 or os.environ.get("TPL_BENCH_FORCE_DIST") == "1"
+    ctl_note = None
+    if dist_on:
         import datetime
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-        # the ranks' agreements around the side figures travel over a gloo group of HOST tensors (SideFigures)
-        ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=max(600.0, 2 * args.side_timeout)))
+        # the ranks' agreements around the side figures travel over a gloo group of HOST tensors (SideFigures); if that group
+        # cannot be made (it is the one piece of the N > 1 path no one-GPU box can try with more than one RCCL rank), the
+        # agreements fall back to the job's own group and device tensors -- the headline must not depend on it
+        try:
+            ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=max(600.0, 2 * args.side_timeout)))
+            probe = torch.zeros(1, dtype=torch.float64)
+            dist.all_reduce(probe, group=ctl)
+            ctl_note = "gloo group of host tensors"
+        except Exception as e:        # noqa: BLE001
+            ctl, ctl_note = None, f"the job's own group, device tensors (no gloo control group: {type(e).__name__}: {e})"[:300]
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    ranks_seen = dist.get_world_size() if world > 1 else 1
-    backend_seen = dist.get_backend() if world > 1 else None      # what the process group IS, not what was asked for
+    ranks_seen = dist.get_world_size() if dist_on else 1
+    backend_seen = dist.get_backend() if dist_on else None        # what the process group IS, not what was asked for
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
 
     def max_over_ranks(x):
         t = torch.tensor([x], dtype=torch.float64, device=dev)
-        if world > 1:
+        if dist_on:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def every_rank(x):
         t = torch.tensor([x], dtype=torch.float64, device=dev)
-        if world == 1:
+        if not dist_on:
             return [float(x)]
         got = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(got, t)
         return [float(g.item()) for g in got]
 
-    side = SideFigures(world, rank, dist, ctl, budget_s=args.side_budget, inject=os.environ.get("TPL_BENCH_INJECT_FAILURE", ""))
+    side = SideFigures(world, rank, dist, ctl, budget_s=args.side_budget, inject=os.environ.get("TPL_BENCH_INJECT_FAILURE", ""),
+                       gather=every_rank if (dist_on and ctl is None) else None, distributed=dist_on)
 
     # BASELINE configs[2] (N = 1) / configs[3] (N > 1): ONE batch of `total` boards, sharded by global board index
     total, L, M, K, W = args.boards, args.L, args.M, args.steps, args.warmup
@@ -1013,7 +1037,7 @@ def main():
             "actor_loop": figures["actor_loop"],
             "mean_episodic_return": mean_return if episodes else None,
             "episodes": episodes,
-            "side_figures": dict(side.summary(), guard="each side figure runs under a guard (an exception becomes {\"error\": ...} under "
+            "side_figures": dict(side.summary(), agreements_over=ctl_note, guard="each side figure runs under a guard (an exception becomes {\"error\": ...} under "
                                  "its key; at N > 1 the ranks agree over a gloo group before and after each); the timed region is not guarded"),
         }
         if abandoned is not None:
@@ -1131,7 +1155,7 @@ def main():
             more["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     side.disarm()
     emit()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

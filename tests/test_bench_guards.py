@@ -47,6 +47,19 @@ def test_figures_past_the_budget_are_skipped_not_started():
     assert "skipped" in got and not started and side.summary()["skipped"] == ["second"]
 
 
+def test_agreements_fall_back_to_a_gather_of_the_jobs_own_group():
+    """When no gloo control group can be made, main() hands SideFigures the device-tensor all-gather of the job's own process
+    group; here a stand-in that reports a second rank as failed (and as over budget)."""
+    bench = _bench()
+    other = iter([0.0, 1.0, 1.0])                          # the other rank: within budget, then failed; then out of budget
+    side = bench.SideFigures(world=2, rank=0, gather=lambda v: [v, next(other)], distributed=True)
+    got = side.run("fused_rollout", lambda: {"ms": 1.0})
+    assert got["failed_ranks"] == [1] and "rank(s) [1] failed" in got["error"]
+    assert "skipped" in side.run("carved_pool_run", lambda: {"ms": 1.0})
+    side = bench.SideFigures(world=2, rank=0, gather=lambda v: [v, 0.0], distributed=True)
+    assert side.run("fused_rollout", lambda: {"ms": 1.0}) == {"ms": 1.0} and side.max_over_ranks(3.0) == 3.0
+
+
 def _rank(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

@@ -155,6 +155,30 @@ def test_bench_headline_survives_failing_side_figures_on_one_and_on_two_ranks():
     assert two["weak_scaling_job"]["value"] > 0 and two["side_figures"]["failed"] == ["fused_rollout"]
 
 
+@pytest.mark.gpu
+def test_bench_one_rank_through_rccl_and_the_gloo_control_group():
+    """The multi-rank plumbing on REAL RCCL, as far as a one-GPU box allows: TPL_BENCH_FORCE_DIST=1 makes a one-rank run initialise
+    the "nccl" process group (bound to its device), create the gloo control group beside it, and send every collective of the N > 1
+    path -- barriers, the all-reduce of the return counters, the all-gather of the ranks' times, SideFigures' agreements -- through
+    them.  (Two RCCL ranks cannot share one GPU, so this is the only way the nccl + gloo combination runs before an 8-GPU node
+    does.)  The line must be the plain one-GPU line's job."""
+    env = dict(os.environ, TPL_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TPL_BENCH_BACKEND", "TPL_BENCH_ONE_GPU"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--boards", "65536",
+           "--sustained", "100", "--actor-boards", "0", "--carved-pool", "0", "--no-config1", "--no-out-of-cache", "--shard-ranks", "0",
+           "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["backend"] == "nccl" and out["ranks_seen"] == 1 and out["n_gpus"] == 1
+    assert out["side_figures"]["agreements_over"] == "gloo group of host tensors" and out["side_figures"]["failed"] == []
+    assert out["fused_rollout"]["value"] > 0 and out["roofline"]["sustained"]["launches"] == 100
+    plain = _bench(1, ["--no-cpu-baseline", "--shard-ranks", "0"])
+    for k in ("episodes", "mean_episodic_return"):
+        assert out[k] == plain[k], k
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True,
