@@ -658,11 +658,19 @@ def measure_actor_loop(torch, T, dev, L, M, boards, seed, keep=None):
     actor = T.Actor(env, T.PolicyMLP(), dtype=torch.bfloat16, use_graph=False, fused=True)
     live = measure_live_supply(torch, T, env, None, None, None, seed, min_swaps=2, min_steps=1000, max_steps=12000,
                                step_fn=lambda t: actor.step())
-    out["live_supply"] = dict({k: live[k] for k in ("value", "ms_per_step", "ms_per_step_without_refresher", "slowdown",
-                                                    "configurations_per_batch", "generator_waves", "pool_swaps", "steps",
-                                                    "configurations_supplied_per_s", "resets_per_s", "pool_reuse_factor")},
+    keep = ("value", "ms_per_step", "ms_per_step_without_refresher", "slowdown", "configurations_per_batch", "generator_waves",
+            "pool_swaps", "steps", "configurations_supplied_per_s", "resets_per_s", "pool_reuse_factor")
+    out["live_supply"] = dict({k: live[k] for k in keep},
                               loop="bf16 policy kernel + tpl_step per step (two launches), greedy, random-init weights; carved pool",
                               note="the reference's reset() hands every episode a fresh game (game/tetris.py:445-447): factor 1")
+    # ... and at the reference's arithmetic width: the split policy kernel (float32 accuracy) + tpl_step per step -- a slower loop
+    # finishes fewer episodes a second beside the same generator, so its pool is re-dealt the fewest times
+    torch.manual_seed(0)
+    actor_s = T.Actor(env, T.PolicyMLP(), dtype=torch.float32, use_graph=False, fused=True, split=True)
+    live_s = measure_live_supply(torch, T, env, None, None, None, seed, min_swaps=2, min_steps=300, max_steps=4000,
+                                 step_fn=lambda t: actor_s.step())
+    out["live_supply"]["float32_accuracy_loop"] = dict({k: live_s[k] for k in keep},
+                                                       loop="split policy kernel + tpl_step per step (two launches)")
     env.terminate()
     return out
 
