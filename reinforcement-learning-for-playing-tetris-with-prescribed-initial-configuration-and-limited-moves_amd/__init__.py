@@ -11,7 +11,7 @@ from ._lib import (LIB_PATH, SYMBOLS, TplError, build_library, carve, forward_ge
                    shape_info)
 
 __all__ = ["BatchedTetris", "Tetris", "Snapshot", "OBS_DIM", "NUM_ACTIONS", "RUNNING", "WON", "LOST", "TplError",
-           "RandomPieceGenerator", "get_tetromino", "piece_translations", "carve", "build_library", "shape_info", "generate_configs", "forward_generate", "pack_policy", "LIB_PATH", "SYMBOLS"]
+           "RandomPieceGenerator", "get_tetromino", "piece_translations", "translate", "carve", "build_library", "shape_info", "generate_configs", "forward_generate", "pack_policy", "LIB_PATH", "SYMBOLS"]
 
 
 def __getattr__(name):
@@ -24,7 +24,7 @@ def __getattr__(name):
         return getattr(importlib.import_module(__name__ + ".pool"), name)
     if name in ("sharding", "actor", "pool"):
         return importlib.import_module(__name__ + "." + name)
-    if name in ("RandomPieceGenerator", "get_tetromino", "piece_translations"):
+    if name in ("RandomPieceGenerator", "get_tetromino", "piece_translations", "translate"):
         return getattr(importlib.import_module(__name__ + ".pieces"), name)
     if name in ("Actor", "PolicyMLP"):
         return getattr(importlib.import_module(__name__ + ".actor"), name)

@@ -25,6 +25,22 @@ def get_tetromino(piece: int, rotations: int):
     return mask, tuple(int(t) for t in topo)
 
 
+def translate(games, rng=None) -> List[Tuple["np.ndarray", List[int]]]:
+    """The reference's `translate(batch)` (game/tetris.py:19-20): the winnable games of the forward generator + solver as the
+    `(board, pieces)` pairs its reset queue holds -- the board as a 20x10 bool array, the pieces as ONE random piece id
+    (`random.randint(0, 6)`) followed by the game's sequence, M + 1 ids.  `games` is what `forward_generate()` returns (a dict
+    of arrays over all seeds; only the winnable ones are translated, as `generate_batch` keeps only those).  The batched form
+    of the same thing, on the device, is `pool.ForwardGames.translate`."""
+    import numpy as np
+    rng = rng if rng is not None else random
+    out = []
+    for k in np.flatnonzero(np.asarray(games["winnable"])):
+        rows = np.asarray(games["rows"][k]).astype(np.uint16)
+        board = ((rows[:, None] >> np.arange(10)) & 1).astype(bool)
+        out.append((board, [rng.randint(0, 6)] + [int(x) for x in games["sequence"][k]]))
+    return out
+
+
 class RandomPieceGenerator:
     def __init__(self, rng=None) -> None:
         self.pieces: List[int] = []

@@ -49,3 +49,22 @@ def test_same_pieces_as_the_reference_under_the_same_seed():
             (piece, index), regenerated = gen.get_random_piece()
             assert (piece, index, int(regenerated)) == tuple(int(x) for x in f["draws"][k, i])
             gen.delete_index(index)
+
+
+def test_translate_hands_over_the_winnable_forward_games_with_one_random_piece_in_front():
+    """translate() (game/tetris.py:19-20) on the forward generator's games for the reference's own seeds 0..99 at L = 5, M = 20
+    (tests/golden/forward_L5_M20.npz: 22 of them winnable): boards as 20x10 bool arrays, M + 1 piece ids of which pieces[1:] is
+    the game's sequence in Tetris.move's ids and pieces[0] what random.randint(0, 6) gives next."""
+    f = np.load(os.path.join(ROOT, "tests", "golden", "forward_L5_M20.npz"))
+    games = tetris.forward_generate(5, 20, f["seeds"])
+    random.seed(5)
+    batch = tetris.translate(games)
+    random.seed(5)
+    leads = [random.randint(0, 6) for _ in batch]
+    keep = np.flatnonzero(f["winnable"])
+    assert len(batch) == len(keep) == 22
+    letter_to_id = np.array([0, 2, 1, 6, 4, 3, 5])             # I J L O S T Z -> piece_translations
+    for (board, pieces), k, lead in zip(batch, keep, leads):
+        assert board.shape == (20, 10) and board.dtype == bool
+        assert np.array_equal((board * (1 << np.arange(10))).sum(1), f["rows"][k])
+        assert pieces == [lead] + letter_to_id[f["sequence"][k]].tolist() and len(pieces) == 21
