@@ -469,6 +469,20 @@ def measure_config_supply(torch, T, dev, L, M, seed, keep=None):
     t0 = time.perf_counter()
     fw = T.forward_generate(5, 20, np.arange(games))
     dt_fw = time.perf_counter() - t0
+    # the same generator + solver as a HIP kernel (one game per lane), seed for seed the host's games
+    fenv = keep(T.BatchedTetris(5, 20, 64, device=dev, seed=seed))
+    games_dev = 1 << 16                                          # a launch of one wave per SIMD: a wave lasts as long as its slowest game
+    fenv.forward_configs(np.arange(games))                       # load the kernel
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    dfw = fenv.forward_configs(np.arange(games_dev))
+    torch.cuda.synchronize(dev)
+    dt_dfw = time.perf_counter() - t0
+    same_fw = bool(np.array_equal(dfw["winnable"][:games].cpu().numpy(), fw["winnable"]) and
+                   np.array_equal(dfw["rows"][:games].cpu().numpy().view(np.uint16), fw["rows"]) and
+                   np.array_equal(dfw["failed_attempts"][:games].cpu().numpy(), fw["failed_attempts"]))
+    del dfw
+    fenv.terminate()
     return {"unit": "configurations/s", "L": L, "M": M,
             "carve_device": {"value": rate_big, "count": count, "roofline": valu_roofline("carve_1048576", rate_big) if (L, M) == (10, 40) else None,
                              "roofline_batch_of_262144": valu_roofline("carve_262144", rate_small) if (L, M) == (10, 40) else None,
@@ -478,7 +492,11 @@ def measure_config_supply(torch, T, dev, L, M, seed, keep=None):
             "carve_host": {"value": host_count / dt_host, "count": host_count, "threads": T._lib.cpu_budget(),
                            "equal_to_device_output": same},
             "forward_generator_solver_host": {"value": games / dt_fw, "games": games, "L": 5, "M": 20,
-                                              "winnable_fraction": float(fw["winnable"].mean())}}
+                                              "winnable_fraction": float(fw["winnable"].mean())},
+            "forward_generator_solver_device": {"value": games_dev / dt_dfw, "games": games_dev, "L": 5, "M": 20, "equal_to_host_output": same_fw,
+                                                "note": "one game per lane, a CPython-compatible MT19937 per lane: a serial, divergent "
+                                                        "search (the reference feeds it a hundred seeds per batch; the carving generator "
+                                                        "is the supply)"}}
 
 
 def measure_live_supply(torch, T, env, actions, reward, done, seed, count=0, min_swaps=3, min_steps=4000, max_steps=40000,
