@@ -179,7 +179,7 @@ class PoolRefresher:
         other buffer -- and the pool is re-dealt more often for the same cost).
         waves: how many persistent 64-lane waves share the generator's queue: its footprint beside the stepping environment.
         0 = chosen by `target_slowdown` from the measured table above (the default 1.13 picks 768 waves: 1.13 x the step
-        time alone for 14 M fresh configurations a second, a pool reuse factor of 330 at 2^20 boards under random play;
+        time alone for 14 M fresh configurations a second, a pool reuse factor of about 300 at 2^20 boards under random play;
         through round 4 the default was count / 256 waves on batches of 65,536: 1.02-1.10 x, 2 M/s, a factor of 2,300).
         What a footprint costs and supplies is in bench.py's `live_supply_run`
         (`by_generator_footprint`; profiles/NOTES.md has the history).  (The step kernel raises its waves'
