@@ -13,7 +13,7 @@ extern int hipMalloc(void** ptr, size_t size);
 extern int hipFree(void* ptr);
 extern int hipMemcpy(void* dst, const void* src, size_t bytes, int kind);
 extern int hipDeviceSynchronize(void);
-enum { kDeviceToHost = 2 };
+enum { kHostToDevice = 1, kDeviceToHost = 2 };
 
 #define CHECK(call)                                                                            \
     do {                                                                                       \
@@ -71,6 +71,47 @@ int main(int argc, char** argv) {
     if (tpl_step(env, NULL, TPL_U8, reward, done, NULL) != TPL_ERR_ARG || strlen(tpl_last_error()) == 0) {
         fprintf(stderr, "null action was not refused\n");
         return 1;
+    }
+    /* the supply side from plain C: both generators on the device against their host forms (same seeds, same outputs) */
+    {
+        const int64_t count = 256;
+        const int32_t gL = 5, gM = 20;
+        uint16_t *d_rows = NULL, *h_rows = malloc((size_t)count * TPL_ROWS * 2), *g_rows = malloc((size_t)count * TPL_ROWS * 2);
+        uint8_t *d_pieces = NULL, *h_pieces = malloc((size_t)count * (gM + 1)), *g_pieces = malloc((size_t)count * (gM + 1));
+        int32_t* d_status = NULL;
+        void* work = NULL;
+        const size_t work_bytes = tpl_generate_configs_device_work_bytes(gM, count);
+        CHECK(hipMalloc((void**)&d_rows, (size_t)count * TPL_ROWS * 2));
+        CHECK(hipMalloc((void**)&d_pieces, (size_t)count * (gM + 1)));
+        CHECK(hipMalloc((void**)&d_status, (size_t)count * sizeof(int32_t)));
+        CHECK(hipMalloc(&work, work_bytes));
+        CHECK(tpl_generate_configs_device(gL, gM, seed, 0, count, 0, d_rows, d_pieces, NULL, NULL, d_status, work, work_bytes, NULL));
+        CHECK(hipMemcpy(g_rows, d_rows, (size_t)count * TPL_ROWS * 2, kDeviceToHost));
+        CHECK(hipMemcpy(g_pieces, d_pieces, (size_t)count * (gM + 1), kDeviceToHost));
+        CHECK(tpl_generate_configs(gL, gM, seed, 0, count, 2, 0, h_rows, h_pieces, NULL, NULL));
+        printf("carve device==host %s\n", memcmp(g_rows, h_rows, (size_t)count * TPL_ROWS * 2) == 0 &&
+                                              memcmp(g_pieces, h_pieces, (size_t)count * (gM + 1)) == 0 ? "ok" : "DIFFERS");
+        hipFree(work); hipFree(d_status);
+
+        uint64_t h_seeds[100], *d_seeds = NULL;
+        uint8_t *d_seq = NULL, *d_win = NULL, h_win[100], g_win[100], *h_seq = malloc(100 * (size_t)gM);
+        for (int k = 0; k < 100; ++k) h_seeds[k] = (uint64_t)k;                /* the reference's own seeds (main.py:39-40) */
+        const size_t fwork_bytes = tpl_forward_generate_device_work_bytes(gM, 100);
+        CHECK(hipMalloc((void**)&d_seeds, sizeof(h_seeds)));
+        CHECK(hipMalloc((void**)&d_seq, 100 * (size_t)gM));
+        CHECK(hipMalloc((void**)&d_win, 100));
+        CHECK(hipMalloc(&work, fwork_bytes));
+        CHECK(hipMemcpy(d_seeds, h_seeds, sizeof(h_seeds), kHostToDevice));
+        CHECK(tpl_forward_generate_device(gL, gM, 4, 1000, d_seeds, 100, d_rows, d_seq, d_win, NULL, NULL, NULL, NULL, work, fwork_bytes, NULL));
+        CHECK(hipMemcpy(g_win, d_win, 100, kDeviceToHost));
+        CHECK(hipMemcpy(g_rows, d_rows, 100 * TPL_ROWS * 2, kDeviceToHost));
+        CHECK(tpl_forward_generate(gL, gM, 4, 1000, h_seeds, 100, 2, h_rows, h_seq, h_win, NULL, NULL, NULL, NULL));
+        int winnable = 0;
+        for (int k = 0; k < 100; ++k) winnable += g_win[k];
+        printf("forward device==host %s winnable %d\n", memcmp(g_win, h_win, 100) == 0 && memcmp(g_rows, h_rows, 100 * TPL_ROWS * 2) == 0 ? "ok" : "DIFFERS",
+               winnable);
+        hipFree(work); hipFree(d_seeds); hipFree(d_seq); hipFree(d_win); hipFree(d_rows); hipFree(d_pieces);
+        free(h_rows); free(g_rows); free(h_pieces); free(g_pieces); free(h_seq);
     }
     CHECK(tpl_destroy(env));
     hipFree(rows); hipFree(pieces); hipFree(action); hipFree(reward); hipFree(done); hipFree(stats);

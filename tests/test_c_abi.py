@@ -63,6 +63,10 @@ def test_standalone_c_program_reproduces_the_oracle(tmp_path):
     assert [int(x) for x in out["stats"].split()] == [s["episodes"], s["lines"], s["wins"], s["topouts"]]
     got = out["reward_sum"].split()
     assert float(got[0]) == round(reward_sum, 1) and int(got[2]) == done_count
+    # the supply side through the C ABI alone: both generators on the device equal their host forms; the forward generator over
+    # the reference's own seeds 0..99 at L = 5, M = 20 finds the 22 winnable games of tests/golden/forward_L5_M20.npz
+    assert out["carve"] == "device==host ok"
+    assert out["forward"] == "device==host ok winnable 22"
 
 
 def test_host_generators_under_address_and_ub_sanitizers(tmp_path):
