@@ -12,7 +12,11 @@
 #include "tpl_internal.h"
 #include "py_random.h"
 
+#include <sched.h>
+
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -190,11 +194,34 @@ bool generate_one(int L, int M, Random& rnd, int64_t max_iters, uint16_t* rows_o
 }  // namespace tpl
 
 
-// One configuration tried on the host before a batch goes out (tpl_internal.h).  The restart rule bounds every
+// Host threads worth starting when the caller names none: the affinity mask, capped by the cgroup CPU quota when there is one
+// (the rule of _lib.cpu_budget() on the Python side; hardware_concurrency() reports every CPU of the machine, a container's
+// share may be a sixteenth of that).
+int tpl::host_cpu_budget() {
+    int n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n < 1) n = (int)std::thread::hardware_concurrency();
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long long period = 0;
+        if (std::fscanf(f, "%31s %lld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0) {
+            const long long q = (std::atoll(quota) + period / 2) / period;
+            if (q >= 1 && q < n) n = (int)q;
+        }
+        std::fclose(f);
+    }
+    return n < 1 ? 1 : n;
+}
+
+// A few configurations tried on the host before a batch goes out (tpl_internal.h).  The restart rule bounds every
 // configuration at some 1,500 base cut-offs; a batch of an (L, M) that cannot be carved at all would spend that on EVERY
 // configuration -- minutes of host threads, or a kernel that runs for minutes -- so the generators first run the rule on
-// one fixed configuration (seed 0x7E7215, index 0; the verdict is kept per (L, M, cut-off)): attempts 0-11 one after the
-// other (a normal (L, M) is through with the first: a third of a millisecond at L = 10), the doubled ones side by side.
+// fixed pilot configurations (seed 0x7E7215, indices 0..kPilots-1; the verdict is kept per (L, M, cut-off)).  The batch is
+// refused only when EVERY pilot runs into every cut-off: under a marginal cut-off, where a configuration in a hundred caps
+// (the callers' status[] reports those one by one), a single unlucky pilot must not refuse the ninety-nine.  Per pilot:
+// attempts 0-11 one after the other (a normal (L, M) is through with the first attempt of the first pilot: a third of a
+// millisecond at L = 10), the doubled ones side by side on the host's CPU budget.
 int tpl::carve_pilot(int32_t L, int32_t M, int64_t cutoff) {
     if (M < carve_fewest_pieces(L))
         return fail_msg(TPL_ERR_ARG, "L=%d cannot be carved with M=%d pieces: two columns of %d cells need at least %d", L, M, L,
@@ -208,15 +235,17 @@ int tpl::carve_pilot(int32_t L, int32_t M, int64_t cutoff) {
         const auto it = verdicts.find(key);
         if (it != verdicts.end()) { known = true; ok = it->second; }
     }
+    constexpr int kPilots = 4;
     if (!known) {
         constexpr uint64_t kPilotSeed = 0x7E7215ULL;
         uint16_t rows[kRows];
         uint8_t pieces[256];
-        for (int a = 0; a < 12 && !ok; ++a) {
-            Decisions rnd(kPilotSeed, 0, (uint32_t)a);
-            ok = generate_one(L, M, rnd, carve_cutoff(L, cutoff, a), rows, pieces, nullptr, nullptr);
-        }
-        if (!ok) {
+        for (uint64_t pilot = 0; pilot < (uint64_t)kPilots && !ok; ++pilot) {
+            for (int a = 0; a < 12 && !ok; ++a) {
+                Decisions rnd(kPilotSeed, pilot, (uint32_t)a);
+                ok = generate_one(L, M, rnd, carve_cutoff(L, cutoff, a), rows, pieces, nullptr, nullptr);
+            }
+            if (ok) break;
             std::atomic<bool> found{false};
             std::atomic<int> next{12};
             auto work = [&] {
@@ -225,12 +254,12 @@ int tpl::carve_pilot(int32_t L, int32_t M, int64_t cutoff) {
                 for (;;) {
                     const int a = next.fetch_add(1);
                     if (a >= kCarveAttempts || found.load()) return;
-                    Decisions rnd(kPilotSeed, 0, (uint32_t)a);
+                    Decisions rnd(kPilotSeed, pilot, (uint32_t)a);
                     if (generate_one(L, M, rnd, carve_cutoff(L, cutoff, a), r, p, nullptr, nullptr, &found)) found.store(true);
                 }
             };
-            int threads = (int)std::thread::hardware_concurrency();
-            threads = threads < 1 ? 1 : threads > kCarveAttempts - 12 ? kCarveAttempts - 12 : threads;
+            int threads = host_cpu_budget();
+            threads = threads > kCarveAttempts - 12 ? kCarveAttempts - 12 : threads;
             std::vector<std::thread> pool;
             for (int t = 1; t < threads; ++t) pool.emplace_back(work);
             work();
@@ -241,9 +270,10 @@ int tpl::carve_pilot(int32_t L, int32_t M, int64_t cutoff) {
         verdicts[key] = ok;
     }
     if (!ok)
-        return fail_msg(TPL_ERR_STATE, "L=%d M=%d: the pilot configuration did not finish within %d attempts (base cut-off %lld "
+        return fail_msg(TPL_ERR_STATE, "L=%d M=%d: none of the %d pilot configurations finished within %d attempts (base cut-off %lld "
                         "trips, the last ones at %lld): not finished within the restart rule's bound -- a larger `cutoff` searches on",
-                        L, M, kCarveAttempts, (long long)carve_cutoff(L, cutoff, 0), (long long)carve_cutoff(L, cutoff, kCarveAttempts - 1));
+                        L, M, kPilots, kCarveAttempts, (long long)carve_cutoff(L, cutoff, 0),
+                        (long long)carve_cutoff(L, cutoff, kCarveAttempts - 1));
     return TPL_OK;
 }
 
@@ -254,8 +284,7 @@ static int run_generator(int32_t L, int32_t M, int64_t count, int32_t threads, u
     if (L < 1 || L > 16) return fail_msg(TPL_ERR_ARG, "carving needs 1 <= L <= 16 (got %d)", L);
     if (M < 1 || M > 254) return fail_msg(TPL_ERR_ARG, "M=%d out of range [1, 254]", M);
     if (count < 1 || !rows || !pieces) return fail_msg(TPL_ERR_ARG, "bad count / output pointers");
-    if (threads < 1) threads = (int32_t)std::thread::hardware_concurrency();
-    if (threads < 1) threads = 1;
+    if (threads < 1) threads = (int32_t)host_cpu_budget();
     if ((int64_t)threads > count) threads = (int32_t)count;
     std::atomic<int64_t> next{0};
     std::atomic<int64_t> failed{-1};

@@ -186,8 +186,7 @@ extern "C" int tpl_forward_generate(int32_t L, int32_t M, int32_t initial_height
     if (initial_height_max < 1 || initial_height_max > 16) return fail_msg(TPL_ERR_ARG, "initial_height_max must be in [1, 16]");
     if (max_attempts < 1) return fail_msg(TPL_ERR_ARG, "max_attempts must be positive");
     if (!seeds || count < 1 || !rows || !sequence || !winnable) return fail_msg(TPL_ERR_ARG, "bad seeds / count / output pointers");
-    if (threads < 1) threads = (int32_t)std::thread::hardware_concurrency();
-    if (threads < 1) threads = 1;
+    if (threads < 1) threads = (int32_t)host_cpu_budget();
     if ((int64_t)threads > count) threads = (int32_t)count;
     std::atomic<int64_t> next{0};
     auto work = [&] {

@@ -66,8 +66,12 @@ int fail_msg(int code, const char* fmt, ...);
 int check_can_advance(tpl_env* e);
 void count_steps(tpl_env* e, int64_t steps);
 
-// carve_generator.hip: the restart rule tried on ONE fixed configuration on the host (verdict kept per (L, M, cutoff)): TPL_OK,
-// or TPL_ERR_ARG / TPL_ERR_STATE with the message set when this (L, M) cannot be carved / does not finish within the rule's bound.
+// carve_generator.hip: host threads worth starting when a caller names none (affinity mask capped by the cgroup CPU quota)
+int host_cpu_budget();
+
+// carve_generator.hip: the restart rule tried on a few fixed configurations on the host (verdict kept per (L, M, cutoff)): TPL_OK,
+// or TPL_ERR_ARG / TPL_ERR_STATE with the message set when this (L, M) cannot be carved / NONE of the pilots finishes within the
+// rule's bound (single configurations that cap are the callers' status[] to report).
 // Both generators call it before a batch goes out -- on the device the alternative is a kernel that runs for minutes.
 int carve_pilot(int32_t L, int32_t M, int64_t cutoff);
 

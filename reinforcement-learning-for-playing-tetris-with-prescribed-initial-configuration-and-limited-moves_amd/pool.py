@@ -119,15 +119,35 @@ class ForwardGames:
         self.solution_len = out["solution_len"][keep].contiguous()
         self.count = int(self.rows.shape[0])
         self._torch = torch
+        self._index = None
 
     def translate(self, seed: int = 0, batch: int = 0, lead: bool = True):
-        """(rows int16 [count, 20], pieces uint8 [count, M + 1]) on the device, enqueued on the current stream (no host wait).
-        The extra piece of game g in batch b is a function of (seed, b, g): rng = numpy's PCG64 seeded with (seed, b)."""
+        """(rows int16 [count, 20], pieces uint8 [count, M + 1]) on the device, enqueued on the current stream.  NO host wait:
+        the extra piece of game g in batch b is drawn ON THE DEVICE, a splitmix64 hash of (seed, b, g) in torch's wrapping int64
+        arithmetic (through round 5 it was drawn by numpy and copied up from pageable memory -- a copy that holds the calling
+        thread until the stream has reached it, i.e. a stall of the step loop's host thread at every swap)."""
         torch = self._torch
-        extra = np.random.default_rng((int(seed), int(batch))).integers(0, 7, (self.count, 1)).astype(np.uint8)
-        extra = torch.from_numpy(extra).to(self.device, non_blocking=True)
-        pieces = torch.cat([extra, self.sequence] if lead else [self.sequence, extra], dim=1)
+        pieces = torch.cat([self._draw(seed, batch), self.sequence] if lead else [self.sequence, self._draw(seed, batch)], dim=1)
         return self.rows, pieces
+
+    def _draw(self, seed: int, batch: int):
+        """uint8 [count, 1] in 0..6, a function of (seed, batch, game index) alone (the same on any stream, any device)."""
+        torch = self._torch
+        if self._index is None:
+            self._index = torch.arange(self.count, dtype=torch.int64, device=self.device)
+
+        def signed(v):                                          # a 64-bit pattern as the int64 torch computes in
+            v &= (1 << 64) - 1
+            return v - (1 << 64) if v >> 63 else v
+
+        def shr(x, s):                                          # logical shift right of an int64 tensor
+            return (x >> s) & ((1 << (64 - s)) - 1)
+        key = signed((int(seed) * 0xD1342543DE82EF95 + int(batch) * 0xA0761D6478BD642F + 0x2545F4914F6CDD1D))
+        x = self._index * signed(0x9E3779B97F4A7C15) + key
+        x = (x ^ shr(x, 30)) * signed(0xBF58476D1CE4E5B9)
+        x = (x ^ shr(x, 27)) * signed(0x94D049BB133111EB)
+        x = x ^ shr(x, 31)
+        return (shr(x, 33) % 7).to(torch.uint8).unsqueeze(1)
 
 
 def blend(carved, forward_games, seed: int = 0, batch: int = 0, lead: bool = True):

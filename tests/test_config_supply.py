@@ -208,11 +208,13 @@ def test_restart_rule_host_generator_equals_the_oracle(oracle, L, M, n, cutoff):
 def test_restart_rule_does_not_move_the_distribution_of_configurations(L, M, n):
     """Which configurations a seed names is conditioned on a search ending within its cut-off (csrc/tpl_device.h, restart rule;
     round-4 advisor finding: host, device and oracle changed together, so parity cannot see a shift).  Pinned here against ONE
-    unbounded search per configuration (cutoff = 2^28): solution length, filled cells and stack height agree in the mean within
-    2 % and in distribution within 0.03 (largest gap between the two empirical distribution functions).  Measured at 20,000
-    configurations each: (10, 40) 14.36 vs 14.39 pieces, 43.5 vs 43.4 cells; (5, 20) 6.88 vs 6.93 pieces (z = -3.2: the rule
-    favours searches that end early, which carve 0.7 % fewer pieces -- visible, small), 23.4 vs 23.2 cells; (10, 12) and
-    (7, 10), where M binds, no difference."""
+    unbounded search per configuration (cutoff = 2^28): solution length, filled cells and stack height.  The rule DOES shift
+    the distribution, a little (INTEGRATION.md states it): it favours searches that end early, which carve slightly fewer pieces.
+    Measured with this seed: (5, 20) at 20,000 configurations 6.879 vs 6.928 pieces (-0.71 %, z = -3.2), 23.39 vs 23.19 cells
+    (+0.83 %, z = +3.2), largest gap between the two empirical distribution functions 0.013; (10, 40) at 5,000: -0.26 % / +0.35 %
+    (|z| < 0.8), gap 0.011; (10, 12), where M binds: |z| < 0.3, gap 0.009.  The bounds are a few sigma around those figures
+    (round-5 advisor finding: 2 % and 0.03 would have let a bias several times as large through): |z| <= 5 on every mean --
+    1.1 % at (5, 20) -- and a gap of at most 0.02."""
     import tetris_piclim as T
 
     def figures(cutoff):
@@ -223,10 +225,30 @@ def test_restart_rule_does_not_move_the_distribution_of_configurations(L, M, n):
     ruled, unbounded = figures(0), figures(1 << 28)
     for name in ruled:
         a, b = ruled[name], unbounded[name]
-        assert abs(a.mean() - b.mean()) <= 0.02 * b.mean(), (name, a.mean(), b.mean())
+        se = float(np.sqrt(a.var() / n + b.var() / n))
+        assert abs(a.mean() - b.mean()) <= 5.0 * se, (name, a.mean(), b.mean(), se)
         grid = np.unique(np.concatenate([a, b]))
         gap = np.abs(np.searchsorted(np.sort(a), grid, side="right") / n - np.searchsorted(np.sort(b), grid, side="right") / n).max()
-        assert gap <= 0.03, (name, gap)
+        assert gap <= 0.02, (name, gap)
+
+
+def test_one_capped_pilot_configuration_does_not_refuse_the_batch(oracle):
+    """Round-5 advisor finding: carve_pilot used to judge a whole (L, M, cut-off) by ONE fixed configuration.  At (8, 40) with
+    a base cut-off of one trip a fifth of all configurations run into every cut-off -- and so does pilot 0 (seed 0x7E7215, index
+    0) while pilots 1-3 finish: the batch must go ahead (only when EVERY pilot caps is it refused), configurations that cap are
+    reported one by one, and a stretch in which none caps (22 from index 4 of seed 5, by the oracle) is the oracle's."""
+    import tetris_piclim as T
+    L, M, cutoff = 8, 40, 1
+    pilots = [oracle.generate_config_seeded(L, M, 0x7E7215, k, cutoff)[0] < 0 for k in range(4)]
+    assert pilots[0] and not all(pilots)
+    rows, pieces = T.generate_configs(L, M, 22, seed=5, first=4, cutoff=cutoff)
+    for k in range(22):
+        it, r, p, _ = oracle.generate_config_seeded(L, M, 5, 4 + k, cutoff)
+        assert it >= 0 and np.array_equal(r, rows[k]) and np.array_equal(p, pieces[k]), k
+    with pytest.raises(T.TplError, match="configuration 3 did not finish"):       # not the pilot's message
+        T.generate_configs(L, M, 8, seed=5, first=0, cutoff=cutoff)
+    with pytest.raises(T.TplError, match="none of the 4 pilot configurations"):   # nothing ends within these cut-offs
+        T.generate_configs(10, 12, 8, seed=1, cutoff=1)
 
 
 @pytest.mark.gpu

@@ -68,3 +68,27 @@ def test_translate_hands_over_the_winnable_forward_games_with_one_random_piece_i
         assert board.shape == (20, 10) and board.dtype == bool
         assert np.array_equal((board * (1 << np.arange(10))).sum(1), f["rows"][k])
         assert pieces == [lead] + letter_to_id[f["sequence"][k]].tolist() and len(pieces) == 21
+
+
+def test_forward_games_draw_their_extra_piece_on_the_device_without_a_host_copy():
+    """pool.ForwardGames.translate puts one random piece in front of every forward game (game/tetris.py:19-20).  Round-5 advisor
+    finding: it drew that piece with numpy and copied it up from pageable memory (a host wait at every pool swap).  The draw is
+    now tensor arithmetic on the games' device -- a splitmix64 hash of (seed, batch, game) in wrapping int64 -- so here, on the
+    CPU: a function of its three keys alone, pieces 0..6 about evenly, different batches unrelated."""
+    import torch
+    import tetris_piclim as T
+    games = T.pool.ForwardGames.__new__(T.pool.ForwardGames)
+    games._torch, games.count, games.device, games._index = torch, 70000, torch.device("cpu"), None
+    games.rows = torch.zeros((games.count, 20), dtype=torch.int16)
+    games.sequence = torch.full((games.count, 20), 9, dtype=torch.uint8)
+    a = games._draw(3, 5).numpy().ravel()
+    assert a.dtype == np.uint8 and a.min() == 0 and a.max() == 6
+    assert np.abs(np.bincount(a, minlength=7) / games.count - 1 / 7).max() < 0.006          # ~4 sigma at 70,000 draws
+    assert np.array_equal(games._draw(3, 5).numpy().ravel(), a)
+    for other in (games._draw(3, 6), games._draw(4, 5)):
+        assert abs((other.numpy().ravel() == a).mean() - 1 / 7) < 0.01
+    assert np.array_equal(games._draw(3, 5).numpy().ravel()[:1000], games.__class__._draw(games, 3, 5)[:1000].numpy().ravel())
+    rows, pieces = games.translate(3, 5)
+    assert pieces.shape == (games.count, 21) and np.array_equal(pieces[:, 0].numpy(), a) and (pieces[:, 1:] == 9).all()
+    _, tail = games.translate(3, 5, lead=False)
+    assert np.array_equal(tail[:, -1].numpy(), a) and (tail[:, :-1] == 9).all()
