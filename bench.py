@@ -4,753 +4,55 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one lockstep pass of the hot path (tpl_step: one Tetris.move per board, auto-reset of finished
-boards from the device pool) over one batch of synthetic actions.  Workload = BASELINE.json configs[2] at N = 1 and
-configs[3] at N > 1: 1,048,576 boards IN TOTAL, L=10, M=40, synthetic boards / 7-bag piece lists / uniform actions
-(SURVEY 8d), all resident in HBM before the timed region.  N > 1 shards that one batch by global board index
-(1,048,576 / N boards per GPU: fixed total work, "scaling": "strong"), one process per GPU, the same pool on every
-rank, no data-path collective; one RCCL all-reduce of the episodic-return counters closes the timed region.  The N-GPU
-job is the one-GPU job sharded: same episodes, same mean return.  Side keys: `fused_rollout` (the same job, K steps per
-launch), `shard_run` (N = 1: rank 0's shard of an 8-GPU run, measured on this GPU), `weak_scaling_job` (N > 1:
-1,048,576 boards on EVERY rank -- a different, larger job, never `value`).
+A "step" is one lockstep pass of the hot path (tpl_step: one Tetris.move per board, auto-reset of finished boards from the device
+pool) over one batch of synthetic actions.  Workload = BASELINE.json configs[2] at N = 1 and configs[3] at N > 1: 1,048,576 boards
+IN TOTAL, L=10, M=40, synthetic boards / 7-bag piece lists / uniform actions, all resident in HBM before the timed
+region.  N > 1 shards that one batch by global board index (1,048,576 / N boards per GPU: fixed total work, "scaling": "strong"),
+one process per GPU, the same pool on every rank, no data-path collective; one RCCL all-reduce of the episodic-return counters
+closes the timed region.  The N-GPU job is the one-GPU job sharded: same episodes, same mean return.
+`python bench.py --gpus N` with N > 1 and no RANK in the environment starts the N ranks itself (a child process, spawned before
+anything touches the GPU) and exits with the child's status.
 
-`python bench.py --gpus N` with N > 1 and no RANK in the environment starts the N ranks itself (a child
-`python -m torch.distributed.run`, spawned before anything touches the GPU) and exits with the child's status.
+Launch mode (`config.launch_mode`): every step is ONE step_kernel launch over the rank's boards in either mode.  "eager" = one
+tpl_step() call per step (N = 1 always: the N = 1 point of a scaling run is the plain bench line).  "graph" = the same launches
+captured <= 50 at a time and replayed ("persistent stream, no host sync per step, HIP graphs for the rollout loop"),
+chosen for N > 1 when a rank holds fewer than 2^19 boards: there the host's ~5 us per tpl_step() call are as long as the device's
+period, and a host-bound rank would set the node's figure.  `timing.host_call_us` is the measured cost of a tpl_step() call,
+`timing.host_issue_us_per_step` what the timed loop's issue cost the host per step in the mode used.
 
-Timing: `value` and `ms_per_step` come from a HIP-event pair on the launch stream around EXACTLY K step
-launches (max over ranks), the region bracketed by barrier + synchronize on both sides; the job's one collective (the
-all-reduce of the return counters) closes the region and is reported apart as `collective_ms`, the host's wall clock
-over region + collective as `wall_ms_per_step`.  The last of the W warm-up steps is enqueued after the synchronize,
-directly ahead of the first timed launch ("excluding one warm-up"): a launch into a queue that has run dry
-pays the GPU's wake-up, 20-160 us by how long it idled (tools/launch_probe.py), which is not a property of a step; an
-event ahead of that launch puts its duration in the line (`timing.launch_after_synchronize_ms`).  `roofline.kernel_ms`
-is the launch period over the K timed launches; `roofline.sustained` is the same loop over 2000 launches right after.
+Timing: `value` and `ms_per_step` come from a HIP-event pair on the launch stream around EXACTLY K steps (max over
+ranks), the region bracketed by barrier + synchronize on both sides; the all-reduce closes the region and is reported apart
+(`timing.collective_ms`).  The last of the W warm-up steps is enqueued after the synchronize, directly ahead of the first timed
+launch ("excluding one warm-up"): a launch into a queue that has run dry pays the GPU's wake-up, 20-160 us, which is
+not a property of a step (`timing.launch_after_synchronize_ms`).
 
-The headline cannot be lost to what follows it: every side figure runs under a guard (`SideFigures`: an exception becomes
-`{"error": ...}` under the figure's key; at N > 1 the ranks agree before and after each figure over a gloo group of host
-tensors, so none waits in a collective for one that raised; figures past `--side-budget` seconds are skipped; a figure still
-running after `--side-timeout` is abandoned and the line printed with what there is).  A failure INSIDE the timed region is
-not guarded: the run ends with a non-zero status.
-
-Prints ONE JSON line (rank 0).  `roofline` prices the step kernel against HBM with the canonical
-96 B/board-step of SURVEY 8(d); `cpu_baseline` is the CPU oracle (a scalar C port of the reference's move)
-timed on this box's host cores over a bounded sample of the same workload, with the NumPy per-board restatement
-(the reference's own operation sequence) beside it.  Side figures that never enter `value`: `fused_rollout`
-(tpl_rollout), `carved_pool_run` (the step loop on carved configurations), `config1_run` (BASELINE configs[1]:
-65,536 boards, L=5, M=20), `actor_loop` (BASELINE configs[4]: 262,144 boards driven by the 217-128-128-128-128-14
-policy).  The timed region is the first GPU work of the process; every side figure follows it (`--side-figures-first`
-restores the order of rounds 2-3, which ran the figures that own their boards ahead of it: measured same box, alternating,
-15.59 / 15.69 / 15.62 us per step over the 20 timed steps this way, 15.82 / 15.66 / 15.68 that way).
+Output.  stdout carries ONE JSON line, the contract's: the headline keys first, `roofline` (the step kernel against HBM at the
+canonical 96 B/board-step of SURVEY 8(d); `frac` = this run, `frac_hbm_resident` = the same kernel where nothing fits the 256 MiB
+Infinity Cache), `cpu_baseline` (the C oracle on this box's host cores; `limited_by` says what bounds them), `scaling_model` (N = 1:
+the periods of a 2-, 4- and 8-GPU run's shards measured on this GPU, and the value and efficiency they imply) and one number per
+side figure.  The full record -- every side figure with its own roofline, bench_side.py -- goes to `--detail` (default
+gpurun_out/bench_detail_n<N>.json) and, as one line prefixed BENCH_DETAIL, to stderr.  Side figures never enter `value`; each
+runs under a guard (bench_side.SideFigures): an exception costs its own key, figures past --side-budget are skipped, and if one
+hangs past --side-timeout the line is printed with what there is and the process exits with status 3.  A failure INSIDE the timed
+region is not guarded: the run ends non-zero with no line.
 """
 import argparse
-import ctypes
 import json
 import os
 import socket
-import statistics
 import subprocess
 import sys
 import time
+import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_BOARD_STEP = 96          # SURVEY 8(d): 46 B read + 49 B write, rounded
-HBM_PEAK_GBS = 8000.0                   # MI355X HBM3E peak (MI355X_MICROARCH.md)
-MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 (MI355X_MICROARCH.md)
-MFMA_F32_PEAK_TFLOPS = 157.3            # f32-input MFMA = the f32 vector rate (MI355X_MICROARCH.md)
-MODEL_FLOPS_PER_BOARD = 2.0 * (217 * 128 + 3 * 128 * 128 + 128 * 14)     # Model(217, 14), model/model.py:9-20: 157,440
-SIMDS, PEAK_CLOCK_GHZ = 1024, 2.4       # 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
-_VALU_ISSUE = None
+from bench_side import (ALGO_BYTES_PER_BOARD_STEP, HBM_ACHIEVABLE_GBS, HBM_PEAK_GBS, SideFigures, WATCHDOG_STATUS,  # noqa: E402,F401
+                        action_rows, launch_mode_for, library_digest, numpy_port_leg, valu_roofline)
+import bench_side as B  # noqa: E402
 
-
-def valu_roofline(form, units_per_s):
-    """The roofline of a kernel that HBM does not bound: VECTOR-INSTRUCTION ISSUE.  A SIMD issues one wave64 vector instruction
-    per c cycles at best -- c = the kernel's instruction mix priced with the issue costs measured on gfx950 (tools/valu_mix.py,
-    tools/valu_rates.hip: 2.5 cycles for a handful of plain opcodes, 4 for the rest) -- and the chip has 1,024 SIMDs, so
-    `peak` = 1024 x 2.4 GHz / c wave-instructions a second.  `achieved` = vector instructions per unit of work (SQ_INSTS_VALU of
-    the committed counter pass of this same form, profiles/valu_issue.json, written by tools/update_valu_issue.py) x the units per
-    second measured HERE.  Like `roofline.traffic`, the per-unit count comes from the committed profile (PMC counters cannot be
-    read from inside the process) and says which."""
-    global _VALU_ISSUE
-    if _VALU_ISSUE is None:
-        try:
-            _VALU_ISSUE = json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))["forms"]
-        except (OSError, KeyError, ValueError):
-            _VALU_ISSUE = {}
-    f = _VALU_ISSUE.get(form)
-    if not f or not units_per_s:
-        return None
-    c = f["cycles_per_valu_instruction"]
-    achieved = f["valu_per_unit"] * units_per_s / 1e9
-    peak = SIMDS * PEAK_CLOCK_GHZ / c
-    out = {"bound": "valu-issue", "achieved": achieved, "peak": peak, "unit": "G wave-instructions/s", "frac": achieved / peak,
-           "valu_instructions_per_" + f["unit"].replace("-", "_"): f["valu_per_unit"], "cycles_per_valu_instruction": c,
-           "lanes_active_per_valu_instruction": f.get("lanes_active_per_valu_instruction"),
-           "in_the_profiled_run": {"frac": f["frac"], "frac_at_the_clock_held": f["frac_at_clock_held"],
-                                   "clock_GHz_held": f["clock_GHz_held"], "duration_ns": f["duration_ns_median"]},
-           "source": f"NOT counted in this run: {f['source']} (commit {f['stamp'].get('git_head')}, source digest "
-                     f"{str(f['stamp'].get('source_digest'))[:12]}), {f['kernel']} at grid {f['grid']}"}
-    if f.get("lanes_active_per_valu_instruction"):
-        # of the lane-slots the issued instructions offer, the share that did work (divergence inside a wave)
-        out["frac_of_lane_slots"] = out["frac"] * f["lanes_active_per_valu_instruction"] / 64.0
-    return out
-
-
-def numpy_port_leg(L, M, seed, cores, seconds=2.0):
-    """the NumPy per-board restatement of the reference's move (oracle/numpy_port.py: the reference's
-    own operation sequence, so its rate on a core is the reference's rate on that core), one process per host core.
-    Started BEFORE this process touches the GPU (a process that has initialised HIP must not exec another)."""
-    cmd = [sys.executable, "-m", "oracle.numpy_port", str(seed), "256", str(L), str(M), str(seconds)]
-    procs = [subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, text=True) for _ in range(cores)]
-    rates = []
-    for p in procs:
-        out, _ = p.communicate(timeout=120)
-        if p.returncode == 0:
-            rates.append(json.loads(out.strip().splitlines()[-1])["moves_per_s"])
-    if len(rates) != cores:
-        return None
-    return {"value": sum(rates), "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "per_core": sum(rates) / cores,
-            "sample": f"{cores} processes x {seconds:.0f} s of move-and-reset over 256 synthetic configurations, L={L} M={M}"}
-
-
-def cpu_model():
-    """Model name of the host CPU (SURVEY 8d-ii asks for it beside the core count)."""
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.lower().startswith("model name"):
-                return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return None
-
-
-def cpu_baseline(L, M, seed, numpy_leg, seconds=2.0):
-    """The oracle's loop (game/performance_test.py:13-17 shape: move, reset when finished) on the host cores: a bounded
-    sample of about `seconds` of wall time on all the cores the container may use."""
-    from oracle import oracle as O
-    import tetris_piclim as T
-    cores = T._lib.cpu_budget()                                  # affinity mask capped by the cgroup CPU quota
-    boards, steps = 262144, 40
-    O.bench_run(seed, 4096, L, M, 8, cores)                      # warm the thread pool / page in
-    done, sec = O.bench_run(seed, boards, L, M, steps, cores)    # calibration: a few hundredths of a second
-    steps = int(max(40, min(20000, seconds * (done / sec) / boards)))
-    done, sec = O.bench_run(seed, boards, L, M, steps, cores)
-    out = {"value": done / sec, "unit": "env-steps/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
-           "sample": f"{boards} boards x {steps} lockstep steps, L={L} M={M}, auto-reset, {cores} threads, {sec:.1f}s",
-           "numpy_port": numpy_leg}
-    if numpy_leg and "per_core" in numpy_leg:
-        out["c_port_over_numpy_port_per_core"] = (done / sec / cores) / numpy_leg["per_core"]
-    try:
-        # the Python reference itself cannot travel to this box; its rate beside both restatements was measured in
-        # the build container (tests/golden/time_reference.py), one core each, same workload
-        ref = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_timing.json")))
-        out["reference_in_build_container"] = {k: ref[k] for k in (
-            "reference_moves_per_s", "numpy_port_moves_per_s", "c_port_env_steps_per_s", "c_port_over_reference",
-            "numpy_port_over_reference")}
-    except (OSError, KeyError, ValueError):
-        pass
-    return out
-
-
-def timed(torch, dev, fn, reps):
-    """Average milliseconds of fn() over `reps` calls, by HIP events on the current stream."""
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize(dev)
-    return e0.elapsed_time(e1) / reps
-
-
-class SideFigures:
-    """Runs the side figures of the line so that none of them can take the headline with it (round-4 review: an exception in a
-    side figure lost the line, and at N > 1 left the other ranks in a collective until the process group timed out).
-
-    * `run(name, fn)` calls fn() under a guard: an exception becomes `{"error": "<type>: <message>"}` under that key.
-    * At world > 1 a figure runs on every rank or on none, and every collective of a figure happens OUTSIDE fn: before it the
-      ranks agree whether to start (one of them may be out of time), after it whether all of them came through -- both over
-      `ctl`, a gloo group of host tensors that a sick GPU cannot take down.  Only then are the ranks' numbers combined
-      (`max_over_ranks`), so no rank ever waits in a collective for one that raised.
-    * `budget_s`: figures that would start after that many seconds of side figures are skipped (`{"skipped": ...}`).
-    * `watchdog(seconds, emit)`: if the side figures are still running after that long, `emit()` (rank 0: print the line with
-      what there is) is called from a timer thread and the process exits with status 0 -- a hung side figure cannot turn a
-      measured headline into a killed run.
-    `inject` names figures made to fail on purpose ("name" or "name@rank", comma separated; TPL_BENCH_INJECT_FAILURE): the
-    tests' way to see all of the above happen."""
-
-    def __init__(self, world=1, rank=0, dist=None, ctl=None, budget_s=None, inject="", clock=time.perf_counter, gather=None,
-                 distributed=None):
-        self.world, self.rank, self.dist, self.ctl = world, rank, dist, ctl
-        self.distributed = world > 1 if distributed is None else bool(distributed)   # (a forced one-rank group counts)
-        self._gather_fn = gather      # main() hands in the device-tensor gather of the job's own group when no gloo group could be made
-        self.budget_s, self.clock, self.t0 = budget_s, clock, clock()
-        self.inject = [x.strip() for x in (inject or "").split(",") if x.strip()]
-        self.log = []                 # (name, seconds, outcome) in the order run
-        self.running = None
-        self._timer = None
-
-    # -- host-side agreement between the ranks (gloo)
-    def _gather(self, value):
-        if self._gather_fn is not None:
-            return self._gather_fn(float(value))
-        if not self.distributed:
-            return [float(value)]
-        import torch
-        t = torch.tensor([float(value)], dtype=torch.float64)
-        got = [torch.zeros_like(t) for _ in range(self.world)]
-        self.dist.all_gather(got, t, group=self.ctl)
-        return [float(g.item()) for g in got]
-
-    def max_over_ranks(self, value):
-        return max(self._gather(value))
-
-    def _injected(self, name):
-        return any(x == name or x == f"{name}@{self.rank}" for x in self.inject)
-
-    def run(self, name, fn):
-        over = self.budget_s is not None and self.clock() - self.t0 > self.budget_s
-        if any(self._gather(1.0 if over else 0.0)):
-            self.log.append((name, 0.0, "skipped"))
-            return {"skipped": "the side figures had used their budget (--side-budget"
-                               + (f" = {self.budget_s:.0f} s" if self.budget_s is not None else "") + ") on some rank when this one's turn came"}
-        self.running = name
-        t0 = self.clock()
-        result = error = None
-        try:
-            if self._injected(name):
-                raise RuntimeError(f"failure injected into '{name}' (TPL_BENCH_INJECT_FAILURE)")
-            result = fn()
-        except Exception as e:        # noqa: BLE001 -- whatever it is, the headline survives it
-            error = f"{type(e).__name__}: {e}"[:400]
-        failed = [r for r, f in enumerate(self._gather(0.0 if error is None else 1.0)) if f]
-        self.running = None
-        self.log.append((name, self.clock() - t0, "ok" if not failed else "failed"))
-        if failed:
-            out = {"error": error or f"rank(s) {failed} failed; this rank's own measurement was dropped with theirs"}
-            if self.distributed:
-                out["failed_ranks"] = failed
-            return out
-        return result
-
-    @staticmethod
-    def ok(result):
-        return isinstance(result, dict) and "error" not in result and "skipped" not in result
-
-    def summary(self):
-        return {"seconds": {n: round(s, 3) for n, s, _ in self.log}, "failed": [n for n, _, o in self.log if o == "failed"],
-                "skipped": [n for n, _, o in self.log if o == "skipped"], "total_seconds": round(self.clock() - self.t0, 3)}
-
-    def watchdog(self, seconds, emit):
-        import threading
-
-        def fire():
-            try:
-                emit(self.running)
-            finally:
-                sys.stdout.flush()
-                os._exit(0)
-        self._timer = threading.Timer(seconds, fire)
-        self._timer.daemon = True
-        self._timer.start()
-
-    def disarm(self):
-        if self._timer is not None:
-            self._timer.cancel()
-            self._timer = None
-
-
-def releases_envs(fn):
-    """The measure_* functions that build environments of their own register them through `keep(...)`: whatever happens
-    inside -- the function's guard in SideFigures.run turns an exception into an {"error": ...} entry -- their handles and
-    device memory are released before the next figure starts."""
-    import functools
-
-    @functools.wraps(fn)
-    def wrapper(*args, **kwargs):
-        made = []
-
-        def keep(env):
-            made.append(env)
-            return env
-        try:
-            return fn(*args, keep=keep, **kwargs)
-        finally:
-            for env in made:
-                try:
-                    env.terminate()
-                except Exception:      # noqa: BLE001
-                    pass
-    return wrapper
-
-
-def measure_fused_rollout(torch, T, env, actions, first, K, chunk, compact=False):
-    """tpl_rollout over the same pre-staged actions, `chunk` steps per launch, writing the same
-    per-step reward/done outputs as the step loop -- or, `compact`, tpl_rollout_trajectory: one byte per board-step."""
-    n, dev = env.num_envs, env.device
-    rs = torch.empty((chunk, n), dtype=torch.float32, device=dev)
-    ds = torch.empty((chunk, n), dtype=torch.uint8, device=dev)
-    traj = torch.empty(((chunk + 3) // 4, n), dtype=torch.int32, device=dev)
-    launches = K // chunk
-
-    def run():
-        for c in range(launches):
-            a = actions[first + c * chunk: first + (c + 1) * chunk]
-            if compact:
-                T._lib.check(env._lib.tpl_rollout_trajectory(env._h, ctypes.c_void_p(a.data_ptr()), a.stride(0), chunk,
-                                                             ctypes.c_void_p(traj.data_ptr()), None, env._stream()))
-                continue
-            T._lib.check(env._lib.tpl_rollout(env._h, ctypes.c_void_p(a.data_ptr()), a.stride(0), chunk,
-                                              ctypes.c_void_p(rs.data_ptr()), ctypes.c_void_p(ds.data_ptr()), None, None,
-                                              env._stream()))
-    run()
-    torch.cuda.synchronize(dev)
-    return timed(torch, dev, run, 1) / (launches * chunk)
-
-
-def action_rows(actions):
-    """The rows of an [S, n] action tensor as S views made ONCE.  `actions[t]` inside a loop builds a new view object per step
-    (0.8 us of Python): nothing at 2^20 boards, a seventh of the period at a shard's 131,072, where the host's calls per second
-    are the limit (tools/step_issue_rate.py, tools/step_issue_breakdown.py) -- and no part of what is being measured."""
-    return list(actions.unbind(0))
-
-
-def measure_weak_job(torch, T, dev, rank, world, L, M, per_gpu, seed, K):
-    """Side figure for N > 1 (the headline is BASELINE configs[3], fixed total work): `per_gpu` boards on EVERY rank,
-    i.e. a job that grows with the node.  Same pool on every rank, everything keyed by the global board index.  Returns this
-    rank's ms per step; no collective in here (SideFigures.run), the ranks start together within the agreement that precedes it."""
-    shard = T.sharding.weak_shard(rank, world, per_gpu)
-    env = T.BatchedTetris(L, M, shard.boards, device=dev, seed=seed, global_offset=shard.global_offset,
-                          auto_reset=True, assign="hash")
-    try:
-        rows, pieces = env.synthetic_configs(per_gpu, first=0)
-        env.load_configs(rows, pieces)
-        del rows, pieces
-        env.reset()
-        S = max(1, min(K, 200))
-        actions = torch.empty((S, shard.boards), dtype=torch.uint8, device=dev)
-        for t in range(S):
-            env.synthetic_actions(t, out=actions[t])
-        reward = torch.empty(shard.boards, dtype=torch.float32, device=dev)
-        done = torch.empty(shard.boards, dtype=torch.uint8, device=dev)
-        rows_of = action_rows(actions)
-        for t in range(20):
-            env.step_into(rows_of[t % S], reward, done)
-        torch.cuda.synchronize(dev)
-        step = iter(range(S))
-        ms = timed(torch, dev, lambda: env.step_into(rows_of[next(step)], reward, done), S)
-    finally:
-        env.terminate()
-    return {"ms": ms, "steps": S, "global_boards": shard.global_boards}
-
-
-def weak_job_line(ms, steps, per_gpu, global_boards):
-    gbs = ALGO_BYTES_PER_BOARD_STEP * per_gpu / (ms * 1e-3) / 1e9
-    return {"scaling": "weak", "boards_per_gpu": per_gpu, "global_boards": global_boards, "unit": "env-steps/s",
-            "value": float(global_boards) / (ms * 1e-3), "ms_per_step": ms, "steps": steps,
-            "per_gpu_roofline_frac": gbs / HBM_PEAK_GBS,
-            "note": "NOT the BASELINE workload for N > 1 (that is 1,048,576 boards in total): a job N times as large"}
-
-
-@releases_envs
-def measure_shard_run(torch, T, dev, L, M, seed, total, ranks, chunk, keep=None):
-    """What ONE rank of an 8-GPU run of BASELINE configs[3] does, measured on this one GPU: rank 0's shard of `total`
-    boards over `ranks` GPUs (131,072 boards at the defaults), over the whole `total`-entry pool, in the three forms the
-    library offers: one tpl_step launch per step (the headline's form), `chunk` such steps as one replayed HIP graph, and
-    `chunk` steps per launch (tpl_rollout, same per-step outputs).  `frac` prices each against HBM at the canonical
-    96 B per board-step ON THE SHARD's boards."""
-    shard = T.sharding.strong_shard(0, ranks, total)
-    n = shard.boards
-    env = keep(T.BatchedTetris(L, M, n, device=dev, seed=seed, global_offset=shard.global_offset, auto_reset=True, assign="hash"))
-    rows, pieces = env.synthetic_configs(total, first=0)
-    env.load_configs(rows, pieces)
-    del rows, pieces
-    env.reset()
-    S = 8 * chunk
-    actions = torch.empty((S, n), dtype=torch.uint8, device=dev)
-    for t in range(S):
-        env.synthetic_actions(t, out=actions[t])
-    reward = torch.empty(n, dtype=torch.float32, device=dev)
-    done = torch.empty(n, dtype=torch.uint8, device=dev)
-    rows_of = action_rows(actions)
-    for t in range(50):
-        env.step_into(rows_of[t % S], reward, done)
-    torch.cuda.synchronize(dev)
-
-    def leg(ms, **more):
-        gbs = ALGO_BYTES_PER_BOARD_STEP * n / (ms * 1e-3) / 1e9
-        return dict({"us_per_step": ms * 1e3, "value_per_gpu": float(n) / (ms * 1e-3), "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
-                     f"value_x{ranks}_if_every_rank_matches": float(n) * ranks / (ms * 1e-3)}, **more)
-    step = iter(range(S))
-    ms_step = timed(torch, dev, lambda: env.step_into(rows_of[next(step)], reward, done), S)
-    rs = torch.empty((chunk, n), dtype=torch.float32, device=dev)
-    ds = torch.empty((chunk, n), dtype=torch.uint8, device=dev)
-    replay = env.capture_steps(actions[:chunk], rs, ds)
-    replay()
-    torch.cuda.synchronize(dev)
-    ms_graph = timed(torch, dev, replay, 8) / chunk
-    ms_fused = measure_fused_rollout(torch, T, env, actions, 0, S, chunk)
-    env.terminate()
-    # the multi-step kernel is not an HBM kernel (a board's 64 B cross the memory once per `chunk` steps): priced by vector issue
-    fused_leg = {"us_per_step": ms_fused * 1e3, "value_per_gpu": float(n) / (ms_fused * 1e-3),
-                 f"value_x{ranks}_if_every_rank_matches": float(n) * ranks / (ms_fused * 1e-3), "steps_per_launch": chunk,
-                 "outputs": "per-step reward f32 + done u8 written",
-                 "roofline": valu_roofline("rollout_shard_131072" if n == 131072 else "rollout_f32_u8_50", float(n) / (ms_fused * 1e-3))}
-    return {"workload": f"rank 0's shard of {total} boards over {ranks} GPUs = {n} boards, {total}-entry pool, L={L} M={M}",
-            "boards": n, "global_boards": total, "ranks": ranks, "unit": "env-steps/s",
-            "tpl_step": leg(ms_step, launches_per_step=1),
-            "capture_steps": leg(ms_graph, steps_per_graph=chunk),
-            "tpl_rollout": fused_leg,
-            "note": "measured on ONE GPU; an N-GPU run's headline is global_boards / (the slowest rank's tpl_step period)"}
-
-
-@releases_envs
-def measure_out_of_cache(torch, T, dev, L, M, seed, boards=1 << 23, pool=1 << 21, steps=100, keep=None):
-    """The step loop where nothing fits the 256 MiB Infinity Cache: 2^23 boards (256 MiB of state) over a 2^21-entry
-    pool (another 256 MiB).  Reported per 2^20 boards so that it reads beside the main line."""
-    env = keep(T.BatchedTetris(L, M, boards, device=dev, seed=seed, auto_reset=True, assign="hash"))
-    rows, pieces = env.synthetic_configs(pool)
-    env.load_configs(rows, pieces)
-    del rows, pieces
-    env.reset()
-    S = 8
-    actions = torch.empty((S, boards), dtype=torch.uint8, device=dev)
-    for t in range(S):
-        env.synthetic_actions(t, out=actions[t])
-    reward = torch.empty(boards, dtype=torch.float32, device=dev)
-    done = torch.empty(boards, dtype=torch.uint8, device=dev)
-    for t in range(10):
-        env.step_into(actions[t % S], reward, done)
-    torch.cuda.synchronize(dev)
-    step = iter(range(steps))
-    ms = timed(torch, dev, lambda: env.step_into(actions[next(step) % S], reward, done), steps)
-    env.terminate()
-    gbs = ALGO_BYTES_PER_BOARD_STEP * boards / (ms * 1e-3) / 1e9
-    return {"boards": boards, "pool_entries": pool, "resident_bytes": boards * 32 + pool * 128,
-            "kernel_ms": ms, "us_per_2^20_boards": ms * 1e3 / (boards / float(1 << 20)),
-            "value": float(boards) / (ms * 1e-3), "unit": "env-steps/s", "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
-            "note": "state (32 B/board) + pool (128 B/entry) = 512 MiB, twice the Infinity Cache: every launch streams from HBM"}
-
-
-@releases_envs
-def measure_config_supply(torch, T, dev, L, M, seed, keep=None):
-    """rates of the prescribed-configuration suppliers (side figures).  Carving on the device
-    (a persistent kernel: lanes take configurations from a queue, and once it is dry run further attempts of their wave's
-    stragglers under the restart rule) and on the host cores produce the same configurations; the forward generator +
-    solver is host code.  Device rates by batch size (a launch lasts as long as its slowest wave) and at the reference's
-    own test configuration L = 15, M = 40 (game/main.py:33,50)."""
-    import numpy as np
-    env = keep(T.BatchedTetris(L, M, 64, device=dev, seed=seed))
-
-    def device_rate(e, count, reps=2):
-        e.carved_configs(count)                                  # load the kernel, and let torch's allocator keep the buffers
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for r in range(reps):
-            rows, _ = e.carved_configs(count, first=(r + 1) * count)     # returns after the status check (host sync)
-        return count * reps / (time.perf_counter() - t0), rows
-    count = 1 << 20                                              # a pool's worth
-    rate_big, _ = device_rate(env, count)
-    rate_small, _ = device_rate(env, 1 << 18)
-    rate_huge, _ = device_rate(env, 1 << 22, reps=1)             # the end of a launch amortised over sixteen configurations a lane
-    rows = env.carved_configs(1 << 14, first=0)[0]
-    host_count = 1 << 14
-    t0 = time.perf_counter()
-    hrows, _ = T.generate_configs(L, M, host_count, seed=seed)
-    dt_host = time.perf_counter() - t0
-    same = bool(np.array_equal(rows.cpu().numpy().view(np.uint16), hrows))
-    env.terminate()
-    ref_env = keep(T.BatchedTetris(15, 40, 64, device=dev, seed=seed))
-    rate_ref, _ = device_rate(ref_env, 1 << 18, reps=1)
-    ref_env.terminate()
-    games = 4000
-    t0 = time.perf_counter()
-    fw = T.forward_generate(5, 20, np.arange(games))
-    dt_fw = time.perf_counter() - t0
-    # the same generator + solver as a HIP kernel (one game per lane), seed for seed the host's games
-    fenv = keep(T.BatchedTetris(5, 20, 64, device=dev, seed=seed))
-    games_dev = 1 << 16                                          # a launch of one wave per SIMD: a wave lasts as long as its slowest game
-    fenv.forward_configs(np.arange(games))                       # load the kernel
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    dfw = fenv.forward_configs(np.arange(games_dev))
-    torch.cuda.synchronize(dev)
-    dt_dfw = time.perf_counter() - t0
-    same_fw = bool(np.array_equal(dfw["winnable"][:games].cpu().numpy(), fw["winnable"]) and
-                   np.array_equal(dfw["rows"][:games].cpu().numpy().view(np.uint16), fw["rows"]) and
-                   np.array_equal(dfw["failed_attempts"][:games].cpu().numpy(), fw["failed_attempts"]))
-    del dfw
-    fenv.terminate()
-    return {"unit": "configurations/s", "L": L, "M": M,
-            "carve_device": {"value": rate_big, "count": count, "roofline": valu_roofline("carve_1048576", rate_big) if (L, M) == (10, 40) else None,
-                             "roofline_batch_of_262144": valu_roofline("carve_262144", rate_small) if (L, M) == (10, 40) else None,
-                             "batch_of_262144": rate_small,
-                             "rate_ratio_2^20_over_2^18": rate_big / rate_small, "batch_of_4194304": rate_huge,
-                             "L15_M40_batch_of_262144": rate_ref},
-            "carve_host": {"value": host_count / dt_host, "count": host_count, "threads": T._lib.cpu_budget(),
-                           "equal_to_device_output": same},
-            "forward_generator_solver_host": {"value": games / dt_fw, "games": games, "L": 5, "M": 20,
-                                              "winnable_fraction": float(fw["winnable"].mean())},
-            "forward_generator_solver_device": {"value": games_dev / dt_dfw, "games": games_dev, "L": 5, "M": 20, "equal_to_host_output": same_fw,
-                                                "note": "one game per lane, a CPython-compatible MT19937 per lane: a serial, divergent "
-                                                        "search (the reference feeds it a hundred seeds per batch; the carving generator "
-                                                        "is the supply)"}}
-
-
-def measure_live_supply(torch, T, env, actions, reward, done, seed, count=0, min_swaps=3, min_steps=4000, max_steps=40000,
-                        step_fn=None, **where):
-    """The replenished supply under load (game/tetris.py:195-211, 473-488: producers feed the reset queue while games
-    run): PoolRefresher carves `count` configurations at a time on a side stream while the main stream steps, and each
-    finished batch becomes the current pool (boards in mid-episode finish on the buffer they started from).  Steady state:
-    the timed region starts at the FIRST swap and runs until `min_swaps` more batches have been swapped in (and at least
-    `min_steps` steps); the supply rate is those batches over the wall time between the first and the last swap.  `where` = PoolRefresher's waves / reserved_cus / low_priority.
-    count = 0: PoolRefresher's default, pool-sized batches (one configuration per board).  `step_fn(t)` replaces the random-action
-    step (the policy-driven loop of measure_actor_loop)."""
-    n, dev = env.num_envs, env.device
-    S = actions.shape[0] if actions is not None else 1
-    if step_fn is None:
-        def step_fn(t):
-            env.step_into(actions[t % S], reward, done)
-    rows, pieces = T.generate_configs(env.L, env.M, 4096, seed=seed)          # something carved to start from
-    if env.n_configs:
-        env.reset()                                                           # no board left on the buffer about to be replaced
-    env.load_configs(rows, pieces)
-    env.reset()
-    for t in range(50):
-        step_fn(t)
-    torch.cuda.synchronize(dev)
-    alone = iter(range(50, 10 ** 9))
-    ms_alone = timed(torch, dev, lambda: step_fn(next(alone)), 500 if actions is not None else 100)
-    feeder = T.PoolRefresher(env, count, seed=seed, first=4096, **where)
-    count = feeder.count
-    try:
-        # the supplier's first batch is its start-up (the generator's code is loaded, its work memory and the batch's tensors are
-        # allocated -- a hipMalloc is a device synchronisation): stepped through untimed, the timed region begins at the first swap
-        lead = 0
-        while lead < max_steps and not feeder.poll():
-            for t in range(32):
-                step_fn(lead + t)
-            lead += 32
-        episodes0 = env.stats()["episodes"]
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        swap_times = [time.perf_counter()]
-        e0.record()
-        steps = 0
-        while steps < max_steps and (steps < min_steps or len(swap_times) < min_swaps + 1):
-            for t in range(32):
-                step_fn(lead + steps + t)
-            steps += 32
-            if feeder.poll():
-                swap_times.append(time.perf_counter())       # the host loop runs a bounded queue ahead of the GPU: wall time tracks it
-        e1.record()
-        torch.cuda.synchronize(dev)
-        ms = e0.elapsed_time(e1) / steps
-        resets_per_s = (env.stats()["episodes"] - episodes0) / (ms * 1e-3 * steps)
-        waves = feeder.waves
-    finally:
-        feeder.close()                                        # whatever happened, no generator keeps running beside the next figure
-    fresh_per_s = (len(swap_times) - 1) * count / (swap_times[-1] - swap_times[0]) if len(swap_times) >= 2 else None
-    return {"unit": "env-steps/s", "value": float(n) / (ms * 1e-3), "ms_per_step": ms, "ms_per_step_without_refresher": ms_alone,
-            "slowdown": ms / ms_alone, "configurations_per_batch": count, "generator_waves": waves, "pool_swaps": len(swap_times) - 1, "steps": steps,
-            "steps_before_the_first_swap_untimed": lead,
-            "configurations_supplied_per_s": fresh_per_s, "resets_per_s": resets_per_s,
-            # the reference's reset() blocks on queue.get() (game/tetris.py:445-447): every episode a fresh game, factor 1
-            "pool_reuse_factor": (resets_per_s / fresh_per_s) if fresh_per_s else None}
-
-
-def measure_carved_pool(torch, T, env, actions, reward, done, W, K, pool, seed):
-    """SURVEY 8(d) "realism run": the same step loop on a pool of CARVED (solvable) configurations."""
-    n, dev, S = env.num_envs, env.device, actions.shape[0]
-    rows, pieces = T.generate_configs(env.L, env.M, pool, seed=seed)
-    env.load_configs(rows, pieces)
-    env.reset()
-    for t in range(W):
-        env.step_into(actions[t % S], reward, done)
-    torch.cuda.synchronize(dev)
-    kc = min(K, 500)
-    step = iter(range(W, W + kc))
-    ms = timed(torch, dev, lambda: env.step_into(actions[next(step) % S], reward, done), kc)
-    st = env.stats()
-    return {"value": float(n) / (ms * 1e-3), "unit": "env-steps/s", "ms_per_step": ms, "pool": pool,
-            "mean_moves_per_episode": (W + kc) * float(n) / max(st["episodes"], 1),
-            "win_rate": st["wins"] / max(st["episodes"], 1)}
-
-
-@releases_envs
-def measure_actor_loop(torch, T, dev, L, M, boards, seed, keep=None):
-    """BASELINE configs[4]: boards driven by the policy MLP, obs -> action -> step on the device, three ways."""
-    env = keep(T.BatchedTetris(L, M, boards, device=dev, seed=seed, auto_reset=True, assign="hash"))
-    rows, pieces = env.synthetic_configs(boards)
-    env.load_configs(rows, pieces)
-    env.reset()
-    out = {"boards": boards, "unit": "env-steps/s", "policy": "MLP 217-128-128-128-128-14, greedy, random init",
-           "arithmetic": {"value": "float32 accuracy on the bf16 pipe (split_megakernel)", "fused_mfma_kernel": "bf16 operands, f32 accumulation",
-                          "fused_f32_kernel": "float32 operands and accumulation: the reference's nn.Linear width (model/model.py:9-20)",
-                          "f32_megakernel": "float32 operands and accumulation (v_mfma_f32_16x16x4_f32), T steps per launch",
-                          "split_megakernel": "as fused_split_kernel, T steps per launch",
-                          "fused_split_kernel": "float32 accuracy on the bf16 pipe: every weight and activation as three bf16 pieces, "
-                                                "six v_mfma_f32_16x16x32_bf16 per product, float32 accumulation (within the float32 "
-                                                "kernel's tolerance of a float64 evaluation; not bit-identical to a float32 FMA chain)",
-                          "megakernel": "bf16 operands, f32 accumulation, T steps per launch",
-                          "torch_linear_layers": "torch bf16 Linear layers (hipBLASLt)",
-                          "torch_linear_layers_f32": "torch float32 Linear layers (hipBLASLt)"}}
-    for name, use_fused, dtype in (("fused_mfma_kernel", True, torch.bfloat16), ("fused_f32_kernel", True, torch.float32),
-                                   ("fused_split_kernel", True, torch.float32),
-                                   ("torch_linear_layers", False, torch.bfloat16), ("torch_linear_layers_f32", False, torch.float32)):
-        torch.manual_seed(0)
-        # two launches per iteration when fused: a graph replay costs more than it saves there
-        actor = T.Actor(env, T.PolicyMLP(), dtype=dtype, use_graph=not use_fused, fused=use_fused, split=name == "fused_split_kernel")
-        actor.run(20)
-        torch.cuda.synchronize(dev)
-        ms = timed(torch, dev, actor.step, 300 if dtype is torch.bfloat16 else 60)
-        out[name] = {"value": boards / (ms * 1e-3), "ms_per_step": ms}
-    # T iterations per launch (tpl_actor_rollout): weights stay in LDS, boards in registers; trajectory written
-    torch.manual_seed(0)
-    image = T.actor.policy_image(T.PolicyMLP(), dev)
-    iters = 50
-    env.actor_rollout(image, iters)
-    torch.cuda.synchronize(dev)
-    ms = timed(torch, dev, lambda: env.actor_rollout(image, iters), 6) / iters
-    out["megakernel"] = {"value": boards / (ms * 1e-3), "ms_per_step": ms, "steps_per_launch": iters,
-                         "outputs": "per-step action u8 + reward f32 + done u8 written",
-                         # the model's FLOPs over the WHOLE iteration (policy, exploration draw, move, trajectory stores): what
-                         # the matrix pipe delivers when the per-launch costs (weights into LDS, launch gap) are paid once per T
-                         "model_flops_over_whole_step_frac_of_bf16_peak": MODEL_FLOPS_PER_BOARD * boards / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
-    # the same loop at the reference's arithmetic width: float32 operands and accumulation, T iterations per launch
-    image32m = T.actor.policy_image(T.PolicyMLP(), dev, f32=True)
-    iters32 = 10
-    env.actor_rollout(image32m, iters32)
-    torch.cuda.synchronize(dev)
-    ms = timed(torch, dev, lambda: env.actor_rollout(image32m, iters32), 3) / iters32
-    out["f32_megakernel"] = {"value": boards / (ms * 1e-3), "ms_per_step": ms, "steps_per_launch": iters32,
-                             "outputs": "per-step action u8 + reward f32 + done u8 written"}
-    image_sm = T.actor.policy_image(T.PolicyMLP(), dev, f32="split")
-    env.actor_rollout(image_sm, iters32)
-    torch.cuda.synchronize(dev)
-    ms = timed(torch, dev, lambda: env.actor_rollout(image_sm, iters32), 3) / iters32
-    out["split_megakernel"] = {"value": boards / (ms * 1e-3), "ms_per_step": ms, "steps_per_launch": iters32,
-                               "outputs": "per-step action u8 + reward f32 + done u8 written"}
-    # BASELINE configs[4] is "driven by model/model.py policy": a float32 nn.Linear stack (model/model.py:9-20).  The figure of
-    # this block is therefore the fastest form at FLOAT32 ACCURACY -- the split megakernel (every product from three bf16 pieces
-    # per operand, float32 accumulation; within 2e-5 (1 + max|ref|) of a float64 evaluation, the float32 kernel's own tolerance:
-    # tests/test_policy_kernel.py) -- and the bf16 megakernel a named side key with ITS tolerance
-    out["value"] = out["split_megakernel"]["value"]
-    out["value_is"] = "split_megakernel: float32-accuracy policy (|logit - float64 ref| <= 2e-5 (1 + max|ref|)), T steps per launch"
-    out["bf16_megakernel"] = dict(out["megakernel"], tolerance="|logit - float64 ref| <= 2e-2 (1 + max|ref|): bf16 operands, "
-                                  "f32 accumulation -- NOT the reference's arithmetic width; actions agree with the float64 "
-                                  "policy wherever its margin exceeds twice that")
-    # the policy kernel alone against the dense bf16 MFMA peak: USEFUL FLOPs per board -- 2 x (217 x 128 + 3 x 128 x 128 +
-    # 128 x 14) = 157,440, the model's own (SURVEY 8d; the kernel issues 159,744: K padded to 224, the head as a 16-row tile)
-    # -- over its own duration
-    act = torch.empty(boards, dtype=torch.uint8, device=dev)
-    for _ in range(5):
-        env.policy_act(image, out=act)
-    ms = timed(torch, dev, lambda: env.policy_act(image, out=act), 100)
-    tflops = MODEL_FLOPS_PER_BOARD * boards / (ms * 1e-3) / 1e12
-    out["policy_kernel"] = {"ms": ms, "flops_per_board": MODEL_FLOPS_PER_BOARD,
-                            "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_PEAK_TFLOPS,
-                                         "unit": "TFLOP/s", "frac": tflops / MFMA_BF16_PEAK_TFLOPS}}
-    image32 = T.actor.policy_image(T.PolicyMLP(), dev, f32=True)
-    for _ in range(3):
-        env.policy_act(image32, out=act)
-    ms = timed(torch, dev, lambda: env.policy_act(image32, out=act), 20)
-    tflops = MODEL_FLOPS_PER_BOARD * boards / (ms * 1e-3) / 1e12
-    out["policy_kernel_f32"] = {"ms": ms, "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS,
-                                                       "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS}}
-    image_split = T.actor.policy_image(T.PolicyMLP(), dev, f32="split")
-    for _ in range(3):
-        env.policy_act(image_split, out=act)
-    ms_s = timed(torch, dev, lambda: env.policy_act(image_split, out=act), 20)
-    # six bf16 MFMAs per product in the hidden layers and the head, three in layer 1: the FLOPs it ISSUES against the bf16 peak
-    issued = 2.0 * (3 * 224 * 128 + 6 * 3 * 128 * 128 + 6 * 128 * 16) * boards / (ms_s * 1e-3) / 1e12
-    out["policy_kernel_split"] = {"ms": ms_s, "speedup_over_policy_kernel_f32": ms / ms_s,
-                                  "roofline": {"bound": "mfma", "achieved": issued, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                               "frac": issued / MFMA_BF16_PEAK_TFLOPS,
-                                               "note": "bf16 FLOPs issued (3-6 per float32-grade product), not model FLOPs"}}
-    # the replenished supply under the POLICY-driven loop (round-4 review: episodes last 2-3 times as long under a policy as
-    # under random play, so the reuse factor a LEARNER sees is this one): the bf16 policy kernel + tpl_step per step, with
-    # PoolRefresher's defaults beside them (pool-sized batches, the footprint `target_slowdown` picks)
-    torch.manual_seed(0)
-    actor = T.Actor(env, T.PolicyMLP(), dtype=torch.bfloat16, use_graph=False, fused=True)
-    live = measure_live_supply(torch, T, env, None, None, None, seed, min_swaps=2, min_steps=1000, max_steps=12000,
-                               step_fn=lambda t: actor.step())
-    keep = ("value", "ms_per_step", "ms_per_step_without_refresher", "slowdown", "configurations_per_batch", "generator_waves",
-            "pool_swaps", "steps", "configurations_supplied_per_s", "resets_per_s", "pool_reuse_factor")
-    out["live_supply"] = dict({k: live[k] for k in keep},
-                              loop="bf16 policy kernel + tpl_step per step (two launches), greedy, random-init weights; carved pool",
-                              note="the reference's reset() hands every episode a fresh game (game/tetris.py:445-447): factor 1")
-    # ... and at the reference's arithmetic width: the split policy kernel (float32 accuracy) + tpl_step per step -- a slower loop
-    # finishes fewer episodes a second beside the same generator, so its pool is re-dealt the fewest times
-    torch.manual_seed(0)
-    actor_s = T.Actor(env, T.PolicyMLP(), dtype=torch.float32, use_graph=False, fused=True, split=True)
-    live_s = measure_live_supply(torch, T, env, None, None, None, seed, min_swaps=2, min_steps=300, max_steps=4000,
-                                 step_fn=lambda t: actor_s.step())
-    out["live_supply"]["float32_accuracy_loop"] = dict({k: live_s[k] for k in keep},
-                                                       loop="split policy kernel + tpl_step per step (two launches)")
-    env.terminate()
-    return out
-
-
-@releases_envs
-def measure_config1(torch, T, dev, seed, chunk, keep=None):
-    """BASELINE configs[1]: 65,536 boards, random prescribed initial configurations, L=5, M=20, one GPU.  Side figure
-    with its own roofline: a launch this small is bound by the dispatch period of dependent launches, not by HBM."""
-    n, L, M, K = 65536, 5, 20, 400
-    env = keep(T.BatchedTetris(L, M, n, device=dev, seed=seed, auto_reset=True, assign="hash"))
-    rows, pieces = env.synthetic_configs(n)
-    env.load_configs(rows, pieces)
-    env.reset()
-    actions = torch.empty((K, n), dtype=torch.uint8, device=dev)
-    for t in range(K):
-        env.synthetic_actions(t, out=actions[t])
-    reward = torch.empty(n, dtype=torch.float32, device=dev)
-    done = torch.empty(n, dtype=torch.uint8, device=dev)
-    rows_of = action_rows(actions)
-    for t in range(50):
-        env.step_into(rows_of[t], reward, done)
-    torch.cuda.synchronize(dev)
-    step = iter(range(K))
-    ms = timed(torch, dev, lambda: env.step_into(rows_of[next(step)], reward, done), K)
-    out = {"workload": f"{n} boards, random initial configs, L={L} M={M}, auto-reset, uniform actions", "unit": "env-steps/s",
-           "value": float(n) / (ms * 1e-3), "ms_per_step": ms,
-           "roofline": {"bound": "hbm", "achieved": ALGO_BYTES_PER_BOARD_STEP * n / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": ALGO_BYTES_PER_BOARD_STEP * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "kernel": "step_kernel<action, auto_reset>", "kernel_ms": ms}}
-    # the same steps as one replayed HIP graph of 50: at this size the host's few microseconds per call are the limit
-    G = 50
-    rs = torch.empty((G, n), dtype=torch.float32, device=dev)
-    ds = torch.empty((G, n), dtype=torch.uint8, device=dev)
-    replay = env.capture_steps(actions[:G], rs, ds)
-    replay()
-    torch.cuda.synchronize(dev)
-    ms_g = timed(torch, dev, replay, 8) / G
-    out["graph_replay"] = {"value": float(n) / (ms_g * 1e-3), "ms_per_step": ms_g, "steps_per_graph": G}
-    if chunk > 0:
-        ms_f = measure_fused_rollout(torch, T, env, actions, 0, K // chunk * chunk, chunk)
-        out["fused_rollout"] = {"value": float(n) / (ms_f * 1e-3), "ms_per_step": ms_f, "steps_per_launch": chunk}
-    # north_star's step(action) -> (obs, reward, done) for a host-driven loop: the move and the [n,217] float32 observation
-    # as ONE launch (tpl_step_observe) against tpl_step followed by tpl_expand_obs
-    obs = torch.empty((n, 217), dtype=torch.float32, device=dev)
-    step = iter(range(2 * K))
-
-    def two_launches():
-        env.step_into(rows_of[next(step) % K], reward, done)
-        env.observe(out=obs)
-    for t in range(20):
-        env.step_observe_into(rows_of[t], reward, done, obs)
-    torch.cuda.synchronize(dev)
-    ms_two = timed(torch, dev, two_launches, K)
-    ms_one = timed(torch, dev, lambda: env.step_observe_into(rows_of[next(step) % K], reward, done, obs), K)
-    bytes_moved = (32 + 32 + 1 + 4 + 1 + 217 * 4) * n            # state in and out, action, reward, done, observation
-    out["obs_step"] = {"unit": "env-steps/s", "observation": "float32 [n, 217] written every step",
-                       "step_then_observe": {"value": float(n) / (ms_two * 1e-3), "ms_per_step": ms_two, "launches": 2},
-                       "step_observe": {"value": float(n) / (ms_one * 1e-3), "ms_per_step": ms_one, "launches": 1,
-                                        "achieved_GBs": bytes_moved / (ms_one * 1e-3) / 1e9},
-                       "speedup": ms_two / ms_one}
-    env.terminate()
-    return out
+GRAPH_STEPS = 50                        # steps per captured graph in "graph" mode (the last one holds the remainder)
 
 
 def self_launch(args):
@@ -767,7 +69,7 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -778,34 +80,103 @@ def main():
     ap.add_argument("--M", type=int, default=40)
     ap.add_argument("--pool", type=int, default=0, help="pool entries, the same pool on every rank (default: one per board of the job)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--launch-mode", choices=("auto", "eager", "graph"), default="auto",
+                    help="auto: replayed graphs of <= 50 steps for N > 1 below 2^19 boards per GPU, eager tpl_step() calls otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--actor-boards", type=int, default=262144, help="boards of the config-5 actor-loop side measurement (0 = skip)")
     ap.add_argument("--carved-pool", type=int, default=65536, help="size of the carved pool of the realism run (0 = skip)")
     ap.add_argument("--chunk", type=int, default=50, help="steps per launch of the fused-rollout side measurement (0 = skip)")
     ap.add_argument("--sustained", type=int, default=2000, help="launches of the sustained pass after the timed region (0 = skip)")
     ap.add_argument("--no-config1", action="store_true", help="skip the BASELINE configs[1] side line")
-    ap.add_argument("--side-figures-first", action="store_true", help="run the figures that own their boards before the timed region (the order of rounds 2-3)")
     ap.add_argument("--shard-ranks", type=int, default=8,
-                    help="N = 1 only: also run rank 0's shard of the job over this many GPUs (`shard_run`; 0 = skip)")
+                    help="N = 1 only: measure the shards of a 2-, 4- and this-many-GPU run on this GPU (`scaling_model`, `shard_run`; 0 = skip)")
     ap.add_argument("--no-weak-job", action="store_true", help="N > 1: skip the weak-scaling side figure (--boards per GPU)")
     ap.add_argument("--no-out-of-cache", action="store_true", help="skip the 2^23-board side run (N = 1 only)")
     ap.add_argument("--no-side-figures", action="store_true", help="the headline, its roofline and the CPU baseline only")
     ap.add_argument("--side-budget", type=float, default=240.0,
                     help="seconds of side figures after which the remaining ones are skipped (the headline is never skipped)")
     ap.add_argument("--side-timeout", type=float, default=480.0,
-                    help="seconds after which a side figure that is STILL running is abandoned: the line is printed with what there is")
+                    help="seconds after which a side figure that is STILL running is abandoned: the line is printed, exit status 3")
+    ap.add_argument("--detail", default=None, help="where the full record goes (default gpurun_out/bench_detail_n<N>.json; '-' = nowhere)")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
         ap.error("--gpus and --steps must be positive, --warmup non-negative")
     if args.no_side_figures:
         args.actor_boards = args.carved_pool = args.chunk = args.sustained = args.shard_ranks = 0
         args.no_config1 = args.no_weak_job = args.no_out_of_cache = True
+    return args
 
+
+def traffic_of(n):
+    """HBM bytes per launch by the PMC counters, scaled to `n` boards.  The counters cannot be read from inside this process
+    (rocprofv3 collects them in passes of their own), so the figure comes from the committed profile of this same command
+    (profiles/traffic.json <- tools/profile_step.sh + tools/update_traffic.py) and says so; `stale` = that profile was taken on
+    other kernel sources than the library loaded now."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        scale = n / float(tj.get("boards_per_launch_measured", 1 << 20))      # the kernel's traffic is linear in the board count
+        dec = tj.get("decomposed_estimate_bytes")
+        return {"traffic": tj["hbm_bytes_per_launch"] * scale, "traffic_decomposed": dec * scale if dec else None,
+                "traffic_stale": tj.get("source_digest") != library_digest(),
+                "traffic_source": f"NOT measured in this run: rocprofv3 --pmc passes of this command, {tj.get('source')} (commit "
+                                  f"{tj.get('commit')}, source digest {str(tj.get('source_digest'))[:12]}), scaled to {n} boards"}
+    except Exception:                 # noqa: BLE001
+        return {"traffic": None, "traffic_decomposed": None, "traffic_stale": None, "traffic_source": None}
+
+
+def compact(d):
+    """The ONE line of stdout from the full record `d`: the contract's keys, scalars only inside `config` / `roofline` /
+    `cpu_baseline` (a reader that truncates nested objects and long strings keeps every number), one number per side figure."""
+    def pick(src, keys):
+        return {k: src.get(k) for k in keys} if isinstance(src, dict) else src
+    ok = SideFigures.ok
+    out = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                             "vs_baseline", "dtype", "data")}
+    out["config"] = pick(d["config"], ("workload", "launch_mode", "global_boards", "boards_per_gpu", "L", "M", "parallelism"))
+    out["roofline"] = pick(d["roofline"], ("bound", "achieved", "peak", "unit", "frac", "frac_hbm_resident", "hbm_resident_working_set_bytes",
+                                           "frac_of_achievable_hbm", "traffic", "traffic_stale", "kernel", "kernel_ms", "kernel_ms_median",
+                                           "frac_median", "boards_per_launch", "algorithmic_bytes_per_launch"))
+    if "cpu_baseline" in d:
+        out["cpu_baseline"] = pick(d["cpu_baseline"], ("value", "unit", "cores", "cores_available", "cores_used", "limited_by", "cpu_model",
+                                                       "kind", "sample", "error"))
+    out["timing"] = pick(d["timing"], ("per_rank_ms_per_step", "host_call_us", "host_issue_us_per_step", "collective_ms", "wall_ms_per_step",
+                                       "launch_after_synchronize_ms"))
+    sm = d.get("scaling_model")
+    if ok(sm):
+        fused_key = next((k for k in sm if k.startswith("fused_")), None)
+        out["scaling_model"] = {"basis": "shards of the same 2^20-board job measured on THIS one GPU; efficiency = value_xN / (N x value_x1)",
+                                "per_launch": {k: pick(v, ("boards_per_gpu", "launch_mode", "us_per_step", "value", "efficiency"))
+                                               for k, v in sm["per_launch"].items()},
+                                fused_key: {k: pick(v, ("us_per_step", "value", "efficiency")) for k, v in sm[fused_key].items()},
+                                "weak_x8": pick(sm["weak"], ("value_x8", "efficiency"))}
+    side = {}
+    fr = d.get("fused_rollout")
+    if ok(fr):
+        side["fused_rollout"] = dict({"value": fr["value"], "steps_per_launch": fr["steps_per_launch"]},
+                                     **pick(fr["roofline"] or {}, ("bound", "frac", "frac_hw", "frac_of_lane_slots")))
+    for key, sub in (("shard_run", "tpl_step"), ("shard_run", "capture_steps"), ("shard_run", "tpl_rollout")):
+        if ok(d.get(key)):
+            side.setdefault(key, {"boards": d[key]["boards"]})[sub + "_us_per_step"] = d[key][sub]["us_per_step"]
+    for key in ("weak_scaling_job", "carved_pool_run", "config1_run", "actor_loop"):
+        if ok(d.get(key)):
+            side[key] = d[key].get("value")
+    if ok(d.get("live_supply_run")):
+        side["live_supply_run"] = pick(d["live_supply_run"], ("slowdown", "configurations_supplied_per_s", "pool_reuse_factor"))
+    if ok(d.get("config_supply")):
+        cd = d["config_supply"]["carve_device"]
+        side["config_supply_carve_device"] = dict({"value": cd["value"]}, **pick(cd["roofline"] or {}, ("frac", "frac_hw", "frac_of_lane_slots")))
+    out["side"] = side
+    out["side_figures"] = pick(d["side_figures"], ("failed", "skipped", "total_seconds", "abandoned"))
+    for k in ("mean_episodic_return", "episodes", "ranks_seen", "backend", "detail"):
+        out[k] = d.get(k)
+    return out
+
+
+def main():
+    args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, local = (int(os.environ.get(k, "0" if k != "WORLD_SIZE" else "1")) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` or under "
                  f"torch.distributed.run with --nproc-per-node equal to --gpus")
@@ -824,53 +195,39 @@ def main():
     import torch.distributed as dist
     import tetris_piclim as T
 
-    # TPL_BENCH_BACKEND=gloo and TPL_BENCH_ONE_GPU=1 exist only to rehearse the multi-rank path on a one-GPU box
+    # TPL_BENCH_BACKEND=gloo and TPL_BENCH_ONE_GPU=1 exist only to rehearse the multi-rank path on a one-GPU box;
+    # TPL_BENCH_FORCE_DIST=1 sends a ONE-rank run through the process group as an N-rank run (real RCCL on a one-GPU box)
     backend = os.environ.get("TPL_BENCH_BACKEND", "nccl")
     if os.environ.get("TPL_BENCH_ONE_GPU") == "1":
         local = 0
-    ctl = None
-    # TPL_BENCH_FORCE_DIST=1: a ONE-rank run goes through the process group as an N-rank run does (RCCL all-reduce / all-gather on
-    # device tensors, the gloo control group beside an "nccl" default group): the multi-rank plumbing on real RCCL, on a one-GPU box
+    ctl = ctl_note = None
     dist_on = world > 1 or os.environ.get("TPL_BENCH_FORCE_DIST") == "1"
-    ctl_note = None
     if dist_on:
         import datetime
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29541")
-            os.environ.setdefault("RANK", "0")
-            os.environ.setdefault("WORLD_SIZE", "1")
+            for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29541"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+                os.environ.setdefault(k, v)
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
         # the ranks' agreements around the side figures travel over a gloo group of HOST tensors (SideFigures); if that group
-        # cannot be made (it is the one piece of the N > 1 path no one-GPU box can try with more than one RCCL rank), the
-        # agreements fall back to the job's own group and device tensors -- the headline must not depend on it
+        # cannot be made, they fall back to the job's own group and device tensors -- the headline must not depend on it
         try:
             ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=max(600.0, 2 * args.side_timeout)))
-            probe = torch.zeros(1, dtype=torch.float64)
-            dist.all_reduce(probe, group=ctl)
+            dist.all_reduce(torch.zeros(1, dtype=torch.float64), group=ctl)
             ctl_note = "gloo group of host tensors"
         except Exception as e:        # noqa: BLE001
             ctl, ctl_note = None, f"the job's own group, device tensors (no gloo control group: {type(e).__name__}: {e})"[:300]
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    ranks_seen = dist.get_world_size() if dist_on else 1
-    backend_seen = dist.get_backend() if dist_on else None        # what the process group IS, not what was asked for
 
     def barrier():
         if dist_on:
             dist.barrier()
-
-    def max_over_ranks(x):
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
-        if dist_on:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
 
     def every_rank(x):
         t = torch.tensor([x], dtype=torch.float64, device=dev)
@@ -883,63 +240,45 @@ def main():
     side = SideFigures(world, rank, dist, ctl, budget_s=args.side_budget, inject=os.environ.get("TPL_BENCH_INJECT_FAILURE", ""),
                        gather=every_rank if (dist_on and ctl is None) else None, distributed=dist_on)
 
-    # BASELINE configs[2] (N = 1) / configs[3] (N > 1): ONE batch of `total` boards, sharded by global board index
+    # BASELINE configs[2] (N = 1) / configs[3] (N > 1): ONE batch of `total` boards, sharded by global board index; the same
+    # pool on every rank (entry e = synthetic configuration e), actions and assignment keyed by the GLOBAL board index: the
+    # N-GPU job is the one-GPU job sharded -- the same episodes and the same mean return for every N (tests/test_multi_rank_gpu.py)
     total, L, M, K, W = args.boards, args.L, args.M, args.steps, args.warmup
-    shard = T.sharding.strong_shard(rank, world, total)           # contiguous blocks of global board indices
-    n = shard.boards                                              # this rank's boards
-    figures = {"actor_loop": None, "config_supply": None, "config1_run": None, "weak_scaling_job": None, "shard_run": None}
-
-    def own_board_figures():
-        """The side figures that build boards of their own (never part of `value`), each under SideFigures' guard."""
-        if world == 1:
-            if args.actor_boards > 0:
-                figures["actor_loop"] = side.run("actor_loop", lambda: measure_actor_loop(torch, T, dev, L, M, args.actor_boards, args.seed))
-            if args.carved_pool > 0:
-                figures["config_supply"] = side.run("config_supply", lambda: measure_config_supply(torch, T, dev, L, M, args.seed))
-            if not args.no_config1:
-                figures["config1_run"] = side.run("config1_run", lambda: measure_config1(torch, T, dev, args.seed, args.chunk))
-            if args.shard_ranks > 1 and args.chunk > 0:
-                figures["shard_run"] = side.run("shard_run", lambda: measure_shard_run(torch, T, dev, L, M, args.seed, total,
-                                                                                          args.shard_ranks, args.chunk))
-        elif not args.no_weak_job:
-            got = side.run("weak_scaling_job", lambda: measure_weak_job(torch, T, dev, rank, world, L, M, total, args.seed, K))
-            if side.ok(got):          # every rank came through: only now are their numbers combined
-                got = weak_job_line(side.max_over_ranks(got["ms"]), got["steps"], total, got["global_boards"])
-            figures["weak_scaling_job"] = got
-
-    if args.side_figures_first:
-        own_board_figures()
-
-    pool = args.pool or total
-    env = T.BatchedTetris(L, M, n, device=dev, seed=args.seed, global_offset=shard.global_offset, auto_reset=True,
-                          assign="hash")
-    # the same pool on every rank (entry e = synthetic configuration e): with actions and assignment keyed by the
-    # global board index, the N-GPU job is the one-GPU job of `total` boards over this pool, sharded -- the same
-    # episodes and the same mean return for every N (tests/test_multi_rank_gpu.py)
+    shard = T.sharding.strong_shard(rank, world, total)
+    n, pool = shard.boards, args.pool or total
+    mode = launch_mode_for(world, n, args.launch_mode)
+    env = T.BatchedTetris(L, M, n, device=dev, seed=args.seed, global_offset=shard.global_offset, auto_reset=True, assign="hash")
     rows, pieces = env.synthetic_configs(pool, first=0)
     env.load_configs(rows, pieces)
     del rows, pieces
     env.reset()
-    # synthetic actions for every step, staged in HBM before timing (at most 4096 distinct steps = 4 GiB at 2^20
-    # boards; a longer run cycles through them).  No more rows than the W + K steps need: every megabyte written here
-    # is a megabyte of the boards and the pool pushed out of the Infinity Cache right before the clock starts.
+    # synthetic actions for every step, staged in HBM before timing (at most 4096 distinct steps; a longer run cycles).  No more
+    # rows than the W + K steps need: every megabyte written here pushes boards and pool out of the Infinity Cache
     S = min(max(W + K, 1), 4096)
     actions = torch.empty((S, n), dtype=torch.uint8, device=dev)
     for t in range(S):
         env.synthetic_actions(t, out=actions[t])
     reward = torch.empty(n, dtype=torch.float32, device=dev)
     done = torch.empty(n, dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize(dev)
-
-    # ---- the timed region: W untimed + exactly K timed steps, barrier + synchronize on both sides.  The LAST of the W
-    # warm-up steps is enqueued after the synchronize, directly ahead of the first timed launch (SURVEY 8d: "between two
-    # stream-synchronised hipEvents, excluding one warm-up"): a launch into a queue that has run dry pays the GPU's
-    # wake-up (20-160 us by how long it idled, tools/launch_probe.py), which is not a property of a step.
-    # NOTHING in here is guarded: a failure inside the timed region ends the run with a non-zero status (under
-    # torch.distributed.run that takes the other ranks down with it) -- an unmeasured headline must not look measured.
     rows_of = action_rows(actions)              # the row views, made once: at a shard's size the host's call rate is the period
+
+    # ---- the timed region: W untimed + exactly K timed steps, barrier + synchronize on both sides.  NOTHING in here is
+    # guarded: a failure ends the run with a non-zero status -- an unmeasured headline must not look measured.
     for t in range(max(W - 1, 0)):
         env.step_into(rows_of[t % S], reward, done)
+    replays = []
+    if mode == "graph":
+        # the K timed steps as captured graphs of <= GRAPH_STEPS step_kernel launches, step t on action row t as in eager mode;
+        # captured HERE (a capture runs nothing: snapshot, K enqueues into the graph, restore), replayed inside the region
+        g_max = min(GRAPH_STEPS, K)
+        rs = torch.empty((g_max, n), dtype=torch.float32, device=dev)
+        ds = torch.empty((g_max, n), dtype=torch.uint8, device=dev)
+        t = W
+        while t < W + K:
+            g = min(g_max, W + K - t)
+            replays.append(env.capture_steps([rows_of[(t + i) % S] for i in range(g)], rs[:g], ds[:g]))
+            replays[-1].prepare()
+            t += g
     T.sharding.mean_episodic_return(env.stats_tensor(), env.reward_params)   # load the reduction kernels / RCCL rings
     torch.cuda.synchronize(dev)
     barrier()
@@ -951,8 +290,14 @@ def main():
     if W >= 1:
         env.step_into(rows_of[(W - 1) % S], reward, done)        # warm-up step W of W: takes the idle queue's wake-up
     ev_a.record()
-    for t in range(W, W + K):
-        env.step_into(rows_of[t % S], reward, done)
+    h0 = time.perf_counter()
+    if mode == "graph":
+        for replay in replays:
+            replay()
+    else:
+        for t in range(W, W + K):
+            env.step_into(rows_of[t % S], reward, done)
+    h1 = time.perf_counter()
     ev_c.record()
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
@@ -962,223 +307,114 @@ def main():
     barrier()
     torch.cuda.synchronize(dev)
     t3 = time.perf_counter()
-    region_ms_rank = ev_a.elapsed_time(ev_c)
-    per_rank_ms = every_rank(region_ms_rank / K)
-    region_ms = max(per_rank_ms) * K                              # max over ranks
-    wake_ms = max_over_ranks(ev_w.elapsed_time(ev_a)) if W >= 1 else None    # the warm-up launch behind the synchronize
-    steady_ms = region_ms / K
-    wall_ms = max_over_ranks((t3 - t0) * 1e3)
-    collective_ms = max_over_ranks((t2 - t1) * 1e3)
+    host_issue_us = (h1 - h0) / K * 1e6
+    host_call_us = host_issue_us
+    if mode == "graph":                                           # what a tpl_step() call costs the host, measured apart
+        torch.cuda.synchronize(dev)
+        h0 = time.perf_counter()
+        for t in range(64):
+            env.step_into(rows_of[t % S], reward, done)
+        host_call_us = (time.perf_counter() - h0) / 64 * 1e6
+        torch.cuda.synchronize(dev)
+    per_rank_ms = every_rank(ev_a.elapsed_time(ev_c) / K)
+    steady_ms = max(per_rank_ms)                                  # max over ranks
+    wake_ms = max(every_rank(ev_w.elapsed_time(ev_a))) if W >= 1 else None
+    wall_ms, collective_ms = max(every_rank((t3 - t0) * 1e3)), max(every_rank((t2 - t1) * 1e3))
+    host_call_us, host_issue_us = max(every_rank(host_call_us)), max(every_rank(host_issue_us))
+    value = float(total) / (steady_ms * 1e-3)
 
-    # each rank's kernel priced on the boards of ITS shard
-    per_rank_roofline = []
+    per_rank_roofline = []                                        # each rank's kernel priced on the boards of ITS shard
     for r, ms_r in enumerate(per_rank_ms):
         nb = T.sharding.strong_shard(r, world, total).boards
         gbs = ALGO_BYTES_PER_BOARD_STEP * nb / (ms_r * 1e-3) / 1e9
         per_rank_roofline.append({"rank": r, "boards": nb, "kernel_ms": ms_r, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS})
 
-    # ---- the headline is complete from here on; everything below adds side keys to it and none of it can lose it
-    more = {"sustained": None, "fused_rollout": None, "carved_pool_run": None, "live_supply_run": None, "out_of_cache": None,
-            "cpu_baseline": None}
+    # ---- the headline is complete from here on; everything below adds side keys to the record and none of it can lose it
+    c = types.SimpleNamespace(torch=torch, T=T, dev=dev, args=args, side=side, rank=rank, world=world, total=total, n=n, L=L, M=M, K=K,
+                              W=W, S=S, env=env, actions=actions, reward=reward, done=done, value=value, ms_per_step=steady_ms,
+                              more={"sustained": None, "fused_rollout": None, "carved_pool_run": None, "live_supply_run": None,
+                                    "out_of_cache": None, "cpu_baseline": None},
+                              figures={"actor_loop": None, "config_supply": None, "config1_run": None, "weak_scaling_job": None,
+                                       "shard_run": None, "scaling_model": None})
+    detail_path = args.detail or os.path.join(ROOT, "gpurun_out", f"bench_detail_n{world}.json")
 
-    def line(abandoned=None):
-        """The one JSON line, from what has been measured so far (rank 0 only)."""
+    def record(abandoned=None):
+        """The full record, from what has been measured so far."""
+        more, figures = c.more, c.figures
         achieved = ALGO_BYTES_PER_BOARD_STEP * n / (steady_ms * 1e-3) / 1e9
-        # HBM bytes per launch by the PMC counters: these cannot be read from inside this process (rocprofv3 collects them
-        # in passes of their own), so the figure comes from the committed profile of this same command and says so
-        traffic = traffic_source = traffic_dec = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                # measured at 1,048,576 boards per launch; the kernel's traffic is linear in the board count
-                traffic = tj.get("hbm_bytes_per_launch") * (n / float(1 << 20))
-                if tj.get("decomposed_estimate_bytes"):
-                    traffic_dec = tj["decomposed_estimate_bytes"] * (n / float(1 << 20))
-                traffic_source = (f"NOT measured in this run: rocprofv3 --pmc passes of this command, {tj.get('source')}"
-                                  f" (commit {tj.get('commit')}, source digest {str(tj.get('source_digest'))[:12]}), scaled to {n} boards")
-            except Exception:         # noqa: BLE001
-                traffic = traffic_source = traffic_dec = None
-        sustained = more["sustained"] if side.ok(more["sustained"]) else None
+        tr = traffic_of(n)
+        sustained = more["sustained"] if side.ok(more["sustained"]) else {}
+        ooc = more["out_of_cache"] if side.ok(more["out_of_cache"]) else {}
+        what = f"{total} boards " + (f"sharded over {world} GPUs" if world > 1 else "on 1 GPU")
         out = {
-            "metric": "env-steps/sec (whole node) at 1M parallel 20x10 boards",
-            "value": float(total) * K / (region_ms * 1e-3),
-            "unit": "env-steps/s",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": W,
-            "ms_per_step": region_ms / K,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic",
-            "config": {"workload": f"{total} boards in total" + (f", batch-sharded over {world} GPUs ({n} on rank 0)" if world > 1 else " on 1 GPU")
-                                   + f", random initial configs, L={L} M={M}, uniform random actions, auto-reset from a "
-                                   f"{pool}-entry device pool (the same pool on every rank), one tpl_step launch per step "
-                                   + ("(BASELINE configs[3])" if world > 1 else "(BASELINE configs[2])"),
+            "metric": "env-steps/sec (whole node) at 1M parallel 20x10 boards", "value": value, "unit": "env-steps/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": steady_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"{what}, L={L} M={M}, random configs + actions, auto-reset, 1 launch/step ({mode}), "
+                                   f"BASELINE configs[{3 if world > 1 else 2}]",
+                       "workload_detail": f"{total} boards in total" + (f", batch-sharded over {world} GPUs ({n} on rank 0)" if world > 1 else " on 1 GPU")
+                                          + f", random initial configs, L={L} M={M}, uniform random actions, auto-reset from a {pool}-entry "
+                                          "device pool (the same pool on every rank), one tpl_step launch per step",
+                       "launch_mode": mode, "launch_mode_is": ("one tpl_step() call per step" if mode == "eager" else
+                                                               f"the same step_kernel launches, captured <= {GRAPH_STEPS} at a time and replayed "
+                                                               f"({len(replays)} graph(s) for the {K} timed steps)"),
                        "global_boards": total, "boards_per_gpu": n, "L": L, "M": M, "parallelism": f"batch-shard x{world}"},
-            "timing": {"clock": "HIP events on the launch stream around the K launches, max over ranks",
+            "timing": {"clock": "HIP events on the launch stream around the K steps, max over ranks",
                        "warmup_placement": f"{max(W - 1, 0)} warm-up step(s) before the synchronize, {min(W, 1)} after it directly "
                                            "ahead of the first timed launch (it takes the wake-up of the idle queue)",
                        "per_rank_ms_per_step": per_rank_ms, "wall_ms_per_step": wall_ms / K, "collective_ms": collective_ms,
-                       "launch_after_synchronize_ms": wake_ms,
-                       "order": "the timed region is the first GPU work of the process; the figures on the main boards (sustained pass, "
-                                "fused rollout, carved pool, live supply), the out-of-cache run, the side figures that own their boards "
-                                "(actor loop, config supply, configs[1], shard_run; the weak job for N > 1) and the C leg of the CPU "
-                                "baseline follow it (its NumPy leg runs in child processes before this process touches the GPU)",
-                       "note": "launch_after_synchronize_ms = the last warm-up launch, the one that finds the queue empty "
-                               "(outside the timed region); the K timed launches follow it back to back"},
-            "ranks_seen": ranks_seen,
-            "backend": backend_seen,
+                       "launch_after_synchronize_ms": wake_ms, "host_call_us": host_call_us, "host_issue_us_per_step": host_issue_us,
+                       "host_call_is": "what one tpl_step() call costs the host thread (max over ranks)"
+                                       + ("" if mode == "eager" else ", measured over 64 eager calls behind the region"),
+                       "host_bound": bool(host_issue_us > 0.9 * steady_ms * 1e3)},
+            "ranks_seen": dist.get_world_size() if dist_on else 1, "backend": dist.get_backend() if dist_on else None,
             "per_rank_roofline": per_rank_roofline,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         # counter bytes over the same launch period: what the memory system delivered, against the peak
-                         "frac_traffic": (traffic / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         # the same counters read request by request: 128-B requests for the coalesced streams, 64-B for
-                         # the gathers (the guide's formula doubles every read request)
-                         "traffic_decomposed": traffic_dec,
-                         "frac_traffic_decomposed": (traffic_dec / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic_dec else None,
-                         "out_of_cache": more["out_of_cache"],
-                         "kernel": "step_kernel<action, auto_reset>", "kernel_ms": steady_ms, "boards_per_launch": n,
-                         "priced_on": "rank 0's shard of the job over the slowest rank's launch period",
-                         "kernel_ms_source": "launch period over the K timed launches (HIP events on the launch stream)",
-                         "kernel_ms_mean": steady_ms,
-                         "kernel_ms_median": (sustained or {}).get("kernel_ms_median_of_50s"),
-                         "frac_median": (sustained or {}).get("frac"),
-                         "launch_after_synchronize_ms": wake_ms,
-                         "sustained": more["sustained"],
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_BOARD_STEP * n,
-                         "node": {"achieved": ALGO_BYTES_PER_BOARD_STEP * total / (steady_ms * 1e-3) / 1e9,
-                                  "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                                  "frac": ALGO_BYTES_PER_BOARD_STEP * total / (steady_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)}},
-            "fused_rollout": more["fused_rollout"],
-            "shard_run": figures["shard_run"],
-            "weak_scaling_job": figures["weak_scaling_job"],
-            "carved_pool_run": more["carved_pool_run"],
-            "live_supply_run": more["live_supply_run"],
-            "config1_run": figures["config1_run"],
-            "config_supply": figures["config_supply"],
-            "actor_loop": figures["actor_loop"],
-            "mean_episodic_return": mean_return if episodes else None,
-            "episodes": episodes,
-            "side_figures": dict(side.summary(), agreements_over=ctl_note, guard="each side figure runs under a guard (an exception becomes {\"error\": ...} under "
-                                 "its key; at N > 1 the ranks agree over a gloo group before and after each); the timed region is not guarded"),
+            "roofline": dict({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                              # the same kernel where NOTHING fits the 256 MiB Infinity Cache (2^23 boards + a 2^21-entry pool = 512 MiB):
+                              # `frac` above is helped by the cache (32 MB of state + 26 MB of action rows sit inside it)
+                              "frac_hbm_resident": ooc.get("frac"), "hbm_resident_working_set_bytes": ooc.get("resident_bytes"),
+                              "frac_of_achievable_hbm": achieved / HBM_ACHIEVABLE_GBS}, **tr,
+                             frac_traffic=(tr["traffic"] / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr["traffic"] else None,
+                             frac_traffic_decomposed=(tr["traffic_decomposed"] / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr["traffic_decomposed"] else None,
+                             out_of_cache=more["out_of_cache"], kernel="step_kernel<action, auto_reset>", kernel_ms=steady_ms, boards_per_launch=n,
+                             priced_on="rank 0's shard of the job over the slowest rank's launch period",
+                             kernel_ms_source="launch period over the K timed steps (HIP events on the launch stream)",
+                             kernel_ms_median=sustained.get("kernel_ms_median_of_50s"), frac_median=sustained.get("frac"),
+                             sustained=more["sustained"], algorithmic_bytes_per_launch=ALGO_BYTES_PER_BOARD_STEP * n,
+                             node={"achieved": ALGO_BYTES_PER_BOARD_STEP * total / (steady_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS * world,
+                                   "unit": "GB/s", "frac": ALGO_BYTES_PER_BOARD_STEP * total / (steady_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)}),
+            "fused_rollout": more["fused_rollout"], "scaling_model": figures["scaling_model"], "shard_run": figures["shard_run"],
+            "weak_scaling_job": figures["weak_scaling_job"], "carved_pool_run": more["carved_pool_run"],
+            "live_supply_run": more["live_supply_run"], "config1_run": figures["config1_run"], "config_supply": figures["config_supply"],
+            "actor_loop": figures["actor_loop"], "mean_episodic_return": mean_return if episodes else None, "episodes": episodes,
+            "side_figures": dict(side.summary(), agreements_over=ctl_note,
+                                 guard="each side figure runs under a guard (an exception becomes {\"error\": ...} under its key; at N > 1 the "
+                                       "ranks agree over a gloo group before and after each); the timed region is not guarded"),
+            "detail": None if detail_path == "-" else os.path.relpath(detail_path, ROOT),
         }
         if abandoned is not None:
             out["side_figures"]["abandoned"] = (f"'{abandoned}' was still running {args.side_timeout:.0f} s into the side figures "
-                                                "(--side-timeout): the line was printed by the watchdog with what had been measured")
+                                                f"(--side-timeout): line printed by the watchdog, exit status {WATCHDOG_STATUS}")
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = more["cpu_baseline"]
         return out
 
     def emit(abandoned=None):
-        if rank == 0:
-            print(json.dumps(line(abandoned)), flush=True)
+        if rank != 0:
+            return
+        full = record(abandoned)
+        if detail_path != "-":
+            try:
+                os.makedirs(os.path.dirname(detail_path) or ".", exist_ok=True)
+                with open(detail_path, "w") as f:
+                    json.dump(full, f, indent=1)
+            except OSError as e:
+                full["detail"] = f"not written: {e}"
+        print("BENCH_DETAIL " + json.dumps(full), file=sys.stderr, flush=True)
+        print(json.dumps(compact(full)), flush=True)
 
     side.watchdog(args.side_timeout, emit)
-
-    # ---- the same loop, sustained: `--sustained` launches with an event every 50, right after the timed region
-    def sustained_pass():
-        groups = args.sustained // 50
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(groups + 1)]
-        evs[0].record()
-        for g in range(groups):
-            for t in range(50):
-                env.step_into(actions[(g * 50 + t) % S], reward, done)
-            evs[g + 1].record()
-        torch.cuda.synchronize(dev)
-        per = [evs[g].elapsed_time(evs[g + 1]) / 50 for g in range(groups)]
-        return {"launches": groups * 50, "kernel_ms_mean_this_rank": evs[0].elapsed_time(evs[-1]) / (groups * 50),
-                "kernel_ms_median_of_50s": statistics.median(per), "kernel_ms_min_of_50s": min(per), "kernel_ms_max_of_50s": max(per)}
-    if args.sustained >= 100:
-        sustained = side.run("sustained", sustained_pass)
-        if side.ok(sustained):
-            sustained["kernel_ms_mean"] = side.max_over_ranks(sustained.pop("kernel_ms_mean_this_rank"))
-            sustained["value"] = float(total) / (sustained["kernel_ms_mean"] * 1e-3)
-            sustained["frac"] = ALGO_BYTES_PER_BOARD_STEP * n / (sustained["kernel_ms_median_of_50s"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-        more["sustained"] = sustained
-
-    # ---- side figures on the main boards (after the timed region)
-    def fused_figures():
-        """This rank's milliseconds per step in each form of the fused rollout (no collective in here)."""
-        nonlocal S, actions
-        if S < max(2 * args.chunk, 200):                          # the fused form wants whole chunks of distinct steps
-            S = max(2 * args.chunk, 200)
-            actions = torch.empty((S, n), dtype=torch.uint8, device=dev)
-            for t in range(S):
-                env.synthetic_actions(t, out=actions[t])
-        whole = S // args.chunk * args.chunk
-        ms = {"f32_u8": measure_fused_rollout(torch, T, env, actions, 0, whole, args.chunk),
-              # the same steps recorded as the compact trajectory (one byte per board-step, decoded on the learner's side)
-              "compact": measure_fused_rollout(torch, T, env, actions, 0, whole, args.chunk, compact=True),
-              # ... and with 200 steps per launch (a launch's fixed part -- the 64 B per board of state in and out, the launch
-              # gap -- is some 20 us: a quarter of a 50-step launch's step time, a fifteenth of a 200-step one's)
-              "compact_200": measure_fused_rollout(torch, T, env, actions, 0, 200, 200, compact=True),
-              "f32_u8_200": measure_fused_rollout(torch, T, env, actions, 0, 200, 200)}
-        # the same kernel under the uniform random policy drawn on the device (no actions staged, no per-step outputs)
-        env.rollout_random(100, seed=args.seed)
-        torch.cuda.synchronize(dev)
-        ms["device_random"] = timed(torch, dev, lambda: env.rollout_random(100, seed=args.seed), 4) / 100
-        return ms
-    if args.chunk > 0:
-        fused = side.run("fused_rollout", fused_figures)
-        if side.ok(fused):
-            ms = {k: side.max_over_ranks(v) for k, v in sorted(fused.items())}
-            fused = {"value": float(total) / (ms["f32_u8"] * 1e-3), "unit": "env-steps/s", "steps_per_launch": args.chunk,
-                     "ms_per_step": ms["f32_u8"], "outputs": "per-step reward f32 + done u8 written", "kernel": "rollout_kernel<auto_reset>",
-                     # priced on rank 0's boards over the slowest rank's time, like the headline's roofline
-                     "roofline": valu_roofline("rollout_f32_u8_50", float(n) / (ms["f32_u8"] * 1e-3)),
-                     "compact_trajectory": {"value": float(total) / (ms["compact"] * 1e-3), "ms_per_step": ms["compact"],
-                                            "roofline": valu_roofline("rollout_compact_50", float(n) / (ms["compact"] * 1e-3)),
-                                            "steps_per_launch": args.chunk,
-                                            "outputs": "one byte per board-step (rows cleared, how the move ended, reset, frozen), "
-                                                       "a dword per board every fourth step; tpl_decode_trajectory -> reward f32, done u8"},
-                     "at_200_steps_per_launch": {"compact_trajectory": float(total) / (ms["compact_200"] * 1e-3),
-                                                 "reward_f32_and_done_u8": float(total) / (ms["f32_u8_200"] * 1e-3)},
-                     "device_random_policy": {"value": float(total) / (ms["device_random"] * 1e-3), "ms_per_step": ms["device_random"],
-                                              "roofline": valu_roofline("rollout_random_100", float(n) / (ms["device_random"] * 1e-3)),
-                                              "steps_per_launch": 100, "outputs": "reward sums and episode counts only"}}
-        more["fused_rollout"] = fused
-    if args.carved_pool > 0 and world == 1:
-        more["carved_pool_run"] = side.run("carved_pool_run", lambda: measure_carved_pool(torch, T, env, actions, reward, done, W, K,
-                                                                                           args.carved_pool, args.seed))
-
-        def live_figures():
-            live = measure_live_supply(torch, T, env, actions, reward, done, args.seed)
-            # the same run by the generator's footprint: how many persistent waves share its queue, and -- the form the
-            # round-2 review asked for -- confined to 32 compute units by a CU-masked stream (which turns out to be the
-            # expensive way: profiles/r03_live_supply)
-            live["generator"] = ("PoolRefresher defaults: a plain side stream, pool-sized batches (one configuration per board), "
-                                 "the footprint its target_slowdown = 1.13 picks from the measured table")
-            keep = ("ms_per_step", "slowdown", "pool_swaps", "steps", "configurations_per_batch", "generator_waves",
-                    "configurations_supplied_per_s", "pool_reuse_factor")
-            live["by_generator_footprint"] = [
-                dict(generator=name, **{k: v for k, v in measure_live_supply(torch, T, env, actions, reward, done, args.seed, **kw).items() if k in keep})
-                for name, kw in (("256 waves, batches of 65,536 (the default through round 4)", dict(waves=256, count=65536)),
-                                 ("1024 waves, pool-sized batches", dict(waves=1024)), ("512 waves, pool-sized batches", dict(waves=512)),
-                                 ("64 waves, batches of 65,536", dict(waves=64, count=65536)),
-                                 ("256 waves on a 32-CU stream, batches of 65,536", dict(waves=256, count=65536, reserved_cus=32)))]
-            return live
-        more["live_supply_run"] = side.run("live_supply_run", live_figures)
-    try:
-        env.terminate()
-    except Exception:                 # noqa: BLE001 -- a side figure may have left the handle in a state it cannot be destroyed from
-        pass
-    del actions
-    if world == 1 and not args.no_out_of_cache:
-        more["out_of_cache"] = side.run("out_of_cache", lambda: measure_out_of_cache(torch, T, dev, L, M, args.seed))
-    # ---- side figures that own their boards (never part of `value`): last, so that the timed region is the first thing the GPU
-    # does in this process (behind the matrix kernels of the actor loop the same twenty steps read 0.2 us a step slower)
-    if not args.side_figures_first:
-        own_board_figures()
-    if rank == 0 and not args.no_cpu_baseline:
-        # rank 0's host cores, after every collective of the job (the other ranks are on their way out)
-        try:
-            more["cpu_baseline"] = cpu_baseline(L, M, args.seed, numpy_leg)
-        except Exception as e:        # noqa: BLE001
-            more["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+    B.after_the_timed_region(c, numpy_leg)
     side.disarm()
     emit()
     if dist_on:

@@ -204,7 +204,11 @@ def check(status: int) -> None:
 
 def cpu_budget() -> int:
     """Host threads worth starting: the affinity mask, capped by the cgroup CPU quota when there is one (a
-    container that sees 256 CPUs but may use 16 of them runs slower with 256 threads than with 16)."""
+    container that sees 256 CPUs but may use 16 of them runs slower with 256 threads than with 16); TPL_CPU_BUDGET=<n>
+    overrides both."""
+    override = os.environ.get("TPL_CPU_BUDGET", "")
+    if override.isdigit() and int(override) >= 1:
+        return int(override)
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]

@@ -322,8 +322,10 @@ class BatchedTetris:
         steps (the boards move on; refill the action rows in between).  For batches small enough that the host's few
         microseconds per step_into() call are the limit (65,536 boards: 6.3 -> 5.0 us per step); at 2^20 boards it
         changes nothing.  The graph carries the pool pointers of the moment of capture: the callable captures again by
-        itself after a load_configs()."""
-        K = actions.shape[0]
+        itself after a load_configs().  `actions` may also be a sequence of K row tensors (rows that are not neighbours in
+        memory); `replay.prepare()` captures ahead of the first replay (a capture costs a snapshot, a restore and K enqueues:
+        not something to leave inside a timed region)."""
+        K = len(actions)
         for t in range(K):
             self._own(actions[t], _INT_CODES, "actions[t]")
             self._own(rewards[t], torch.float32, "rewards[t]")
@@ -353,6 +355,12 @@ class BatchedTetris:
             # the library counts steps as they pass through its API (the pool-swap guard); a replay does not: tell it
             check(self._lib.tpl_note_steps(self._h, K))
 
+        def prepare():
+            if state["pool"] != self.pool_generation:
+                capture()
+
+        replay.prepare = prepare
+        replay.steps = K
         return replay
 
     def step(self, action, observe: bool = True, obs_dtype=torch.float32):

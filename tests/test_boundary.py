@@ -136,6 +136,6 @@ def test_generator_work_memory_is_sized_by_lanes_not_by_configurations():
 
 
 def test_bench_names_the_host_cpu():
-    import bench
+    import bench_side as bench
     model = bench.cpu_model()
     assert model is None or (isinstance(model, str) and model.strip())

@@ -57,19 +57,38 @@ def test_two_hip_ranks_equal_one_process_and_the_oracle(tmp_path, oracle, mode):
 
 
 def _bench(gpus, extra=(), boards=65536, inject=None, base=("--sustained", "100", "--actor-boards", "0", "--carved-pool", "0",
-                                                             "--no-config1", "--no-out-of-cache")):
-    env = dict(os.environ, TPL_BENCH_ONE_GPU="1", TPL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    env.pop("RANK", None)
-    env.pop("WORLD_SIZE", None)
+                                                             "--no-config1", "--no-out-of-cache"), env_more=None, rehearsal=True):
+    """One run of bench.py; returns the FULL record (--detail) after checking what stdout carries: exactly ONE JSON line, the
+    compact form of that record, with the contract's keys."""
+    import tempfile
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TPL_BENCH_BACKEND", "TPL_BENCH_ONE_GPU", "TPL_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    if rehearsal:                                 # several ranks on this box's one GPU, over gloo
+        env.update(TPL_BENCH_ONE_GPU="1", TPL_BENCH_BACKEND="gloo")
     if inject:
         env["TPL_BENCH_INJECT_FAILURE"] = inject
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "20", "--warmup", "5", "--boards", str(boards),
-           *base, *extra]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    env.update(env_more or {})
+    with tempfile.TemporaryDirectory() as tmp:
+        detail = os.path.join(tmp, "detail.json")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "20", "--warmup", "5", "--boards", str(boards),
+               "--detail", detail, *base, *extra]
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+        full = json.load(open(detail))
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, lines                 # ONE JSON line, whatever happened to the side figures
-    return json.loads(lines[0])
+    assert len(lines) == 1, lines                 # ONE JSON line on stdout, whatever happened to the side figures
+    line = json.loads(lines[0])
+    assert len(lines[0]) < 6000
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[k] == full[k], k
+    assert line["config"]["workload"] == full["config"]["workload"] and len(line["config"]["workload"]) <= 128
+    assert line["config"]["launch_mode"] == full["config"]["launch_mode"] and line["roofline"]["frac"] == full["roofline"]["frac"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "frac_hbm_resident"} <= set(line["roofline"])
+    assert line["timing"]["host_call_us"] == full["timing"]["host_call_us"] > 0
+    assert line["episodes"] == full["episodes"] and line["mean_episodic_return"] == full["mean_episodic_return"]
+    assert [l for l in res.stderr.splitlines() if l.startswith("BENCH_DETAIL {")]
+    return full
 
 
 @pytest.mark.gpu
@@ -84,8 +103,12 @@ def test_bench_gpus_2_headline_is_the_one_gpu_job_sharded():
     assert out["steps"] == 20 and out["warmup"] == 5 and len(out["timing"]["per_rank_ms_per_step"]) == 2
     assert out["scaling"] == "strong"
     cfg = out["config"]
-    assert cfg["global_boards"] == 65536 and cfg["boards_per_gpu"] == 32768 and "65536 boards in total" in cfg["workload"]
-    assert "configs[3]" in cfg["workload"]
+    assert cfg["global_boards"] == 65536 and cfg["boards_per_gpu"] == 32768 and "65536 boards sharded over 2 GPUs" in cfg["workload"]
+    assert "configs[3]" in cfg["workload"] and "65536 boards in total" in cfg["workload_detail"]
+    # below 2^19 boards per GPU an N > 1 run replays captured graphs (one step_kernel launch per step all the same): the
+    # host's cost per step of the timed loop is then a fraction of a tpl_step() call's
+    assert cfg["launch_mode"] == "graph" and "(graph)" in cfg["workload"] and "1 graph(s) for the 20 timed steps" in cfg["launch_mode_is"]
+    assert 0 < out["timing"]["host_issue_us_per_step"] < out["timing"]["host_call_us"]
     assert [(r["rank"], r["boards"]) for r in out["per_rank_roofline"]] == [(0, 32768), (1, 32768)]
     assert all(r["frac"] > 0 for r in out["per_rank_roofline"])
     # value = GLOBAL boards x steps / time (never boards-per-GPU x ranks of a larger job)
@@ -100,6 +123,8 @@ def test_bench_gpus_2_headline_is_the_one_gpu_job_sharded():
     assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] >= 1 and out["cpu_baseline"]["cpu_model"]
     one = _bench(1, ["--no-cpu-baseline", "--shard-ranks", "2"])
     assert one["n_gpus"] == 1 and one["backend"] is None and one["scaling"] == "strong"
+    assert one["config"]["launch_mode"] == "eager" and "(eager)" in one["config"]["workload"]      # N = 1 is always the plain line
+    assert one["timing"]["host_issue_us_per_step"] == one["timing"]["host_call_us"]
     assert one["config"]["global_boards"] == 65536 and one["config"]["boards_per_gpu"] == 65536
     assert "configs[2]" in one["config"]["workload"] and one["weak_scaling_job"] is None
     assert out["episodes"] > 65536
@@ -114,8 +139,21 @@ def test_bench_gpus_2_headline_is_the_one_gpu_job_sharded():
     # the multi-step kernel is priced by vector-instruction issue, not by the 96 B a step it does not move
     fused_leg = sr["tpl_rollout"]
     assert fused_leg["us_per_step"] < sr["tpl_step"]["us_per_step"] and "frac" not in fused_leg
-    assert fused_leg["roofline"]["bound"] == "valu-issue" and 0 < fused_leg["roofline"]["frac"] < 1
-    assert one["fused_rollout"]["roofline"]["bound"] == "valu-issue" and 0 < one["fused_rollout"]["roofline"]["frac"] < 1
+    for r in (fused_leg["roofline"], one["fused_rollout"]["roofline"]):
+        assert r["bound"] == "valu-issue" and 0 < r["frac_of_lane_slots"] <= r["frac_hw"] <= r["frac"] < 1
+    # the scaling model of the one-GPU line: the 2- and 4-rank shards of THIS job measured on this GPU, value = global boards / period
+    sm = one["scaling_model"]
+    assert set(sm["per_launch"]) == {"x2", "x4"} and sm["per_launch"]["x2"]["boards_per_gpu"] == 32768
+    assert sm["per_launch"]["x2"]["launch_mode"] == "graph"
+    assert sm["per_launch"]["x2"]["us_per_step"] == sr["capture_steps"]["us_per_step"]
+    for k, leg in sm["per_launch"].items():
+        assert leg["value"] == pytest.approx(65536 / (leg["us_per_step"] * 1e-6), rel=1e-9)
+        assert leg["efficiency"] == pytest.approx(leg["value"] / (int(k[1:]) * one["value"]), rel=1e-9)
+    # the eager form of the same two-rank run: the same job again (same episodes, same mean return)
+    eager = _bench(2, ["--no-cpu-baseline", "--launch-mode", "eager", "--no-weak-job"])
+    assert eager["config"]["launch_mode"] == "eager"
+    for k in ("episodes", "mean_episodic_return"):
+        assert eager[k] == one[k], k
 
 
 @pytest.mark.gpu
@@ -131,6 +169,7 @@ def test_bench_sharded_job_of_1048576_boards_on_four_ranks_is_the_one_gpu_job():
     assert all(0 < r["frac"] < 1 for r in out["per_rank_roofline"])
     assert out["config"]["global_boards"] == 1 << 20 and out["config"]["boards_per_gpu"] == 262144
     assert out["value"] == pytest.approx((1 << 20) / (out["ms_per_step"] * 1e-3), rel=1e-9)
+    assert out["config"]["launch_mode"] == "graph" and out["timing"]["host_call_us"] > 0       # 262,144 boards per GPU: below 2^19
     assert out["fused_rollout"] is None and out["weak_scaling_job"] is None and "cpu_baseline" not in out
     assert out["side_figures"]["failed"] == [] and out["side_figures"]["seconds"] == {}
     one = _bench(1, boards=1 << 20, base=("--no-side-figures", "--no-cpu-baseline"))
@@ -162,15 +201,8 @@ def test_bench_one_rank_through_rccl_and_the_gloo_control_group():
     path -- barriers, the all-reduce of the return counters, the all-gather of the ranks' times, SideFigures' agreements -- through
     them.  (Two RCCL ranks cannot share one GPU, so this is the only way the nccl + gloo combination runs before an 8-GPU node
     does.)  The line must be the plain one-GPU line's job."""
-    env = dict(os.environ, TPL_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TPL_BENCH_BACKEND", "TPL_BENCH_ONE_GPU"):
-        env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--boards", "65536",
-           "--sustained", "100", "--actor-boards", "0", "--carved-pool", "0", "--no-config1", "--no-out-of-cache", "--shard-ranks", "0",
-           "--no-cpu-baseline"]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
-    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
-    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    out = _bench(1, ["--no-cpu-baseline", "--shard-ranks", "0"], rehearsal=False,
+                 env_more=dict(TPL_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())))
     assert out["backend"] == "nccl" and out["ranks_seen"] == 1 and out["n_gpus"] == 1
     assert out["side_figures"]["agreements_over"] == "gloo group of host tensors" and out["side_figures"]["failed"] == []
     assert out["fused_rollout"]["value"] > 0 and out["roofline"]["sustained"]["launches"] == 100

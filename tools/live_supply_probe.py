@@ -23,7 +23,7 @@ def main():
     args = ap.parse_args()
     import torch
     import tetris_piclim as T
-    import bench
+    import bench_side as bench
     n, dev = args.boards, torch.device("cuda", 0)
     env = T.BatchedTetris(10, 40, n, device=dev, auto_reset=True)
     S = 64
