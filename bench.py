@@ -127,15 +127,16 @@ def traffic_of(n):
 def compact(d):
     """The ONE line of stdout from the full record `d`: the contract's keys, scalars only inside `config` / `roofline` /
     `cpu_baseline` (a reader that truncates nested objects and long strings keeps every number), one number per side figure."""
-    def pick(src, keys):
-        return {k: src.get(k) for k in keys} if isinstance(src, dict) else src
+    def pick(src, keys, always=()):
+        return {k: src.get(k) for k in keys if k in src or k in always} if isinstance(src, dict) else src
     ok = SideFigures.ok
     out = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                              "vs_baseline", "dtype", "data")}
     out["config"] = pick(d["config"], ("workload", "launch_mode", "global_boards", "boards_per_gpu", "L", "M", "parallelism"))
     out["roofline"] = pick(d["roofline"], ("bound", "achieved", "peak", "unit", "frac", "frac_hbm_resident", "hbm_resident_working_set_bytes",
-                                           "frac_of_achievable_hbm", "traffic", "traffic_stale", "kernel", "kernel_ms", "kernel_ms_median",
-                                           "frac_median", "boards_per_launch", "algorithmic_bytes_per_launch"))
+                                           "traffic", "traffic_stale", "frac_traffic", "kernel", "kernel_ms", "kernel_ms_median",
+                                           "frac_median", "boards_per_launch", "algorithmic_bytes_per_launch"),
+                           always=("frac_hbm_resident", "traffic", "traffic_stale"))
     if "cpu_baseline" in d:
         out["cpu_baseline"] = pick(d["cpu_baseline"], ("value", "unit", "cores", "cores_available", "cores_used", "limited_by", "cpu_model",
                                                        "kind", "sample", "error"))
@@ -373,7 +374,9 @@ def main():
                               # the same kernel where NOTHING fits the 256 MiB Infinity Cache (2^23 boards + a 2^21-entry pool = 512 MiB):
                               # `frac` above is helped by the cache (32 MB of state + 26 MB of action rows sit inside it)
                               "frac_hbm_resident": ooc.get("frac"), "hbm_resident_working_set_bytes": ooc.get("resident_bytes"),
-                              "frac_of_achievable_hbm": achieved / HBM_ACHIEVABLE_GBS}, **tr,
+                              # what the memory system DELIVERED (counter bytes / period) against the ~6.3 TB/s a streaming kernel reaches
+                              "traffic_rate_over_achievable_hbm": (tr["traffic"] / (steady_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS) if tr["traffic"] else None},
+                             **tr,
                              frac_traffic=(tr["traffic"] / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr["traffic"] else None,
                              frac_traffic_decomposed=(tr["traffic_decomposed"] / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr["traffic_decomposed"] else None,
                              out_of_cache=more["out_of_cache"], kernel="step_kernel<action, auto_reset>", kernel_ms=steady_ms, boards_per_launch=n,

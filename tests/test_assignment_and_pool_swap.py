@@ -537,8 +537,9 @@ def test_pool_refresher_drops_capped_batches_goes_on_and_stops_after_three_in_a_
     cut-offs.  By the oracle, batches 0 and 1 of 512 hold such configurations, 2-4 do not, 5-7 do.  poll() drops a capped batch
     (said once, naming L, M and the cut-off), keeps the pool, starts the next; a clean batch is swapped in; after
     `max_capped_batches` = 3 capped batches IN A ROW the refresher stops instead of burning the generator's worst case beside
-    the loop for ever (round-4 advisor finding).  `strict=True` raises at the first capped batch.  An (L, M) whose pilot does
-    not finish is refused at construction."""
+    the loop for ever (round-4 advisor finding).  `strict=True` raises at the first capped batch.  An (L, M, cut-off) under which
+    NONE of the pilot configurations finishes is refused at construction -- one capped pilot alone refuses nothing (round-5
+    advisor finding; tests/test_config_supply.py::test_one_capped_pilot_...)."""
     import warnings
     import torch
     L, M, n, count, cutoff, seed = 8, 40, 2048, 512, 2, 1
@@ -569,8 +570,10 @@ def test_pool_refresher_drops_capped_batches_goes_on_and_stops_after_three_in_a_
             env.step(env.synthetic_actions(t), observe=False)
             strict.poll()
     strict.close()
-    with pytest.raises(T.TplError, match="pilot"):
-        T.PoolRefresher(env, count, seed=seed, cutoff=1)
+    env.terminate()
+    env = T.BatchedTetris(10, 12, 64, seed=1)
+    with pytest.raises(T.TplError, match="none of the 4 pilot configurations"):
+        T.PoolRefresher(env, 128, seed=seed, cutoff=1)
     env.terminate()
     env = T.BatchedTetris(16, 6, 64, seed=1)
     with pytest.raises(T.TplError, match="at least 8"):          # two shafts through sixteen rows take eight pieces

@@ -191,7 +191,7 @@ def test_compact_line_keeps_the_contract_keys_and_fits_a_truncating_reader():
             "timing": {"clock": "...", "per_rank_ms_per_step": [0.01568], "host_call_us": 5.0, "host_issue_us_per_step": 5.0, "collective_ms": 0.1,
                        "wall_ms_per_step": 0.02, "launch_after_synchronize_ms": 0.06, "note": "y" * 300},
             "roofline": dict({"bound": "hbm", "achieved": 6400.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.80, "frac_hbm_resident": 0.77,
-                              "hbm_resident_working_set_bytes": 1 << 29, "frac_of_achievable_hbm": 1.02, "kernel": "step_kernel<action, auto_reset>",
+                              "hbm_resident_working_set_bytes": 1 << 29, "kernel": "step_kernel<action, auto_reset>",
                               "kernel_ms": 0.01568, "kernel_ms_median": 0.0152, "frac_median": 0.83, "boards_per_launch": 1 << 20,
                               "algorithmic_bytes_per_launch": 96 << 20, "sustained": {"launches": 2000}, "out_of_cache": {"frac": 0.77}}, **tr),
             "cpu_baseline": {"value": 4e8, "unit": "env-steps/s", "cores": 16, "cores_available": 128, "cores_used": 16,
@@ -224,7 +224,15 @@ def test_compact_line_keeps_the_contract_keys_and_fits_a_truncating_reader():
     assert line["roofline"]["frac"] == 0.80 and line["roofline"]["frac_hbm_resident"] == 0.77 and line["roofline"]["traffic_stale"] in (True, False)
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
     assert {"value", "unit", "cores", "kind", "sample", "cores_available", "cores_used", "limited_by"} <= set(line["cpu_baseline"])
-    assert line["timing"]["host_call_us"] == 5.0
+    assert line["timing"]["host_call_us"] == 5.0 and "error" not in line["cpu_baseline"]
+
+    def fractions(node, path=""):                                   # no fraction anywhere in the line exceeds 1
+        for k, v in (node.items() if isinstance(node, dict) else []):
+            if isinstance(v, dict):
+                yield from fractions(v, path + k + ".")
+            elif isinstance(v, (int, float)) and not isinstance(v, bool) and (k.startswith("frac") or k == "efficiency"):
+                yield path + k, v
+    assert all(0 <= v <= 1 for _, v in fractions(line)), list(fractions(line))
     assert line["scaling_model"]["per_launch"]["x8"] == {"boards_per_gpu": 131072, "launch_mode": "graph", "us_per_step": 5.1, "value": 2.05e11,
                                                          "efficiency": 0.38}
     assert line["side"]["fused_rollout"]["frac_hw"] == 0.33 and line["side"]["actor_loop"] == 1.67e9 and "carved_pool_run" not in line["side"]

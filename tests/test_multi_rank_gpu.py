@@ -57,7 +57,7 @@ def test_two_hip_ranks_equal_one_process_and_the_oracle(tmp_path, oracle, mode):
 
 
 def _bench(gpus, extra=(), boards=65536, inject=None, base=("--sustained", "100", "--actor-boards", "0", "--carved-pool", "0",
-                                                             "--no-config1", "--no-out-of-cache"), env_more=None, rehearsal=True):
+                                                             "--no-config1", "--no-out-of-cache"), env_more=None, rehearsal=True, steps=20):
     """One run of bench.py; returns the FULL record (--detail) after checking what stdout carries: exactly ONE JSON line, the
     compact form of that record, with the contract's keys."""
     import tempfile
@@ -71,7 +71,7 @@ def _bench(gpus, extra=(), boards=65536, inject=None, base=("--sustained", "100"
     env.update(env_more or {})
     with tempfile.TemporaryDirectory() as tmp:
         detail = os.path.join(tmp, "detail.json")
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "20", "--warmup", "5", "--boards", str(boards),
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", str(steps), "--warmup", "5", "--boards", str(boards),
                "--detail", detail, *base, *extra]
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
         assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
@@ -154,6 +154,22 @@ def test_bench_gpus_2_headline_is_the_one_gpu_job_sharded():
     assert eager["config"]["launch_mode"] == "eager"
     for k in ("episodes", "mean_episodic_return"):
         assert eager[k] == one[k], k
+
+
+@pytest.mark.gpu
+def test_bench_graph_mode_with_a_remainder_graph_is_the_eager_job():
+    """70 timed steps in graph mode = one graph of 50 step_kernel launches and one of 20, step t on action row t: the same
+    episodes and mean return as 70 eager tpl_step() calls -- on two ranks (where graph mode is the default below 2^19 boards per
+    GPU) and forced on one."""
+    quiet = ("--no-side-figures", "--no-cpu-baseline")
+    eager = _bench(1, boards=65536, base=quiet, steps=70)
+    assert eager["config"]["launch_mode"] == "eager" and eager["steps"] == 70
+    for gpus, extra in ((2, ()), (1, ("--launch-mode", "graph"))):
+        out = _bench(gpus, extra, boards=65536, base=quiet, steps=70)
+        assert out["config"]["launch_mode"] == "graph" and "2 graph(s) for the 70 timed steps" in out["config"]["launch_mode_is"]
+        assert out["steps"] == 70 and out["value"] == pytest.approx(65536 / (out["ms_per_step"] * 1e-3), rel=1e-9)
+        for k in ("episodes", "mean_episodic_return"):
+            assert out[k] == eager[k], (gpus, k)
 
 
 @pytest.mark.gpu
