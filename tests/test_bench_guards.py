@@ -248,3 +248,17 @@ def test_cpu_limits_name_what_bounds_the_baseline_threads(monkeypatch):
     monkeypatch.setenv("TPL_CPU_BUDGET", "3")
     lim = bench_side.cpu_limits()
     assert lim["cores_used"] == 3 and lim["limited_by"] == "TPL_CPU_BUDGET=3"
+
+
+def test_committed_counter_profiles_were_taken_on_these_kernel_sources():
+    """`roofline.traffic` and the per-unit instruction counts of the `valu-issue` rooflines come from committed rocprofv3 counter
+    passes (PMC counters cannot be read from inside the bench process): they must be OF THIS LIBRARY -- the digest of the kernel
+    sources stamped into profiles/traffic.json and into every form of profiles/valu_issue.json is the digest of csrc/ + include/ as
+    they stand (a kernel change without a new `tools/profile_step.sh` / `tools/profile_valu.sh` run fails here; at run time the
+    line's `roofline.traffic_stale` / `count_stale` say the same about the loaded library)."""
+    import tetris_piclim as T
+    digest = T._lib._source_digest()
+    traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert traffic["source_digest"] == digest, "profiles/traffic.json was measured on other kernel sources: run tools/profile_step.sh + tools/update_traffic.py"
+    for name, f in json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))["forms"].items():
+        assert f["stamp"]["source_digest"] == digest and f["stamp"]["library_built_from_these_sources"], name
