@@ -335,7 +335,7 @@ def measure_fused_rollout(torch, T, env, actions, first, K, chunk, compact=False
 def action_rows(actions):
     """The rows of an [S, n] action tensor as S views made ONCE.  `actions[t]` inside a loop builds a new view object per step
     (0.8 us of Python): nothing at 2^20 boards, a seventh of the period at a shard's 131,072, where the host's calls per second
-    are the limit (tools/step_issue_rate.py, tools/step_issue_breakdown.py) -- and no part of what is being measured."""
+    are the limit (`timing.host_call_us`; profiles/NOTES.md, round-4 host issue-rate table) -- and no part of what is being measured."""
     return list(actions.unbind(0))
 
 
@@ -463,7 +463,8 @@ def scaling_model(shard_runs, total, value_x1, us_x1, fused_value_x1, chunk):
         us = run["tpl_step" if mode == "eager" else "capture_steps"]["us_per_step"]
         value = float(total) / (us * 1e-6)
         per_launch[f"x{ranks}"] = {"boards_per_gpu": run["boards"], "launch_mode": mode, "us_per_step": us, "value": value,
-                                   "efficiency": value / (ranks * value_x1), "host_call_us": run["tpl_step"]["host_call_us"]}
+                                   "efficiency": value / (ranks * value_x1), "host_call_us": run["tpl_step"]["host_call_us"],
+                                   "eager_us_per_step": run["tpl_step"]["us_per_step"], "graph_us_per_step": run["capture_steps"]["us_per_step"]}
         us_f = run["tpl_rollout"]["us_per_step"]
         fused[f"x{ranks}"] = {"us_per_step": us_f, "value": float(total) / (us_f * 1e-6),
                               "efficiency": (float(total) / (us_f * 1e-6)) / (ranks * fused_value_x1) if fused_value_x1 else None}
