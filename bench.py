@@ -173,10 +173,26 @@ def compact(d):
     return out
 
 
+def only_the_line_on_stdout():
+    """From here on file descriptor 1 is stderr's: whatever a library prints on stdout while this process runs -- gloo's
+    "[Gloo] Rank 0 is connected to 1 peer ranks" at every group creation, a runtime's warnings -- lands on stderr, and the ONE
+    JSON line goes out through the returned writer on the real stdout."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+
+    def write(text):
+        data = (text + "\n").encode()
+        while data:
+            data = data[os.write(real, data):]
+    return write
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args))
+    write_line = only_the_line_on_stdout()
     world, rank, local = (int(os.environ.get(k, "0" if k != "WORLD_SIZE" else "1")) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` or under "
@@ -414,7 +430,7 @@ def main():
             except OSError as e:
                 full["detail"] = f"not written: {e}"
         print("BENCH_DETAIL " + json.dumps(full), file=sys.stderr, flush=True)
-        print(json.dumps(compact(full)), flush=True)
+        write_line(json.dumps(compact(full)))
 
     side.watchdog(args.side_timeout, emit)
     B.after_the_timed_region(c, numpy_leg)

@@ -76,8 +76,8 @@ def _bench(gpus, extra=(), boards=65536, inject=None, base=("--sustained", "100"
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
         assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
         full = json.load(open(detail))
-    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, lines                 # ONE JSON line on stdout, whatever happened to the side figures
+    lines = res.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), lines   # ONE line on stdout and nothing else (gloo's chatter goes to stderr)
     line = json.loads(lines[0])
     assert len(lines[0]) < 6000
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
