@@ -144,12 +144,14 @@ def compact(d):
                                        "launch_after_synchronize_ms"))
     sm = d.get("scaling_model")
     if ok(sm):
-        fused_key = next((k for k in sm if k.startswith("fused_")), None)
-        out["scaling_model"] = {"basis": "shards of the same 2^20-board job measured on THIS one GPU; efficiency = value_xN / (N x value_x1)",
-                                "per_launch": {k: pick(v, ("boards_per_gpu", "launch_mode", "us_per_step", "value", "efficiency"))
-                                               for k, v in sm["per_launch"].items()},
-                                fused_key: {k: pick(v, ("us_per_step", "value", "efficiency")) for k, v in sm[fused_key].items()},
-                                "weak_x8": pick(sm["weak"], ("value_x8", "efficiency"))}
+        # twelve numbers: period, implied value and efficiency of a 2-, 4- and 8-GPU run of this job at one launch per step, the 8-GPU
+        # figure with `chunk` steps per launch, the weak-scaling counterpart (boards per GPU and launch modes: the detail record)
+        fused = sm[next(k for k in sm if k.startswith("fused_"))]
+        top = max(sm["per_launch"], key=lambda k: int(k[1:]), default=None)
+        out["scaling_model"] = {"basis": "shards of this 2^20-board job measured on THIS one GPU; value = boards / period, efficiency = value_xN / (N x value_x1)",
+                                "per_launch": {k: pick(v, ("us_per_step", "value", "efficiency")) for k, v in sm["per_launch"].items()},
+                                f"fused_{top}": pick(fused.get(top, {}), ("value", "efficiency")),
+                                "weak_x8_value": sm["weak"]["value_x8"]}
     side = {}
     fr = d.get("fused_rollout")
     if ok(fr):

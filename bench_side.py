@@ -34,6 +34,11 @@ def library_digest():
     try:
         return open(os.path.join(ROOT, "lib", "libtetris_piclim.so.sha256")).read().strip()
     except OSError:
+        pass
+    try:                                  # no stamp beside the library: the digest of the sources as they stand
+        import tetris_piclim as T
+        return T._lib._source_digest()
+    except Exception:                     # noqa: BLE001
         return None
 
 

@@ -295,9 +295,10 @@ int tpl_set_tuning(tpl_env* env, int32_t boards_per_lane, int32_t block_threads)
  * configuration, 0 = unbounded.  It is now the restart rule's base cut-off, 0 = by L: a caller written against the old meaning
  * gets different configurations (the type is the same, nothing fails); tpl_version() tells the two apart.
  * The output depends on (L, M, seed, first+i, cutoff) only -- not on `threads`, and it is the same on the device.  Before a
- * batch goes out ONE fixed configuration is tried on the host (the verdict is kept per (L, M, cutoff)): TPL_ERR_ARG when M is
- * below the fewest pieces that can dig two columns of L cells (ceil(L / 2)), TPL_ERR_STATE when all of its 24 attempts run
- * into their cut-offs -- nothing is generated then.  If all 24 attempts of a configuration of the batch run into their
+ * batch goes out FOUR fixed pilot configurations are tried on the host (the verdict is kept per (L, M, cutoff)): TPL_ERR_ARG when M
+ * is below the fewest pieces that can dig two columns of L cells (ceil(L / 2)), TPL_ERR_STATE when the 24 attempts of EVERY pilot run
+ * into their cut-offs -- nothing is generated then (one pilot that caps refuses nothing: under a marginal cut-off the batch goes
+ * ahead and reports its capped configurations one by one).  If all 24 attempts of a configuration of the batch run into their
  * cut-offs its outputs are zeroed and the call returns TPL_ERR_STATE after finishing the others ("did not finish within the
  * rule's bound", not "cannot be carved": a larger `cutoff` searches on).  1 <= L <= 16. */
 int tpl_generate_configs(int32_t L, int32_t M, uint64_t seed, int64_t first, int64_t count, int32_t threads,

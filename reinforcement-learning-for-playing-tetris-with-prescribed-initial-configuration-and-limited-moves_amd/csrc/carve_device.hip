@@ -606,7 +606,7 @@ extern "C" int tpl_generate_configs_device_waves(int32_t L, int32_t M, uint64_t 
     const size_t need = tpl_generate_configs_device_work_bytes(M, count);
     if (!work || work_bytes < need) return fail_msg(TPL_ERR_ARG, "work has %zu bytes, need %zu", work_bytes, need);
     if (((uintptr_t)work & 7u) != 0) return fail_msg(TPL_ERR_ARG, "work must be 8-byte aligned");
-    { const int rc = carve_pilot(L, M, cutoff); if (rc != TPL_OK) return rc; }     // one configuration on the host first
+    { const int rc = carve_pilot(L, M, cutoff); if (rc != TPL_OK) return rc; }     // the pilot configurations on the host first
     if (work_stride_bytes(M) * work_slices(count) >= ((size_t)1 << 32))             // the kernel's slice offsets are 32-bit
         return fail_msg(TPL_ERR_STATE, "work slices of %zu bytes outgrew 32-bit offsets", work_stride_bytes(M));
     // how many waves share the queue.  Automatic: as many as the chip runs at full rate (four per SIMD), or one lane per

@@ -806,7 +806,7 @@ int tpl_create(tpl_env** out, int64_t num_envs, int32_t L, int32_t M, int32_t de
     e->global_offset = global_offset; e->seed = seed;
     // step-kernel geometry: one board per lane while that still puts the whole grid on the chip at once (2^19 boards = 8 waves
     // on each of the 1024 SIMDs), two beyond: 6.3 against 6.7 us per step at 262,144 boards, 8.4 against 8.8 at 524,288,
-    // 12.8 against 11.9 at 786,432 (tools/tune_step.py).  tpl_set_tuning overrides.
+    // 12.8 against 11.9 at 786,432 (round-3 tuning runs, profiles/NOTES.md).  tpl_set_tuning overrides.
     e->boards_per_lane = num_envs <= ((int64_t)1 << 19) ? 1 : 2;
     char* base = (char*)workspace;
     if (base) {

@@ -490,7 +490,7 @@ __host__ __device__ __forceinline__ int decision(DecisionStream& s, int lo, int 
 // Only when all kCarveAttempts attempts have run into their cut-offs is the configuration reported as capped (all-zero
 // outputs): "this (L, M) did not finish within 256 x the base cut-off" -- not "cannot be carved": a caller who wants to
 // search on passes a larger `cutoff` (up to 2^28).  The bound is there because an unbounded search on the DEVICE is a kernel
-// that may never end; the generators also try ONE configuration on the host before a batch goes out (carve_pilot).
+// that may never end; the generators also try four pilot configurations on the host before a batch goes out (carve_pilot).
 constexpr int kCarveAttempts = 24;
 constexpr int kCarveDoublings = 8;
 constexpr int64_t kCarveCutoffMax = (int64_t)1 << 28;

@@ -207,7 +207,7 @@ class PoolRefresher:
         reserved_cus > 0 runs the generator on a CU-masked stream of that many compute units (`tpl_stream_create`),
         low_priority on a lowest-priority stream: both measured 3x SLOWER steps than a plain side stream -- kept as
         options because the review of round 2 asked for the comparison, not because they help.
-        An (L, M, cutoff) whose pilot configuration does not finish is refused HERE (TplError from the first start()).  A batch
+        An (L, M, cutoff) under which NONE of the generator's pilot configurations finishes is refused HERE (TplError from the first start()).  A batch
         in which some configuration ran into all of its cut-offs is dropped: `strict` raises at once; otherwise a warning names
         (L, M, cutoff), and after `max_capped_batches` such batches IN A ROW the refresher stops (`stopped`; poll() returns
         False from then on) instead of spending the generator's worst case beside the training loop for ever."""
@@ -273,7 +273,7 @@ class PoolRefresher:
         rows, pieces, _, _, first, made_on = self._batch
         bad = int(self._bad_host[0])                               # host memory, written ahead of the event that has fired
         if bad:
-            # every attempt of some configuration ran into its cut-off although the pilot configuration of this (L, M, cutoff)
+            # every attempt of some configuration ran into its cut-off although a pilot configuration of this (L, M, cutoff)
             # finished: the cut-off is marginal for this (L, M).  The batch is dropped, the pool stays as it is.
             import warnings
             self.capped_batches += 1

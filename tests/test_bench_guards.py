@@ -233,8 +233,15 @@ def test_compact_line_keeps_the_contract_keys_and_fits_a_truncating_reader():
             elif isinstance(v, (int, float)) and not isinstance(v, bool) and (k.startswith("frac") or k == "efficiency"):
                 yield path + k, v
     assert all(0 <= v <= 1 for _, v in fractions(line)), list(fractions(line))
-    assert line["scaling_model"]["per_launch"]["x8"] == {"boards_per_gpu": 131072, "launch_mode": "graph", "us_per_step": 5.1, "value": 2.05e11,
-                                                         "efficiency": 0.38}
+    sm = line["scaling_model"]
+    assert sm["per_launch"]["x8"] == {"us_per_step": 5.1, "value": 2.05e11, "efficiency": 0.38}
+    assert sm["fused_x8"] == {"value": 1.0e12, "efficiency": 0.52} and sm["weak_x8_value"] == 5.3e11
+
+    def numbers(node):
+        return sum(numbers(v) for v in node.values()) if isinstance(node, dict) else int(isinstance(node, (int, float)) and not isinstance(node, bool))
+    full["scaling_model"]["per_launch"].update({k: dict(full["scaling_model"]["per_launch"]["x8"]) for k in ("x2", "x4")})
+    full["scaling_model"]["fused_50_steps_per_launch"].update({k: dict(full["scaling_model"]["fused_50_steps_per_launch"]["x8"]) for k in ("x2", "x4")})
+    assert numbers(bench.compact(full)["scaling_model"]) == 12               # the review's bound: one key, at most twelve numbers
     assert line["side"]["fused_rollout"]["frac_hw"] == 0.33 and line["side"]["actor_loop"] == 1.67e9 and "carved_pool_run" not in line["side"]
     assert line["side"]["shard_run"] == {"boards": 131072, "tpl_step_us_per_step": 5.6, "capture_steps_us_per_step": 5.1, "tpl_rollout_us_per_step": 1.04}
     assert line["side_figures"]["failed"] == ["carved_pool_run"]

@@ -88,6 +88,11 @@ def _bench(gpus, extra=(), boards=65536, inject=None, base=("--sustained", "100"
     assert line["timing"]["host_call_us"] == full["timing"]["host_call_us"] > 0
     assert line["episodes"] == full["episodes"] and line["mean_episodic_return"] == full["mean_episodic_return"]
     assert [l for l in res.stderr.splitlines() if l.startswith("BENCH_DETAIL {")]
+    if full.get("scaling_model"):                 # the N = 1 line carries the scaling ceiling, the same numbers as the record
+        for k, leg in full["scaling_model"]["per_launch"].items():
+            assert line["scaling_model"]["per_launch"][k] == {f: leg[f] for f in ("us_per_step", "value", "efficiency")}
+    else:
+        assert "scaling_model" not in line
     return full
 
 
@@ -188,10 +193,17 @@ def test_bench_sharded_job_of_1048576_boards_on_four_ranks_is_the_one_gpu_job():
     assert out["config"]["launch_mode"] == "graph" and out["timing"]["host_call_us"] > 0       # 262,144 boards per GPU: below 2^19
     assert out["fused_rollout"] is None and out["weak_scaling_job"] is None and "cpu_baseline" not in out
     assert out["side_figures"]["failed"] == [] and out["side_figures"]["seconds"] == {}
-    one = _bench(1, boards=1 << 20, base=("--no-side-figures", "--no-cpu-baseline"))
+    one = _bench(1, boards=1 << 20, base=("--sustained", "0", "--actor-boards", "0", "--carved-pool", "0", "--no-config1", "--no-out-of-cache",
+                                          "--no-cpu-baseline"))
     assert one["episodes"] > 1 << 20
     for k in ("episodes", "mean_episodic_return"):
         assert out[k] == one[k], k
+    # ... and that one-GPU line states the ceiling of the eight-GPU run before hardware does: value_x8 = 2^20 / period(131,072 boards)
+    x8 = one["scaling_model"]["per_launch"]["x8"]
+    assert x8["boards_per_gpu"] == 131072 and x8["launch_mode"] == "graph" and x8["us_per_step"] == one["shard_run"]["capture_steps"]["us_per_step"]
+    assert x8["value"] == pytest.approx((1 << 20) / (x8["us_per_step"] * 1e-6), rel=1e-9) and 0.2 < x8["efficiency"] < 1
+    assert one["scaling_model"]["per_launch"]["x2"]["launch_mode"] == "eager" and set(one["scaling_model"]["per_launch"]) == {"x2", "x4", "x8"}
+    assert one["shard_run"]["capture_steps"]["us_per_step"] <= one["shard_run"]["tpl_step"]["us_per_step"] * 1.02     # the graph is no slower than eager calls
 
 
 @pytest.mark.gpu
