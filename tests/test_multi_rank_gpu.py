@@ -237,6 +237,13 @@ def test_bench_one_rank_through_rccl_and_the_gloo_control_group():
     plain = _bench(1, ["--no-cpu-baseline", "--shard-ranks", "0"])
     for k in ("episodes", "mean_episodic_return"):
         assert out[k] == plain[k], k
+    # ... and the graph launch mode of an N > 1 run UNDER a live RCCL process group (its watchdog thread polls events while the
+    # step launches are being captured): capture and replay must go through, and give the same job
+    graph = _bench(1, ["--no-cpu-baseline", "--shard-ranks", "0", "--launch-mode", "graph"], rehearsal=False,
+                   env_more=dict(TPL_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())))
+    assert graph["backend"] == "nccl" and graph["config"]["launch_mode"] == "graph" and graph["side_figures"]["failed"] == []
+    for k in ("episodes", "mean_episodic_return"):
+        assert graph[k] == plain[k], k
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
