@@ -119,7 +119,10 @@ class ForwardGames:
         self.solution_len = out["solution_len"][keep].contiguous()
         self.count = int(self.rows.shape[0])
         self._torch = torch
-        self._index = None
+        # game indices for translate()'s draw, made HERE and waited for (construction has a host sync anyway): translate() runs on
+        # whatever side stream a refresher uses, and must not depend on a tensor another stream may still be writing
+        self._index = torch.arange(self.count, dtype=torch.int64, device=self.device)
+        torch.cuda.synchronize(self.device)
 
     def translate(self, seed: int = 0, batch: int = 0, lead: bool = True):
         """(rows int16 [count, 20], pieces uint8 [count, M + 1]) on the device, enqueued on the current stream.  NO host wait:
