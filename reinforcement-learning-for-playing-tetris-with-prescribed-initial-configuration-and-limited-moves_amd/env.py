@@ -684,15 +684,26 @@ class Tetris:
     the reference's queue (:445-447), resetting twice in a row gives two different games).  render=True (the pygame
     window, :158-182) is out of scope and raises.
 
-    One divergence from the reference: a FINISHED game is frozen.  The reference's move() keeps popping pieces and
-    changing board / moves_used / lines_cleared after `state` has been set (game/tetris.py:354-422 never looks at it);
-    here move() on a game whose state is not None raises RuntimeError, so that a ported caller fails loudly instead of
-    reading a board that no longer changes."""
+    One divergence from the reference BY DEFAULT: a FINISHED game is frozen.  The reference's move() keeps popping pieces
+    and changing board / moves_used / lines_cleared after `state` has been set (game/tetris.py:354-422 never looks at it), and
+    its reset() leaves lines_cleared / moves_used / state as they were (:438-449); here move() on a game whose state is not
+    None raises RuntimeError, so that a ported caller fails loudly instead of reading a board that no longer changes, and
+    reset() starts the counters from zero.
+
+    `reference_quirks=True` gives the reference's behaviour instead, both parts (pinned by tests/golden/afterlife.npz, recorded
+    from the reference): a finished game goes on -- `state` is overwritten only where the reference assigns it, so a won game
+    can turn lost and a lost one won; move() raises IndexError once the M + 1 pieces are used up (`pieces.pop(0)`, :356) -- and
+    the three scalars survive reset().  The board mechanics of every move (clamp, drop, top-out, lock, full-row test,
+    compaction) run on the device as ever; what the device cannot hold is a finished game's bookkeeping -- its packed state
+    derives the piece cursor from moves_used and stops at M -- so in this mode lines_cleared / moves_used / state live in the
+    object, every move is handed to the device as the first move of a game whose next two pieces are the current ones, and
+    the reference's six lines of terminal tests (:372-374, 389-394, 415-422) are applied to what came back."""
 
     _STATE = {RUNNING: None, WON: True, LOST: False}
 
     def __init__(self, L: int, M: int, warm_reset: bool = True, render: bool = False, framerate: int = 30,
-                 debug: bool = False, configs=None, device="cuda:0", seed: Optional[int] = None, pool_size: int = 64):
+                 debug: bool = False, configs=None, device="cuda:0", seed: Optional[int] = None, pool_size: int = 64,
+                 reference_quirks: bool = False):
         if render:
             raise NotImplementedError("the pygame window of the reference is not part of this build")
         del framerate
@@ -724,6 +735,9 @@ class Tetris:
         self._finished = False
         self._board = None
         self._cache = None                 # packed_state() of the current position (one export per move, not per read)
+        self._quirks = bool(reference_quirks)
+        self._lines = self._moves = self._consumed = 0                     # reference_quirks: the scalars the object keeps
+        self._state = None
         self._env.reset()
 
     def _config(self) -> int:
@@ -735,7 +749,45 @@ class Tetris:
             raise AttributeError("solution is recorded only with debug=True and self-generated configurations")
         return self._solutions[self._config()]
 
+    def _move_as_the_reference(self, rotations: int, location: int) -> None:
+        """move() under reference_quirks: game/tetris.py:354-422 with `state` never read."""
+        pieces = self._pieces_host[self._config()]
+        if self._consumed >= len(pieces):
+            raise IndexError("pop from empty list")                       # :356 self.pieces.pop(0)
+        # the device plays this move as the FIRST move of a game: counters zero, running, window = [current, next, none...]
+        cur = int(pieces[self._consumed])
+        nxt = int(pieces[self._consumed + 1]) if self._consumed + 1 < len(pieces) else 7
+        window = cur | (nxt << 3) | (((1 << 30) - 1) << 6)               # twelve 3-bit ids, 7 = none (DESIGN.md section 2)
+        a, b = (x.cpu().numpy().view(np.uint32).copy() for x in self._env.raw_planes())
+        a[0, 1] &= 0x0FFFFFFF                                              # moves_used, low nibble
+        a[0, 3] &= 0x0FFFFFFF                                              #             high nibble
+        b[0, 1] &= 0xCFFFFFFF                                              # state = running (the pool-slot bit stays)
+        b[0, 2] = (b[0, 2] & 0x000FFFFF) | np.uint32(((window >> 32) & 15) << 28)          # lines_cleared = 0, window[35:32]
+        b[0, 3] = np.uint32(window & 0xFFFFFFFF)
+        self._env.write_raw_planes(torch.from_numpy(a.view(np.int32)), torch.from_numpy(b.view(np.int32)))
+        _, _, cleared = self._env.move(torch.tensor([rotations], dtype=torch.int64), torch.tensor([location], dtype=torch.int64))
+        self._steps += 1
+        self._consumed += 1
+        self._board = self._cache = None
+        placed = int(self._s()["moves"][0]) == 1                          # a top-out consumes the piece and counts no move (:372-374)
+        if not placed:
+            self._state = False
+            return
+        self._moves += 1                                                  # :379
+        rows_cleared = int(cleared.item())
+        if rows_cleared == 0:                                             # :389-394
+            if self._moves >= self.M:
+                self._state = False
+            return
+        self._lines += rows_cleared                                       # :409
+        if self._lines >= self.L:                                         # :415-417 (tested before the move limit)
+            self._state = True
+        elif self._moves >= self.M:                                       # :420-422
+            self._state = False
+
     def move(self, rotations: int, location: int) -> None:
+        if self._quirks:
+            return self._move_as_the_reference(rotations, location)
         if self._finished:
             raise RuntimeError("move() on a finished game: this build freezes a game once state is set (the reference "
                                "keeps mutating it); call reset() first")
@@ -753,6 +805,7 @@ class Tetris:
         self._birth = self._steps
         self._env.reset(mask=[1])
         self._finished = False
+        self._consumed = 0                 # (reference_quirks: lines / moves / state are NOT touched, as in :438-449)
         self._board = self._cache = None
 
     def _s(self):
@@ -781,14 +834,19 @@ class Tetris:
 
     @property
     def pieces(self) -> list:
+        if self._quirks:
+            return self._pieces_host[self._config()][self._consumed:].tolist()
         left = int(self._s()["pieces_left"][0])
         return self._pieces_host[self._config()][self.M + 1 - left:].tolist()
 
-    lines_cleared = property(lambda self: int(self._s()["lines"][0]))
-    moves_used = property(lambda self: int(self._s()["moves"][0]))
-    state = property(lambda self: self._STATE[int(self._s()["state"][0])])
+    lines_cleared = property(lambda self: self._lines if self._quirks else int(self._s()["lines"][0]))
+    moves_used = property(lambda self: self._moves if self._quirks else int(self._s()["moves"][0]))
+    state = property(lambda self: self._state if self._quirks else self._STATE[int(self._s()["state"][0])])
 
     def get_state(self):
+        if self._quirks:
+            pieces = self.pieces                                           # (IndexError with fewer than two left, as :436)
+            return (self.board, pieces[0], pieces[1], self.L - self._lines, self.M - self._moves, self._state)
         s = self._s()
         return (self.board, int(s["cur"][0]), int(s["nxt"][0]), self.L - int(s["lines"][0]),
                 self.M - int(s["moves"][0]), self._STATE[int(s["state"][0])])

@@ -18,6 +18,7 @@ Fixtures (all .npz, little-endian, a few hundred KB in total):
   F3 synthetic_*.npz     first 1024 boards of the synthetic sets stepped for M moves (freeze when finished)
   F4 edges.npz           edge cases (overhang top-out, clamp, rotation modulo, win on last move, ...)
   F5 random_moves.npz    4096 random single moves on random boards
+  F6 afterlife.npz       (make_golden_afterlife.py) finished games played on, counters carried across reset()
 """
 import os
 import random

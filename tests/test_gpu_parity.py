@@ -209,6 +209,107 @@ def test_f4_midgame_counters_on_the_hip_path(T):
     assert ran >= 1
 
 
+def _dealing_order(kinds):
+    """Which pool entry tetris_piclim.Tetris deals at each reset, by the rule its docstring states: entry `steps so far` mod pool
+    size, a step being a move() that reached the device or a reset() that follows no move.  -> (entry per game, pool size)."""
+    steps = birth = 0
+    entries = []
+    for i, kind in enumerate(kinds):
+        if kind == 0:                                   # reset (the first one is the constructor's deal: entry 0)
+            if i > 0:
+                if steps == birth:
+                    steps += 1
+                birth = steps
+            entries.append(steps)
+        elif kind == 1:
+            steps += 1                                  # (a move that raised IndexError never reached the device)
+    return entries, steps + 2
+
+
+def test_afterlife_of_finished_games_with_reference_quirks_on_the_hip_path(T):
+    """tests/golden/afterlife.npz (recorded from the reference) through `Tetris(..., reference_quirks=True)`: finished games
+    that go on -- counters past M and L, terminal state flipping both ways, IndexError when the M + 1 pieces are used up -- and
+    reset() keeping lines_cleared / moves_used / state (game/tetris.py:354-422, 438-449).  Every move's board mechanics run on
+    the device; board, counters, state and the piece list after every event are the reference's."""
+    from test_oracle_golden import afterlife_events
+    f = load_golden("afterlife.npz")
+    ref_state = {0: None, 1: True, 2: False}
+    raised = flips = 0
+    for ci in range(int(f["n"])):
+        L, M = int(f[f"c{ci}_L"]), int(f[f"c{ci}_M"])
+        events = afterlife_events(f, ci)
+        entries, pool = _dealing_order([e[0] for e in events])
+        rows = np.repeat(f[f"c{ci}_rows0"][:1], pool, axis=0)
+        pieces = np.repeat(f[f"c{ci}_pieces"][:1], pool, axis=0)
+        for k, entry in enumerate(entries):
+            rows[entry], pieces[entry] = f[f"c{ci}_rows0"][k], f[f"c{ci}_pieces"][k]
+        game = T.Tetris(L, M, configs=(rows, pieces), reference_quirks=True)
+        k = -1
+        for i, (kind, rot, loc, want_rows, li, mo, st, left) in enumerate(events):
+            before = game.state
+            if kind == 0:
+                k += 1
+                if i > 0:
+                    game.reset()
+                assert np.array_equal(np.array(game.pieces), f[f"c{ci}_pieces"][k]), (ci, k)
+            elif kind == 2:
+                with pytest.raises(IndexError, match="pop from empty list"):
+                    game.move(int(rot), int(loc))
+                raised += 1
+            else:
+                game.move(int(rot), int(loc))
+                flips += before is not None and game.state is not before
+            got = (game.board.astype(np.uint16) << np.arange(10, dtype=np.uint16)).sum(1)
+            assert np.array_equal(got, want_rows), (ci, i)
+            assert (game.lines_cleared, game.moves_used, len(game.pieces)) == (li, mo, left), (ci, i)
+            assert game.state is ref_state[int(st)], (ci, i)
+            if left >= 2:
+                board, cur, nxt, l_rem, m_rem, state = game.get_state()
+                assert (cur, nxt, l_rem, m_rem, state) == (game.pieces[0], game.pieces[1], L - li, M - mo, ref_state[int(st)])
+            else:
+                with pytest.raises(IndexError):
+                    game.get_state()                    # self.pieces[1] of the reference's get_state (:436)
+        game.terminate()
+    assert raised >= 40 and flips >= 6
+
+
+def test_reference_quirks_against_the_oracle_on_random_afterlives(T, oracle):
+    """The same mode against the oracle's move (the reference's, line for line: it never reads `state`) on games the fixture
+    does not hold: other (L, M), every rotation count 0..8 and location 0..10, thirty games in a row through reset()."""
+    rng = np.random.default_rng(5)
+    for L, M in ((1, 2), (3, 9), (6, 25), (10, 40), (250, 254)):
+        n = 30
+        rows = oracle.synth_boards(900 + L, 0, n, min(L, 16))
+        rows[::3] = 0
+        pieces = oracle.synth_pieces(900 + L, 0, n, M)
+        plays = [int(rng.integers(1, M + 4)) for _ in range(n)]
+        kinds = [x for p in plays for x in [0] + [1] * min(p, M + 1)]
+        entries, pool = _dealing_order(kinds)
+        big_rows, big_pieces = np.repeat(rows[:1], pool, axis=0), np.repeat(pieces[:1], pool, axis=0)
+        for k, entry in enumerate(entries):
+            big_rows[entry], big_pieces[entry] = rows[k], pieces[k]
+        game = T.Tetris(L, M, configs=(big_rows, big_pieces), reference_quirks=True)
+        lines = moves = state = 0
+        for k in range(n):
+            if k:
+                game.reset()
+            cpu = oracle.Game(L, M, rows[k], pieces[k], lines, moves, state)
+            for t in range(plays[k]):
+                rot, loc = int(rng.integers(0, 9)), int(rng.integers(0, 11))
+                if t >= M + 1:
+                    with pytest.raises(IndexError):
+                        game.move(rot, loc)
+                    continue
+                game.move(rot, loc)
+                cpu.move(rot, loc)
+                got = (game.board.astype(np.uint16) << np.arange(10, dtype=np.uint16)).sum(1)
+                assert np.array_equal(got, cpu.rows), (L, M, k, t)
+                assert (game.lines_cleared, game.moves_used, game.pieces) == (cpu.lines_cleared, cpu.moves_used, cpu.pieces), (L, M, k, t)
+                assert game.state is {0: None, 1: True, 2: False}[cpu.state], (L, M, k, t)
+            lines, moves, state = cpu.lines_cleared, cpu.moves_used, cpu.state
+        game.terminate()
+
+
 def test_f4_edge_cases(T):
     f = load_golden("edges.npz")
     for i in range(int(f["n"])):

@@ -171,3 +171,37 @@ def test_obs_layout(oracle):
     assert np.array_equal(obs[:, :200], cells)
     assert np.array_equal(obs[:, 200:207].argmax(1), pieces[:, 0]) and np.array_equal(obs[:, 207:214].argmax(1), pieces[:, 1])
     assert np.all(obs[:, 214] == L) and np.all(obs[:, 215] == M) and np.all(obs[:, 216] == 0)
+
+
+def afterlife_events(f, ci):
+    """The events of case `ci` of afterlife.npz: (kind, rotations, location, rows, lines, moves, state, pieces_left)."""
+    return list(zip(f[f"c{ci}_kind"], f[f"c{ci}_action"][:, 0], f[f"c{ci}_action"][:, 1], f[f"c{ci}_rows"], f[f"c{ci}_lines"],
+                    f[f"c{ci}_moves"], f[f"c{ci}_state"], f[f"c{ci}_pieces_left"]))
+
+
+def test_afterlife_of_finished_games_and_counters_across_reset(oracle):
+    """What the reference does with a finished game (tests/golden/make_golden_afterlife.py): move() never reads `state`
+    (game/tetris.py:354-422), so the game goes on -- pieces popped, moves and lines counted past M and L, `state` overwritten only
+    where the code assigns it (won -> lost and lost -> won both occur in the fixture) -- until pop(0) raises IndexError on the
+    empty list (:356); and reset() (:438-449) swaps board and pieces but keeps lines_cleared / moves_used / state.  The oracle's
+    to_move is the reference's move line for line, so it has the same afterlife; the reset is restated here as the reference
+    has it (a new board and piece list under the old counters)."""
+    f = load_golden("afterlife.npz")
+    flips = 0
+    for ci in range(int(f["n"])):
+        L, M = int(f[f"c{ci}_L"]), int(f[f"c{ci}_M"])
+        game, k, lines, moves, state = None, -1, 0, 0, 0
+        for kind, rot, loc, rows, li, mo, st, left in afterlife_events(f, ci):
+            if kind == 0:                                             # reset(): the next prepared game, counters carried
+                k += 1
+                game = oracle.Game(L, M, f[f"c{ci}_rows0"][k], f[f"c{ci}_pieces"][k], lines, moves, state)
+            elif len(game.pieces) == 0:
+                assert kind == 2                                      # the reference raised IndexError: nothing changes
+            else:
+                assert kind == 1
+                before = game.state
+                game.move(int(rot), int(loc))
+                flips += before != 0 and game.state != before
+            lines, moves, state = game.lines_cleared, game.moves_used, game.state
+            assert np.array_equal(game.rows, rows) and (lines, moves, state, len(game.pieces)) == (li, mo, st, left), (ci, kind)
+    assert flips >= 6
