@@ -404,10 +404,11 @@ def main():
                              sustained=more["sustained"], algorithmic_bytes_per_launch=ALGO_BYTES_PER_BOARD_STEP * n,
                              node={"achieved": ALGO_BYTES_PER_BOARD_STEP * total / (steady_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS * world,
                                    "unit": "GB/s", "frac": ALGO_BYTES_PER_BOARD_STEP * total / (steady_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)}),
-            "fused_rollout": more["fused_rollout"], "scaling_model": figures["scaling_model"], "shard_run": figures["shard_run"],
-            "weak_scaling_job": figures["weak_scaling_job"], "carved_pool_run": more["carved_pool_run"],
-            "live_supply_run": more["live_supply_run"], "config1_run": figures["config1_run"], "config_supply": figures["config_supply"],
-            "actor_loop": figures["actor_loop"], "mean_episodic_return": mean_return if episodes else None, "episodes": episodes,
+            # (the record ends with what a reader of its tail wants first: the fused form, the shards, the scaling model)
+            "carved_pool_run": more["carved_pool_run"], "live_supply_run": more["live_supply_run"], "config1_run": figures["config1_run"],
+            "config_supply": figures["config_supply"], "actor_loop": figures["actor_loop"], "weak_scaling_job": figures["weak_scaling_job"],
+            "fused_rollout": more["fused_rollout"], "shard_run": figures["shard_run"], "scaling_model": figures["scaling_model"],
+            "mean_episodic_return": mean_return if episodes else None, "episodes": episodes,
             "side_figures": dict(side.summary(), agreements_over=ctl_note,
                                  guard="each side figure runs under a guard (an exception becomes {\"error\": ...} under its key; at N > 1 the "
                                        "ranks agree over a gloo group before and after each); the timed region is not guarded"),
