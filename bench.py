@@ -165,6 +165,9 @@ def compact(d):
             side[key] = d[key].get("value")
     if ok(d.get("live_supply_run")):
         side["live_supply_run"] = pick(d["live_supply_run"], ("slowdown", "configurations_supplied_per_s", "pool_reuse_factor"))
+        held = d["live_supply_run"].get("reuse_held_at_1")
+        if isinstance(held, dict):
+            side["live_supply_run"].update(value_with_reuse_held_at_1=held.get("value"), reuse_factor_when_held=held.get("pool_reuse_factor"))
     if ok(d.get("config_supply")):
         cd = d["config_supply"]["carve_device"]
         side["config_supply_carve_device"] = dict({"value": cd["value"]}, **pick(cd["roofline"] or {}, ("frac", "frac_hw", "frac_of_lane_slots")))

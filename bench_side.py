@@ -576,14 +576,16 @@ def measure_config_supply(torch, T, dev, L, M, seed, keep=None):
 
 
 def measure_live_supply(torch, T, env, actions, reward, done, seed, count=0, min_swaps=3, min_steps=4000, max_steps=40000,
-                        step_fn=None, **where):
+                        step_fn=None, hold=None, **where):
     """The replenished supply under load (game/tetris.py:195-211, 473-488: producers feed the reset queue while games
     run): PoolRefresher carves `count` configurations at a time on a side stream while the main stream steps, and each
     finished batch becomes the current pool (boards in mid-episode finish on the buffer they started from).  Steady state:
     the timed region starts at the FIRST swap and runs until `min_swaps` more batches have been swapped in (and at least
     `min_steps` steps); the supply rate is those batches over the wall time between the first and the last swap.  `where` = PoolRefresher's waves / reserved_cus / low_priority.
     count = 0: PoolRefresher's default, pool-sized batches (one configuration per board).  `step_fn(t)` replaces the random-action
-    step (the policy-driven loop of measure_actor_loop)."""
+    step (the policy-driven loop of measure_actor_loop).  `hold` = a reuse limit: instead of poll() the loop calls
+    PoolRefresher.hold_reuse(hold) every 32 steps, which WAITS for the generator once the pool has been dealt that many times
+    over -- the step rate then is what the reference's fresh-game-per-episode supply costs."""
     n, dev = env.num_envs, env.device
     S = actions.shape[0] if actions is not None else 1
     if step_fn is None:
@@ -618,7 +620,7 @@ def measure_live_supply(torch, T, env, actions, reward, done, seed, count=0, min
             for t in range(32):
                 step_fn(lead + steps + t)
             steps += 32
-            if feeder.poll():
+            if feeder.hold_reuse(hold) if hold is not None else feeder.poll():
                 swap_times.append(time.perf_counter())       # the host loop runs a bounded queue ahead of the GPU: wall time tracks it
         e1.record()
         torch.cuda.synchronize(dev)
@@ -906,6 +908,15 @@ def live_figures(c):
                          "the footprint its target_slowdown = 1.13 picks from the measured table")
     keep = ("ms_per_step", "slowdown", "pool_swaps", "steps", "configurations_per_batch", "generator_waves",
             "configurations_supplied_per_s", "pool_reuse_factor")
+    # ... and what the reference's supply semantics cost: the pool's reuse HELD at 1.  The loop waits for the generator, which gets
+    # the whole chip (4096 waves); batches of FOUR configurations per board, because a swap has to wait M + 1 = 41 steps and a
+    # board-sized pool is dealt 2.5 times over in those (6 % of the boards finish at every step under random play)
+    held = measure_live_supply(torch, T, env, c.actions, c.reward, c.done, c.args.seed, count=4 * c.n, waves=4096, hold=1.0,
+                               min_swaps=3, min_steps=64, max_steps=20000)
+    live["reuse_held_at_1"] = {k: held[k] for k in ("value", "ms_per_step", "pool_swaps", "steps", "configurations_per_batch",
+                                                    "configurations_supplied_per_s", "resets_per_s", "pool_reuse_factor")}
+    live["reuse_held_at_1"]["note"] = ("PoolRefresher.hold_reuse(1.0): every pool dealt about once, as the reference's queue deals every game once "
+                                       "(game/tetris.py:445-447) -- the step loop then runs at the generator's rate")
     live["by_generator_footprint"] = [
         dict(generator=name, **{k: v for k, v in measure_live_supply(torch, T, env, c.actions, c.reward, c.done, c.args.seed, **kw).items() if k in keep})
         for name, kw in (("256 waves, batches of 65,536 (the default through round 4)", dict(waves=256, count=65536)),

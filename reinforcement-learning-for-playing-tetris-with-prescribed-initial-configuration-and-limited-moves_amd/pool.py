@@ -233,6 +233,8 @@ class PoolRefresher:
         self.stopped = False
         self.forward = ForwardGames(env, forward_seeds) if forward_seeds is not None else None
         self.forward_lead, self._batches = bool(forward_lead), 0
+        self._stats_at_swap = None    # the environment's episode counters when the current pool came in (device tensor)
+        self._pool_entries = 0
         self.start()
 
     def start(self) -> None:
@@ -313,8 +315,32 @@ class PoolRefresher:
                 mem.record_stream(main)
         self.last_batch = (rows, pieces, first)
         self.swaps += 1
+        self._stats_at_swap = self.env.stats_tensor()              # enqueued behind the swap: no host wait
+        self._pool_entries = int(rows.shape[0])
         self.start()
         return True
+
+    def reuse_factor(self) -> float:
+        """How many times over the CURRENT pool has been dealt: episodes finished since it was swapped in / its entries (host
+        sync: one small copy).  The reference deals every game once (reset() blocks on queue.get(), game/tetris.py:445-447);
+        here a pool is re-dealt until the next batch replaces it -- this is the number to watch, hold_reuse() the way to bound
+        it.  0.0 before the first swap."""
+        if self._stats_at_swap is None or not self._pool_entries:
+            return 0.0
+        finished = int((self.env.stats_tensor()[0] - self._stats_at_swap[0]).item())
+        return finished / float(self._pool_entries)
+
+    def hold_reuse(self, limit: float = 1.0) -> bool:
+        """Bound the reuse of a pool: if the current one has been dealt `limit` times over, WAIT on the host for the batch being
+        generated and swap it in (True when a swap happened; False when the limit is not reached, or the handle cannot take a
+        pool yet -- fewer than M + 1 steps since the last swap: step on and call again).  With limit = 1 an episode starts, in
+        expectation, from a configuration no other episode of this pool has had: the reference's supply semantics, at the
+        generator's rate instead of the step kernel's (bench.py: `live_supply_run.reuse_held_at_1`).  Costs a host
+        synchronisation per call: every few steps is enough."""
+        if self.stopped or self._ready is None or self.reuse_factor() < limit:
+            return False
+        self._ready.synchronize()
+        return self.poll()
 
     def close(self) -> None:
         """Waits for the batch in flight and drops it (the side stream itself lives as long as the process)."""

@@ -531,6 +531,50 @@ def test_randomised_mix_of_steps_rollouts_resets_and_pool_swaps(T, oracle):
 
 
 @pytest.mark.gpu
+def test_pool_refresher_can_hold_the_reuse_of_a_pool_at_one(T, oracle):
+    """The reference deals every game once (reset() blocks on queue.get(), game/tetris.py:445-447); a device pool is re-dealt until
+    the next batch replaces it.  `reuse_factor()` counts how many times over the current pool has been dealt, `hold_reuse(limit)`
+    waits for the batch in flight once the limit is reached.  Left alone a small pool under random play is dealt dozens of times
+    over; held at 1 every pool is dealt about once (the steps between two looks and the M + 1 steps a swap has to wait add a
+    little); either way the boards are the oracle's, handed the same batches at the same steps."""
+    L, M, n, count, seed = 4, 16, 8192, 8192, 11
+    runs = {}
+    for held in (False, True):
+        env = T.BatchedTetris(L, M, n, seed=seed, auto_reset=True)
+        rows0, pieces0 = T.generate_configs(L, M, count, seed=seed, first=0)
+        env.load_configs(rows0, pieces0)
+        env.reset()
+        cpu = oracle.Env(n, L, M, 0, seed)
+        cpu.set_pool(rows0, pieces0)
+        cpu.set_options(auto_reset=True, assign_mode=0)
+        cpu.reset()
+        feeder = T.PoolRefresher(env, count, seed=seed, first=count, waves=8)
+        assert feeder.reuse_factor() == 0.0 and feeder.hold_reuse(1.0) is False          # nothing swapped in yet
+        factors, swaps_at = [], []
+        for t in range(400):
+            a = oracle.synth_actions(seed, 0, n, t)
+            _, r_g, d_g, _ = env.step(a, observe=False)
+            r_c, d_c = cpu.step(a)
+            assert np.array_equal(_np(r_g), r_c) and np.array_equal(_np(d_g).astype(np.uint8), d_c), (held, t)
+            before = feeder.reuse_factor() if t % 2 == 1 else None
+            swapped = (feeder.hold_reuse(1.0) if held and feeder.swaps else feeder.poll()) if t % 2 == 1 else False
+            if swapped:
+                if feeder.swaps > 1:
+                    factors.append(before)                                            # how often the pool just replaced had been dealt
+                swaps_at.append(t)
+                rows, pieces, _ = feeder.last_batch
+                cpu.set_pool(_np(rows).view(np.uint16), _np(pieces))
+        _same(_state(env), cpu.get_state(), f"held={held}")
+        assert env.stats() == cpu.stats()
+        runs[held] = (factors, feeder.swaps)
+        feeder.close()
+        env.terminate()
+    free, held = runs[False], runs[True]
+    assert len(held[0]) >= 3 and all(1.0 <= f < 2.5 for f in held[0]), held       # every pool dealt about once before it goes
+    assert free[1] >= 2 and held[1] >= 4
+
+
+@pytest.mark.gpu
 def test_pool_refresher_drops_capped_batches_goes_on_and_stops_after_three_in_a_row(T, oracle):
     """A cut-off that is marginal for its (L, M) -- L = 8, M = 40 with a base cut-off of 2 trips (512 for the last attempts,
     where a search takes 400): the pilot configuration finishes, but a few configurations in a thousand run into all 24
