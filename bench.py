@@ -55,6 +55,17 @@ import bench_side as B  # noqa: E402
 GRAPH_STEPS = 50                        # steps per captured graph in "graph" mode (the last one holds the remainder)
 
 
+def graph_plan(W, K, S, g_max=GRAPH_STEPS):
+    """The K timed steps of "graph" mode as chunks of <= g_max steps: [[action row of each step], ...].  Step t (W <= t < W + K)
+    plays action row t % S -- exactly the row the eager loop hands to tpl_step() for that step."""
+    plan, t = [], W
+    while t < W + K:
+        g = min(g_max, K, W + K - t)
+        plan.append([(t + i) % S for i in range(g)])
+        t += g
+    return plan
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks as a CHILD process -- this process has not
     imported torch or touched the GPU, and it never execs -- and hand back the child's exit status."""
@@ -295,12 +306,9 @@ def main():
         g_max = min(GRAPH_STEPS, K)
         rs = torch.empty((g_max, n), dtype=torch.float32, device=dev)
         ds = torch.empty((g_max, n), dtype=torch.uint8, device=dev)
-        t = W
-        while t < W + K:
-            g = min(g_max, W + K - t)
-            replays.append(env.capture_steps([rows_of[(t + i) % S] for i in range(g)], rs[:g], ds[:g]))
+        for chunk in graph_plan(W, K, S):
+            replays.append(env.capture_steps([rows_of[r] for r in chunk], rs[:len(chunk)], ds[:len(chunk)]))
             replays[-1].prepare()
-            t += g
     T.sharding.mean_episodic_return(env.stats_tensor(), env.reward_params)   # load the reduction kernels / RCCL rings
     torch.cuda.synchronize(dev)
     barrier()

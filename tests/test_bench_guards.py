@@ -269,3 +269,17 @@ def test_committed_counter_profiles_were_taken_on_these_kernel_sources():
     assert traffic["source_digest"] == digest, "profiles/traffic.json was measured on other kernel sources: run tools/profile_step.sh + tools/update_traffic.py"
     for name, f in json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))["forms"].items():
         assert f["stamp"]["source_digest"] == digest and f["stamp"]["library_built_from_these_sources"], name
+
+
+def test_graph_mode_plays_every_step_on_the_action_row_the_eager_loop_would():
+    """bench.graph_plan: the K timed steps as chunks of at most 50 captured launches; step t on action row t % S, whatever K, W and
+    the number of staged rows S are (the driver's K = 20 is one graph; 70 = 50 + 20; past 4096 staged rows the rows wrap)."""
+    bench = _bench()
+    assert bench.graph_plan(5, 20, 25) == [list(range(5, 25))]
+    assert [len(c) for c in bench.graph_plan(5, 70, 75)] == [50, 20]
+    assert [len(c) for c in bench.graph_plan(0, 1, 1)] == [1] and bench.graph_plan(0, 1, 1) == [[0]]
+    for W, K, S in ((5, 20, 25), (50, 2000, 2050), (50, 5000, 4096), (0, 7, 7), (3, 149, 100), (10, 50, 60)):
+        plan = bench.graph_plan(W, K, S)
+        flat = [r for chunk in plan for r in chunk]
+        assert flat == [t % S for t in range(W, W + K)] and all(1 <= len(c) <= 50 for c in plan)
+        assert all(len(c) == 50 for c in plan[:-1])
