@@ -104,9 +104,9 @@ def parse_args():
     ap.add_argument("--no-weak-job", action="store_true", help="N > 1: skip the weak-scaling side figure (--boards per GPU)")
     ap.add_argument("--no-out-of-cache", action="store_true", help="skip the 2^23-board side run (N = 1 only)")
     ap.add_argument("--no-side-figures", action="store_true", help="the headline, its roofline and the CPU baseline only")
-    ap.add_argument("--side-budget", type=float, default=240.0,
+    ap.add_argument("--side-budget", type=float, default=120.0,
                     help="seconds of side figures after which the remaining ones are skipped (the headline is never skipped)")
-    ap.add_argument("--side-timeout", type=float, default=480.0,
+    ap.add_argument("--side-timeout", type=float, default=300.0,
                     help="seconds after which a side figure that is STILL running is abandoned: the line is printed, exit status 3")
     ap.add_argument("--detail", default=None, help="where the full record goes (default gpurun_out/bench_detail_n<N>.json; '-' = nowhere)")
     args = ap.parse_args()
