@@ -144,6 +144,8 @@ def compact(d):
     out = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                              "vs_baseline", "dtype", "data")}
     out["config"] = pick(d["config"], ("workload", "launch_mode", "global_boards", "boards_per_gpu", "L", "M", "parallelism"))
+    if d["config"].get("graph_capture_failed"):
+        out["config"]["graph_capture_failed"] = str(d["config"]["graph_capture_failed"])[:128]
     out["roofline"] = pick(d["roofline"], ("bound", "achieved", "peak", "unit", "frac", "frac_hbm_resident", "hbm_resident_working_set_bytes",
                                            "traffic", "traffic_stale", "frac_traffic", "kernel", "kernel_ms", "kernel_ms_median",
                                            "frac_median", "boards_per_launch", "algorithmic_bytes_per_launch"),
@@ -279,7 +281,7 @@ def main():
     total, L, M, K, W = args.boards, args.L, args.M, args.steps, args.warmup
     shard = T.sharding.strong_shard(rank, world, total)
     n, pool = shard.boards, args.pool or total
-    mode = launch_mode_for(world, n, args.launch_mode)
+    mode = launch_mode_for(world, T.sharding.strong_shard(0, world, total).boards, args.launch_mode)   # by the largest shard: the same on every rank
     env = T.BatchedTetris(L, M, n, device=dev, seed=args.seed, global_offset=shard.global_offset, auto_reset=True, assign="hash")
     rows, pieces = env.synthetic_configs(pool, first=0)
     env.load_configs(rows, pieces)
@@ -299,16 +301,30 @@ def main():
     # guarded: a failure ends the run with a non-zero status -- an unmeasured headline must not look measured.
     for t in range(max(W - 1, 0)):
         env.step_into(rows_of[t % S], reward, done)
-    replays = []
+    replays, capture_failed = [], None
     if mode == "graph":
         # the K timed steps as captured graphs of <= GRAPH_STEPS step_kernel launches, step t on action row t as in eager mode;
-        # captured HERE (a capture runs nothing: snapshot, K enqueues into the graph, restore), replayed inside the region
-        g_max = min(GRAPH_STEPS, K)
-        rs = torch.empty((g_max, n), dtype=torch.float32, device=dev)
-        ds = torch.empty((g_max, n), dtype=torch.uint8, device=dev)
-        for chunk in graph_plan(W, K, S):
-            replays.append(env.capture_steps([rows_of[r] for r in chunk], rs[:len(chunk)], ds[:len(chunk)]))
-            replays[-1].prepare()
+        # captured HERE (a capture runs nothing: snapshot, K enqueues into the graph, restore), replayed inside the region.
+        # Should a capture fail (eight RCCL ranks capturing at once is the one thing no one-GPU box can rehearse) the rank says so
+        # and EVERY rank falls back to eager calls: a slower, host-dependent headline instead of none.
+        saved = env.snapshot()
+        try:
+            if os.environ.get("TPL_BENCH_INJECT_FAILURE") == "graph_capture":
+                raise RuntimeError("failure injected into the graph capture (TPL_BENCH_INJECT_FAILURE)")
+            g_max = min(GRAPH_STEPS, K)
+            rs = torch.empty((g_max, n), dtype=torch.float32, device=dev)
+            ds = torch.empty((g_max, n), dtype=torch.uint8, device=dev)
+            for chunk in graph_plan(W, K, S):
+                replays.append(env.capture_steps([rows_of[r] for r in chunk], rs[:len(chunk)], ds[:len(chunk)]))
+                replays[-1].prepare()
+        except Exception as e:            # noqa: BLE001
+            capture_failed = f"{type(e).__name__}: {e}"[:300]
+            torch.cuda.synchronize(dev)
+            env.restore(saved)
+        del saved
+        if any(every_rank(1.0 if capture_failed else 0.0)):
+            capture_failed = capture_failed or "the capture failed on another rank"
+            mode, replays = "eager", []
     T.sharding.mean_episodic_return(env.stats_tensor(), env.reward_params)   # load the reduction kernels / RCCL rings
     torch.cuda.synchronize(dev)
     barrier()
@@ -385,7 +401,8 @@ def main():
                        "workload_detail": f"{total} boards in total" + (f", batch-sharded over {world} GPUs ({n} on rank 0)" if world > 1 else " on 1 GPU")
                                           + f", random initial configs, L={L} M={M}, uniform random actions, auto-reset from a {pool}-entry "
                                           "device pool (the same pool on every rank), one tpl_step launch per step",
-                       "launch_mode": mode, "launch_mode_is": ("one tpl_step() call per step" if mode == "eager" else
+                       "launch_mode": mode, "graph_capture_failed": capture_failed,
+                       "launch_mode_is": ("one tpl_step() call per step" if mode == "eager" else
                                                                f"the same step_kernel launches, captured <= {GRAPH_STEPS} at a time and replayed "
                                                                f"({len(replays)} graph(s) for the {K} timed steps)"),
                        "global_boards": total, "boards_per_gpu": n, "L": L, "M": M, "parallelism": f"batch-shard x{world}"},

@@ -178,6 +178,20 @@ def test_bench_graph_mode_with_a_remainder_graph_is_the_eager_job():
 
 
 @pytest.mark.gpu
+def test_bench_falls_back_to_eager_calls_when_a_graph_capture_fails():
+    """Eight RCCL ranks capturing graphs at once is the one thing no one-GPU box can rehearse: should a capture fail on any rank,
+    every rank drops to eager calls (the ranks agree before the timed region) and the line says why -- a slower headline instead of
+    none.  Injected here on both of two ranks; the job is still the one-GPU job."""
+    out = _bench(2, ("--no-cpu-baseline", "--no-weak-job"), inject="graph_capture")
+    assert out["config"]["launch_mode"] == "eager" and "injected into the graph capture" in out["config"]["graph_capture_failed"]
+    assert "(eager)" in out["config"]["workload"] and out["value"] > 0
+    plain = _bench(1, ["--no-cpu-baseline", "--shard-ranks", "0"])
+    assert plain["config"]["graph_capture_failed"] is None
+    for k in ("episodes", "mean_episodic_return"):
+        assert out[k] == plain[k], k
+
+
+@pytest.mark.gpu
 def test_bench_sharded_job_of_1048576_boards_on_four_ranks_is_the_one_gpu_job():
     """BASELINE configs[3]'s job -- 1,048,576 boards IN TOTAL, sharded by global board index, `--steps 20 --warmup 5`, side
     figures off -- through bench.py itself with FOUR ranks sharing this box's one GPU over gloo (a GPU box of this pool lets
