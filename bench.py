@@ -31,7 +31,8 @@ canonical 96 B/board-step of SURVEY 8(d); `frac` = this run, `frac_hbm_resident`
 Infinity Cache), `cpu_baseline` (the C oracle on this box's host cores; `limited_by` says what bounds them), `scaling_model` (N = 1:
 the periods of a 2-, 4- and 8-GPU run's shards measured on this GPU, and the value and efficiency they imply) and one number per
 side figure.  The full record -- every side figure with its own roofline, bench_side.py -- goes to `--detail` (default
-gpurun_out/bench_detail_n<N>.json) and, as one line prefixed BENCH_DETAIL, to stderr.  Side figures never enter `value`; each
+gpurun_out/bench_detail_n<N>.json) and, as one line prefixed BENCH_DETAIL, to stderr; the headline alone goes there once already
+right behind the timed region (BENCH_HEADLINE), before any side figure runs.  Side figures never enter `value`; each
 runs under a guard (bench_side.SideFigures): an exception costs its own key, figures past --side-budget are skipped, and if one
 hangs past --side-timeout the line is printed with what there is and the process exits with status 3.  A failure INSIDE the timed
 region is not guarded: the run ends non-zero with no line.
@@ -463,6 +464,19 @@ def main():
         print("BENCH_DETAIL " + json.dumps(full), file=sys.stderr, flush=True)
         write_line(json.dumps(compact(full)))
 
+    if rank == 0:
+        # the headline on record BEFORE any side figure runs (stderr and the detail file; stdout keeps its one line for the end):
+        # should a side figure take the process down instead of raising, the measurement is not lost with it
+        early = record()
+        print("BENCH_HEADLINE " + json.dumps({k: early[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config")}),
+              file=sys.stderr, flush=True)
+        if detail_path != "-":
+            try:
+                os.makedirs(os.path.dirname(detail_path) or ".", exist_ok=True)
+                with open(detail_path, "w") as f:
+                    json.dump(early, f, indent=1)
+            except OSError:
+                pass
     side.watchdog(args.side_timeout, emit)
     B.after_the_timed_region(c, numpy_leg)
     side.disarm()
